@@ -1,0 +1,318 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE.
+
+Development-container only: needs /root/reference (read as text at run time by
+ref_loader.py; nothing of it is stored here).  Fixtures are plain data: inputs,
+expected outputs and per-stage intermediate tables (SURVEY.md section 8(c),
+G1..G7).  Run from anywhere:  python tests/golden/make_golden.py [names...]
+
+All fixtures use the precision dictionary of defaults.py:62-92 unless they say
+otherwise ("prec": "unit_test" -> window_npoints 50, unit_test.py:17-46).
+"""
+import json
+import os
+import sys
+import tempfile
+import time
+import warnings
+
+import numpy
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_loader  # noqa: E402
+
+warnings.simplefilter("ignore")
+deg_to_rad = numpy.pi / 180.0
+
+from params import c_dict, c_dict_2, h_dict_2, hod_dict, hod_dict_2  # noqa: E402
+
+
+def save(name, **arrays):
+    fn = os.path.join(HERE, name + ".npz")
+    numpy.savez_compressed(fn, **arrays)
+    print("wrote", fn, os.path.getsize(fn), "bytes")
+
+
+def stage_tables(h):
+    """Intermediate tables of a reference Halo object (forces lazy init)."""
+    m, c = h.mass, h.cosmo
+    h.power_mm(1.0)
+    out = dict(
+        z=c._redshift, growth=c._growth, chi=c._chi, delta_c=c.delta_c(),
+        delta_v=c.delta_v(), rho_bar=c.rho_bar(), sigma_norm=c._sigma_norm,
+        omega_m=c.omega_m(), ln_mass=m._ln_mass_array, nu=m._nu_array,
+        f_norm=m.f_norm, bias_norm=m.bias_norm, m_star=m.m_star,
+        nu_min=m.nu_min, nu_max=m.nu_max, n_bar=h.n_bar,
+        n_bar_over_rho_bar=h.n_bar_over_rho_bar,
+        ln_k=h._ln_k_array, h_m=h._h_m_spline(h._ln_k_array),
+        pp_mm=h._pp_mm_spline(h._ln_k_array))
+    return out
+
+
+def g1(ns):
+    """unit_test.py HaloTest / MassFunctionTest / CosmologyTestSingleEpoch
+    sample points, computed by the reference as shipped."""
+    k = numpy.logspace(-3, 2, 4)
+    out = {"k": k}
+
+    def grab(tag, h, lin=False):
+        out[tag + "_mm"] = h.power_mm(k)
+        out[tag + "_gm"] = h.power_gm(k)
+        out[tag + "_gg"] = h.power_gg(k)
+        if lin:
+            out[tag + "_lin"] = h.linear_power(k)
+
+    def fresh():
+        cosmo = ns.cosmology.SingleEpoch(0.0, cosmo_dict=c_dict)
+        return ns.halo.Halo(input_hod=ns.hod.HODZheng(hod_dict),
+                            cosmo_single_epoch=cosmo)
+    h = fresh(); grab("base", h, lin=True)
+    h = fresh(); h.set_cosmology(c_dict_2); grab("cosmo2", h, lin=True)
+    h = fresh(); h.set_halo(h_dict_2); grab("halo2", h)
+    h = fresh(); h.set_hod(hod_dict_2); grab("hod2", h)
+    h = fresh(); h.set_redshift(1.0); grab("z1", h, lin=True)
+    # mass function / cosmology sample points (unit_test.py:131-144, 267-279)
+    cosmo = ns.cosmology.SingleEpoch(0.0, cosmo_dict=c_dict)
+    mass = ns.mass_function.MassFunction(cosmo_single_epoch=cosmo)
+    marr = numpy.logspace(9, 16, 4)
+    out["mass_arr"] = marr
+    out["mf_nu"] = mass.nu(marr)
+    out["mf_f_m"] = mass.f_m(marr)
+    out["mf_bias_m"] = mass.bias_m(marr)
+    out["cosmo_scalars"] = numpy.array([
+        cosmo.comoving_distance(), cosmo.growth_factor(), cosmo.omega_m(),
+        cosmo.omega_l(), cosmo.delta_c(), cosmo.delta_v(), cosmo.sigma_r(8.0)])
+    zh = ns.hod.HODZheng(hod_dict)
+    out["hod_first"] = zh.first_moment(marr)
+    out["hod_second"] = zh.second_moment(marr)
+    save("g1_unit_points", **out)
+
+
+def g2(ns):
+    """C1: WMAP7 defaults, z=0, 256 log-spaced k (+ out-of-range probes)."""
+    h = ns.halo.Halo(0.0)
+    k = numpy.logspace(-3, 2, 256)
+    kp = numpy.array([1e-5, 5e-4, 9.999e-4, 0.001, numpy.exp(numpy.log(0.001)),
+                      100.0, numpy.exp(numpy.log(100.0)), 100.0000001, 250.0])
+    t0 = time.time()
+    pmm = h.power_mm(k)
+    t_mm = time.time() - t0
+    st = stage_tables(h)
+    save("g2_wmap7_z0", k=k, lin=h.linear_power(k), mm=pmm, gm=h.power_gm(k),
+         gg=h.power_gg(k), k_probe=kp, lin_probe=h.linear_power(kp),
+         mm_probe=h.power_mm(kp), gm_probe=h.power_gm(kp),
+         gg_probe=h.power_gg(kp), h_g=h._h_g_spline(h._ln_k_array),
+         pp_gm=h._pp_gm_spline(h._ln_k_array),
+         pp_gg=h._pp_gg_spline(h._ln_k_array), t_first_mm=t_mm,
+         **{"st_" + a: b for a, b in st.items()})
+
+
+def g3(ns):
+    """Per-stage intermediates at z in {0, 0.5, 1.0, 1.5} (WMAP7, ST)."""
+    out = {}
+    times = []
+    for z in (0.0, 0.5, 1.0, 1.5):
+        t0 = time.time()
+        h = ns.halo.Halo(z)
+        st = stage_tables(h)
+        times.append(time.time() - t0)
+        for a, b in st.items():
+            out["z%03d_%s" % (round(z * 100), a)] = b
+        # the sigma(R) primitive on a few scales
+        R = numpy.array([0.05, 0.5, 8.0, 50.0, 150.0])
+        out["z%03d_sigma_R" % round(z * 100)] = numpy.array(
+            [h.cosmo.sigma_r(r) for r in R])
+        out["R"] = R
+    out["times"] = numpy.array(times)
+    save("g3_stages", **out)
+
+
+def g4(ns):
+    """C2: P_mm on z = linspace(0, 1.5, 64) x a 257-point subsample of
+    k = logspace(-3, 2, 4096)."""
+    k_full = numpy.logspace(-3, 2, 4096)
+    idx = numpy.unique(numpy.concatenate([numpy.arange(0, 4096, 16), [4095]]))
+    z = numpy.linspace(0.0, 1.5, 64)
+    h = ns.halo.Halo(0.0)
+    out = numpy.empty((z.size, idx.size))
+    times = numpy.empty(z.size)
+    for i, zz in enumerate(z):
+        t0 = time.time()
+        h.set_redshift(zz)
+        out[i] = h.power_mm(k_full)[idx]
+        times[i] = time.time() - t0
+    save("g4_pmm_grid", z=z, k_idx=idx, k=k_full[idx], mm=out, times=times)
+
+
+def g5(ns):
+    """C3: Tinker10 mass function + Zheng HOD, P_gm at z in {0, 0.5, 1}."""
+    k = numpy.logspace(-3, 2, 256)
+    out = {"k": k}
+    for z in (0.0, 0.5, 1.0):
+        tag = "z%03d_" % round(z * 100)
+        t0 = time.time()
+        cosmo = ns.cosmology.SingleEpoch(z)
+        mass = ns.mass_function.TinkerMassFunction(z, cosmo)
+        h = ns.halo.Halo(z, ns.hod.HODZheng(ns.defaults.default_hod_dict),
+                         cosmo, mass)
+        out[tag + "gm"] = h.power_gm(k)
+        out[tag + "t_gm"] = time.time() - t0
+        out[tag + "gg"] = h.power_gg(k)
+        out[tag + "mm"] = h.power_mm(k)
+        out[tag + "tinker"] = numpy.array([
+            mass.delta_v, float(mass._alpha()), float(mass._beta()),
+            float(mass._gamma()), float(mass._phi()), float(mass._eta()),
+            mass.bias_norm])
+        out[tag + "ln_mass"] = mass._ln_mass_array
+        out[tag + "nu"] = mass._nu_array
+        out[tag + "n_bar"] = h.n_bar
+        lk = h._ln_k_array
+        out[tag + "h_m"] = h._h_m_spline(lk)
+        out[tag + "h_g"] = h._h_g_spline(lk)
+        out[tag + "pp_gm"] = h._pp_gm_spline(lk)
+        out[tag + "pp_gg"] = h._pp_gg_spline(lk)
+        out[tag + "pp_mm"] = h._pp_mm_spline(lk)
+    save("g5_tinker_zheng", **out)
+
+
+def _projection(ns, ggl):
+    cosmo_multi = ns.cosmology.MultiEpoch(0.0, 5.0)
+    lens = ns.kernel.dNdzMagLim(0.0, 2.0, 2.0, 0.3, 2.0)
+    wa = ns.kernel.WindowFunctionGalaxy(lens, cosmo_multi)
+    if ggl:
+        src = ns.kernel.dNdzGaussian(0.0, 2.0, 1.0, 0.2)
+        wb = ns.kernel.WindowFunctionConvergence(src, cosmo_multi)
+        K = ns.kernel.GalaxyGalaxyLensingKernel
+    else:
+        wb = ns.kernel.WindowFunctionGalaxy(
+            ns.kernel.dNdzMagLim(0.0, 2.0, 2.0, 0.3, 2.0), cosmo_multi)
+        K = ns.kernel.Kernel
+    kern = K(1e-6 * deg_to_rad, 100.0 * deg_to_rad, wa, wb, cosmo_multi)
+    return cosmo_multi, kern
+
+
+def _kernel_tables(kern):
+    kern.kernel(0.0)
+    a, b = kern.window_function_a, kern.window_function_b
+    a.window_function(1.0); b.window_function(1.0)
+    return dict(
+        z_bar=kern.z_bar, chi_min=kern.chi_min, chi_max=kern.chi_max,
+        ln_ktheta=kern._ln_ktheta_array,
+        kernel=numpy.asarray(kern._kernel_array, dtype=float),
+        wa_chi=a._chi_array, wa=numpy.asarray(a._wf_array, dtype=float),
+        wb_chi=b._chi_array, wb=numpy.asarray(b._wf_array, dtype=float),
+        wa_norm=a._redshift_dist.norm, wb_norm=b._redshift_dist.norm,
+        wa_zmax=a.z_max, wb_zmax=b.z_max,
+        me_z=kern.cosmo._z_array, me_chi=kern.cosmo._chi_array,
+        me_growth=kern.cosmo._growth_array)
+
+
+def g6(ns):
+    """C4: clustering-clustering, gal x gal windows: K[50], z_bar, w(theta) at 33
+    theta in [1e-3, 1] deg and C_l at 33 l in [10, 1e4], for power_gg and power_mm."""
+    cm, kern = _projection(ns, ggl=False)
+    out = _kernel_tables(kern)
+    theta = numpy.logspace(-3, 0, 33) * deg_to_rad
+    ell = numpy.logspace(1, 4, 33)
+    lnkt = numpy.linspace(kern.ln_ktheta_min - 1.0, kern.ln_ktheta_max + 0.5, 64)
+    out.update(theta=theta, ell=ell, lnkt_probe=lnkt,
+               kernel_probe=kern.kernel(lnkt))
+    for ps in ("power_gg", "power_mm"):
+        h = ns.halo.Halo(0.0)
+        t0 = time.time()
+        corr = ns.correlation.Correlation(0.001, 1.0, kern, input_halo=h,
+                                          power_spec=ps)
+        out["w_" + ps] = corr.correlation(theta)
+        out["t_w_" + ps] = time.time() - t0
+        out["theta_bins"] = corr.theta_array
+        out["D_z"] = corr.D_z
+        t0 = time.time()
+        cf = ns.correlation.CorrelationFourier(10, 1e4, kern, input_halo=h,
+                                               powSpec=ps)
+        out["cl_" + ps] = cf.correlation(ell)
+        out["t_cl_" + ps] = time.time() - t0
+    save("g6_limber_galgal", **out)
+
+
+def g7(ns):
+    """C5: J2 kernel (galaxy x convergence) + HaloFit P(k); w_GGL at 33 theta."""
+    cm, kern = _projection(ns, ggl=True)
+    out = _kernel_tables(kern)
+    theta = numpy.logspace(-3, 0, 33) * deg_to_rad
+    ell = numpy.logspace(1, 4, 33)
+    k = numpy.logspace(-3, 2, 256)
+    hf = ns.halo.HaloFit(0.0)
+    out.update(theta=theta, ell=ell, k=k, hf_mm_z0=hf.power_mm(k),
+               hf_gm_z0=hf.power_gm(k), hf_gg_z0=hf.power_gg(k),
+               hf_z0_pars=numpy.array([hf._k_s, hf._n_eff, hf._C, hf._a_n,
+                                       hf._b_n, hf._c_n, hf._gamma_n,
+                                       hf._alpha_n, hf._beta_n, hf._nu_n]),
+               hf_z0_ln_sigma2=hf._ln_sigma2_array)
+    corr = ns.correlation.Correlation(0.001, 1.0, kern, input_halo=hf,
+                                      power_spec="power_gm")
+    t0 = time.time()
+    out["w_ggl"] = corr.correlation(theta)
+    out["t_w_ggl"] = time.time() - t0
+    out["D_z"] = corr.D_z
+    out["hf_zbar_pars"] = numpy.array([hf._k_s, hf._n_eff, hf._C, hf._a_n,
+                                       hf._b_n, hf._c_n, hf._gamma_n,
+                                       hf._alpha_n, hf._beta_n, hf._nu_n])
+    out["hf_gm_zbar"] = hf.power_gm(k)
+    cf = ns.correlation.CorrelationFourier(10, 1e4, kern, input_halo=hf,
+                                           powSpec="power_gm")
+    out["cl_ggl"] = cf.correlation(ell)
+    save("g7_ggl_halofit", **out)
+
+
+def pins():
+    """Known-answer literals held by the reference's own tests (unit_test.py),
+    restricted to the classes that pass against the shipped code."""
+    data = {
+        "source": "unit_test.py:346-407 (HaloTest), 267-303 (MassFunctionTest), "
+                  "183-188 (test_linear_power), 328-335 (HODTest)",
+        "k": "logspace(-3, 2, 4)", "places_halo": 4, "places_cosmo": 7,
+        "places_mass": 7,
+        "HaloTest.test_halo": {
+            "ln_power_mm": [8.34446, 9.53808, 5.59943, -2.80473],
+            "ln_power_gm": [8.24115, 9.47902, 5.19533, -0.71614],
+            "ln_power_gg": [8.15671, 9.42601, 4.59654, -0.49075]},
+        "HaloTest.test_set_cosmology": {
+            "ln_linear_power": [5.16650870, 8.11613036, 3.69335247, -5.84391743],
+            "ln_power_mm": [6.61709, 8.27371, 5.68236, -3.03705],
+            "ln_power_gm": [5.91437, 7.94417, 4.95208, -1.46860],
+            "ln_power_gg": [5.28356, 7.64378, 4.21950, -1.35347]},
+        "HaloTest.test_set_halo": {
+            "ln_power_mm": [8.41964, 9.5614, 5.76978, -2.86396],
+            "ln_power_gm": [8.27334, 9.47549, 5.37421, -0.73567],
+            "ln_power_gg": [8.15326, 9.39862, 4.82581, -0.43823]},
+        "HaloTest.test_set_hod": {
+            "ln_power_gm": [8.84246, 9.98600, 6.68634, 1.20497],
+            "ln_power_gg": [9.17274, 10.38198, 6.26546, -0.14734]},
+    }
+    fn = os.path.join(HERE, "reference_pins.json")
+    with open(fn, "w") as f:
+        json.dump(data, f, indent=1)
+    print("wrote", fn)
+
+
+def main():
+    names = sys.argv[1:] or ["pins", "g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    ns = ref_loader.load()
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)          # the reference's Kernel.__init__ writes files to CWD
+        try:
+            for n in names:
+                t0 = time.time()
+                if n == "pins":
+                    pins()
+                else:
+                    globals()[n](ns)
+                print("  %s: %.1f s" % (n, time.time() - t0))
+        finally:
+            os.chdir(cwd)
+
+
+if __name__ == "__main__":
+    main()
