@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Benchmark of the halo-model P(k, z) hot path on 1..8 MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one full pass of the hot path over BASELINE.json's configs[1]:
+Stage K (every table of the 64 redshifts: sigma_8 normalisation, mass-limit search,
+nu table, splines, normalisations, n_bar, the 50-knot 2-halo / 1-halo integrals)
+followed by Stage E (P_mm on the 4096 x 64 (k, z) grid), with k resident in HBM
+and, for N > 1, the all-gather that re-assembles the grid on every rank.  Rank 0
+prints ONE JSON line (contract in the task description) carrying `roofline`
+(Stage-E kernel, HIP events on the kernel's own stream) and `cpu_baseline` (the
+NumPy oracle = a port of the reference's algorithm, timed on this box's host
+cores on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+NK, NZ, Z_MAX = 4096, 64, 1.5
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 measured copy)
+
+
+def cpu_baseline(which, mass_function, sample_z):
+    """Time the oracle (port of the reference's CPU algorithm) on `sample_z`
+    redshifts x the 4096-point k grid; one host thread."""
+    from oracle import chomp_oracle as o
+    k = numpy.logspace(-3, 2, NK)
+    fam = {"power_mm": ("mm",), "power_gm": ("gm",)}[which]
+    t0 = time.perf_counter()
+    for z in sample_z:
+        e = o.epoch(None, float(z))
+        m = o.mass_table(e, kind=mass_function)
+        t = o.halo_table(e, m, families=fam)
+        o.halo_power(t, fam[0], k)
+    dt = time.perf_counter() - t0
+    return {"value": len(sample_z) * NK / dt, "unit": "samples/s", "cores": 1,
+            "kind": "port",
+            "sample": "%d of the %d redshifts (z=%s) x %d k, oracle/chomp_oracle.py "
+                      "(NumPy/SciPy restatement of the reference, adaptive Romberg), "
+                      "%.1f s" % (len(sample_z), NZ,
+                                  ",".join("%.3g" % z for z in sample_z), NK, dt),
+            "host_cores_available": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3"])
+    ap.add_argument("--roofline-nk", type=int, default=1 << 20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node N"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from chomp_amd import grid
+    which = "power_mm" if args.workload == "c2" else "power_gm"
+    mf = "st" if args.workload == "c2" else "tinker"
+    # weak scaling: every GPU carries configs[1]'s 64 redshift rows, so the global
+    # grid is 4096 k x (64 N) z; at N = 1 this is exactly configs[1].
+    nz = NZ * world
+    z = numpy.linspace(0.0, Z_MAX, nz)
+    stream = torch.cuda.current_stream(dev)
+    hg = grid.HaloGrid(z, mass_function=mf, device=local, stream=stream.cuda_stream,
+                       rank=rank, world=world)
+    k = torch.logspace(-3, 2, NK, dtype=torch.float64, device=dev)
+
+    def step():
+        hg.setup(which)                 # Stage K, this rank's redshifts
+        return hg.power_all(which, k)   # Stage E + all-gather
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        out = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert out.shape == (nz, NK) and bool(torch.isfinite(out).all())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = nz * NK * args.steps / elapsed
+
+    # ---- stage split and roofline (rank 0's shard; HIP events on the kernel stream)
+    def timed(fn, reps):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn()
+        torch.cuda.synchronize(dev)
+        ev0.record(stream)
+        for _ in range(reps):
+            fn()
+        ev1.record(stream)
+        torch.cuda.synchronize(dev)
+        return ev0.elapsed_time(ev1) / reps * 1e-3
+
+    n_local = len(hg.idx)
+    t_setup = timed(lambda: hg.setup(which), max(3, args.steps // 2))
+    buf = torch.empty((n_local, NK), dtype=torch.float64, device=dev)
+    t_e_c2 = timed(lambda: hg.power(which, k, out=buf), 50)
+    nk_big = args.roofline_nk
+    k_big = torch.logspace(-3, 2, nk_big, dtype=torch.float64, device=dev)
+    buf_big = torch.empty((n_local, nk_big), dtype=torch.float64, device=dev)
+    t_e_big = timed(lambda: hg.power(which, k_big, out=buf_big), 10)
+    bytes_big = 16.0 * n_local * nk_big      # 8 B k in + 8 B P out / sample
+    bytes_c2 = 16.0 * n_local * NK
+    roof = {"bound": "hbm", "kernel": "k_power (Stage E)",
+            "workload": "%d k x %d z (enlarged grid, SURVEY 8(d))" % (nk_big, n_local),
+            "achieved": bytes_big / t_e_big / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": bytes_big / t_e_big / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "bytes_per_launch": bytes_big, "avg_launch_us": t_e_big * 1e6,
+            "c2_grid": {"achieved": bytes_c2 / t_e_c2 / 1e9, "avg_launch_us": t_e_c2 * 1e6,
+                        "bytes_per_launch": bytes_c2},
+            "samples_per_s_stage_e_only": n_local * nk_big / t_e_big}
+    del buf_big, k_big
+
+    if rank == 0:
+        res = {
+            "metric": "halo-model P(k,z) samples/sec (Stage K set-up + Stage E grid)",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[%d]: %s, WMAP7, %s mass function, %d k "
+                                   "(logspace -3..2) x %d z (linspace 0..%.1f)"
+                                   % (1 if args.workload == "c2" else 2, which,
+                                      "Sheth-Tormen" if mf == "st" else "Tinker10 + Zheng HOD",
+                                      NK, nz, Z_MAX),
+                       "nk": NK, "nz": nz, "sharding": "z interleaved over %d rank(s), "
+                                                       "one all-gather" % world},
+            "stage_split_rank0": {"stage_k_ms": t_setup * 1e3, "stage_e_ms": t_e_c2 * 1e3,
+                                  "n_local_z": n_local},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline:
+            z1 = numpy.linspace(0.0, Z_MAX, NZ)
+            sz = z1[::8] if args.workload == "c2" else z1[[0, 21, 42, 63]]
+            res["cpu_baseline"] = cpu_baseline(which, mf, sz)
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

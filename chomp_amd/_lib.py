@@ -1,0 +1,435 @@
+"""ctypes binding of libchomp_mi355x.so (include/chomp_mi355x.h).
+
+The HIP library is the only compute path of this package: if it cannot be loaded
+(or built in-tree with hipcc) importing the binding raises -- there is no CPU
+fallback.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+import numpy
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(HERE, "libchomp_mi355x.so")
+
+OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_SCOPE = 0, -1, -2, -3, -4
+HOST, DEVICE = 0, 1
+MF_ST, MF_TINKER = 0, 1
+T_H_M, T_PP_MM, T_H_G, T_PP_GM, T_PP_GG = 1, 2, 4, 8, 16
+FAM_MM, FAM_GM, FAM_GG = T_H_M | T_PP_MM, T_H_M | T_H_G | T_PP_GM, T_H_G | T_PP_GG
+P_LIN, P_MM, P_GM, P_GG, P_HALOFIT = 0, 1, 2, 3, 16
+DNDZ_MAGLIM, DNDZ_GAUSSIAN = 0, 1
+WINDOW_GALAXY, WINDOW_CONVERGENCE = 0, 1
+
+SC = {name: i for i, name in enumerate([
+    "z", "chi", "growth", "omega_m", "omega_l", "delta_c", "delta_v", "rho_bar",
+    "sigma_norm", "ln_mass_min", "ln_mass_max", "nu_min", "nu_max", "m_star",
+    "f_norm", "bias_norm", "n_bar", "n_bar_over_rho_bar", "n_search",
+    "mf_delta_v", "t_alpha", "t_beta", "t_gamma", "t_phi", "t_eta",
+    "growth_norm", "delta_H", "hf_k_s", "hf_n_eff", "hf_C"])}
+SC_COUNT = 30
+TAB = {"ln_mass": 0, "nu": 1, "h_m": 2, "pp_mm": 3, "h_g": 4, "pp_gm": 5,
+       "pp_gg": 6, "levels": 7, "hf_ln_sigma2": 8}
+EV = {"nu_of_mass": 0, "ln_mass_of_nu": 1, "f_nu": 2, "bias_nu": 3,
+      "hod_first": 4, "hod_second": 5, "hod_central": 6, "hod_satellite": 7,
+      "virial_radius": 8, "concentration": 9, "delta_k": 10}
+HF_COUNT = 14
+KI = {name: i for i, name in enumerate([
+    "z_bar", "chi_min", "chi_max", "z_min", "z_max", "D_zbar", "norm_a", "norm_b"])}
+KI_COUNT = 8
+KTAB = {"ln_ktheta": 0, "kernel": 1, "wa_chi": 2, "wa": 3, "wb_chi": 4, "wb": 5,
+        "me_z": 6, "me_chi": 7, "me_growth": 8, "levels": 9}
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+
+
+class Cosmo(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_double) for n in (
+        "omega_m0", "omega_b0", "omega_l0", "omega_r0", "cmb_temp", "h",
+        "sigma_8", "n_scalar", "w0", "wa")]
+
+
+class HaloPar(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_double) for n in (
+        "stq", "st_little_a", "c0", "beta", "alpha", "delta_v")]
+
+
+class HodPar(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_double) for n in (
+        "log_M_min", "sigma", "log_M_0", "log_M_1p", "alpha")]
+
+
+class Config(ctypes.Structure):
+    _fields_ = ([(n, ctypes.c_double) for n in (
+        "k_min", "k_max", "mass_min", "mass_max", "corr_precision",
+        "cosmo_precision", "dNdz_precision", "halo_precision",
+        "kernel_precision", "mass_precision", "window_precision",
+        "global_precision")] +
+        [(n, ctypes.c_int) for n in (
+            "corr_npoints", "cosmo_npoints", "halo_npoints", "kernel_npoints",
+            "kernel_bessel_limit", "mass_npoints", "window_npoints", "divmax")])
+
+
+class Dndz(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int), ("pad_", ctypes.c_int),
+                ("z_min", ctypes.c_double), ("z_max", ctypes.c_double),
+                ("p", ctypes.c_double * 4)]
+
+
+class Window(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int), ("pad_", ctypes.c_int), ("dist", Dndz)]
+
+
+EXPORTS = [
+    "chomp_default_config", "chomp_ctx_create", "chomp_ctx_destroy",
+    "chomp_last_error", "chomp_sync", "chomp_epochs_set", "chomp_mass_setup",
+    "chomp_halo_setup", "chomp_halofit_setup", "chomp_power", "chomp_power_range",
+    "chomp_sigma_r", "chomp_y_nfw", "chomp_get_scalars", "chomp_get_table",
+    "chomp_eval", "chomp_halofit_get", "chomp_halofit_put",
+    "chomp_kernel_setup", "chomp_kernel_info", "chomp_kernel_table",
+    "chomp_kernel_eval", "chomp_window_eval", "chomp_wtheta", "chomp_cell",
+]
+
+
+def sources():
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))
+            if f.endswith((".hip", ".h", ".inc"))] + [
+        os.path.join(HERE, "..", "include", "chomp_mi355x.h")]
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a
+    GPU).  Rebuilds when a source is newer than the .so."""
+    if not force and os.path.exists(LIB_PATH):
+        so_t = os.path.getmtime(LIB_PATH)
+        if all(os.path.getmtime(s) <= so_t for s in sources()):
+            return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-o", LIB_PATH, os.path.join(CSRC, "chomp_capi.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return LIB_PATH
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """Load (building if necessary) the HIP library.  Raises if impossible."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            try:
+                build()
+            except Exception as exc:   # noqa: BLE001
+                raise ImportError(
+                    "chomp_amd: libchomp_mi355x.so is missing and could not be "
+                    "built with hipcc (%s). This package has no CPU fallback."
+                    % exc) from exc
+        L = ctypes.CDLL(LIB_PATH)
+        for name in EXPORTS:
+            if not hasattr(L, name):
+                raise ImportError("chomp_amd: %s lacks symbol %s" % (LIB_PATH, name))
+        vp, sz, i, d = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_double
+        L.chomp_default_config.argtypes = [ctypes.POINTER(Config)]
+        L.chomp_default_config.restype = None
+        L.chomp_ctx_create.argtypes = [ctypes.POINTER(Config), i, vp,
+                                       ctypes.POINTER(vp)]
+        L.chomp_ctx_destroy.argtypes = [vp]
+        L.chomp_ctx_destroy.restype = None
+        L.chomp_last_error.argtypes = [vp]
+        L.chomp_last_error.restype = ctypes.c_char_p
+        L.chomp_sync.argtypes = [vp]
+        L.chomp_epochs_set.argtypes = [vp, sz, ctypes.POINTER(Cosmo), c_double_p]
+        L.chomp_mass_setup.argtypes = [vp, ctypes.POINTER(HaloPar), i]
+        L.chomp_halo_setup.argtypes = [vp, ctypes.POINTER(HaloPar),
+                                       ctypes.POINTER(HodPar), ctypes.c_uint]
+        L.chomp_halofit_setup.argtypes = [vp, sz, sz, d, d, d, d, d]
+        L.chomp_power.argtypes = [vp, i, vp, sz, vp, i]
+        L.chomp_power_range.argtypes = [vp, i, sz, sz, vp, sz, vp, i]
+        L.chomp_sigma_r.argtypes = [vp, sz, c_double_p, sz, c_double_p]
+        L.chomp_y_nfw.argtypes = [vp, sz, c_double_p, c_double_p, sz, c_double_p]
+        L.chomp_get_scalars.argtypes = [vp, sz, c_double_p]
+        L.chomp_get_table.argtypes = [vp, sz, i, c_double_p, sz]
+        L.chomp_eval.argtypes = [vp, sz, i, vp, sz, vp, i]
+        L.chomp_halofit_get.argtypes = [vp, sz, c_double_p]
+        L.chomp_halofit_put.argtypes = [vp, sz, c_double_p]
+        L.chomp_kernel_setup.argtypes = [vp, ctypes.POINTER(Cosmo), d, d, d, d,
+                                         ctypes.POINTER(Window),
+                                         ctypes.POINTER(Window), i]
+        L.chomp_kernel_info.argtypes = [vp, c_double_p]
+        L.chomp_kernel_table.argtypes = [vp, i, c_double_p, sz]
+        L.chomp_kernel_eval.argtypes = [vp, vp, sz, vp, i]
+        L.chomp_window_eval.argtypes = [vp, i, vp, sz, vp, i]
+        L.chomp_wtheta.argtypes = [vp, i, sz, d, d, d, vp, sz, vp, i]
+        L.chomp_cell.argtypes = [vp, i, sz, d, vp, sz, vp, i]
+        for name in EXPORTS:
+            if name not in ("chomp_default_config", "chomp_ctx_destroy",
+                            "chomp_last_error"):
+                getattr(L, name).restype = i
+        _lib = L
+        return _lib
+
+
+def current_device():
+    """HIP ordinal for new contexts: CHOMP_DEVICE, else LOCAL_RANK (one process
+    per GPU under torch.distributed.run), else 0."""
+    for key in ("CHOMP_DEVICE", "LOCAL_RANK"):
+        if key in os.environ:
+            return int(os.environ[key])
+    return 0
+
+
+class ChompError(RuntimeError):
+    pass
+
+
+class ChompScopeError(NotImplementedError):
+    """Feature of the reference that is outside the accelerated hot path."""
+
+
+def make_config(limits, precision):
+    """Snapshot defaults.default_limits / default_precision into a Config."""
+    c = Config()
+    for k in ("k_min", "k_max", "mass_min", "mass_max"):
+        setattr(c, k, float(limits[k]))
+    for k in ("corr_precision", "cosmo_precision", "dNdz_precision",
+              "halo_precision", "kernel_precision", "mass_precision",
+              "window_precision", "global_precision"):
+        setattr(c, k, float(precision[k]))
+    for k in ("corr_npoints", "cosmo_npoints", "halo_npoints", "kernel_npoints",
+              "kernel_bessel_limit", "mass_npoints", "window_npoints", "divmax"):
+        setattr(c, k, int(precision[k]))
+    return c
+
+
+def cosmo_struct(cosmo_dict):
+    """KeyError on a missing key, like the reference (cosmology.py:49-58)."""
+    return Cosmo(*[float(cosmo_dict[k]) for k in (
+        "omega_m0", "omega_b0", "omega_l0", "omega_r0", "cmb_temp", "h",
+        "sigma_8", "n_scalar", "w0", "wa")])
+
+
+def halo_struct(halo_dict):
+    return HaloPar(*[float(halo_dict[k]) for k in (
+        "stq", "st_little_a", "c0", "beta", "alpha", "delta_v")])
+
+
+def hod_struct(hod):
+    return HodPar(float(hod.log_M_min), float(hod.sigma), float(hod.log_M_0),
+                  float(hod.log_M_1p), float(hod.alpha))
+
+
+def _is_torch(x):
+    return type(x).__module__.split(".")[0] == "torch"
+
+
+class Context(object):
+    """Owns one chomp_ctx.  device: HIP ordinal; stream: raw hipStream_t or None."""
+
+    def __init__(self, config, device=0, stream=None):
+        self._L = lib()
+        self._h = ctypes.c_void_p()
+        self.config = config
+        self.device = int(device)
+        rc = self._L.chomp_ctx_create(ctypes.byref(config), self.device,
+                                      ctypes.c_void_p(stream or 0),
+                                      ctypes.byref(self._h))
+        if rc != OK:
+            raise ChompError("chomp_ctx_create failed (%d): no usable MI355X / HIP "
+                             "device; chomp_amd has no CPU fallback" % rc)
+        self.n_epoch = 0
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.chomp_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001
+            pass
+
+    def _check(self, rc):
+        if rc == OK:
+            return
+        msg = self._L.chomp_last_error(self._h).decode()
+        if rc == ERR_SCOPE:
+            raise ChompScopeError(msg)
+        if rc == ERR_ARG:
+            raise ValueError(msg)
+        raise ChompError("%s (code %d)" % (msg, rc))
+
+    # -- Stage K -------------------------------------------------------------
+    def epochs_set(self, cosmo_dicts, z):
+        z = numpy.ascontiguousarray(numpy.atleast_1d(z), dtype=numpy.float64)
+        n = z.size
+        if isinstance(cosmo_dicts, dict):
+            cosmo_dicts = [cosmo_dicts] * n
+        arr = (Cosmo * n)(*[cosmo_struct(c) for c in cosmo_dicts])
+        self._check(self._L.chomp_epochs_set(self._h, n, arr,
+                                             z.ctypes.data_as(c_double_p)))
+        self.n_epoch = n
+
+    def mass_setup(self, halo_dicts, mf_kind):
+        n = self.n_epoch
+        if isinstance(halo_dicts, dict):
+            halo_dicts = [halo_dicts] * n
+        arr = (HaloPar * n)(*[halo_struct(h) for h in halo_dicts])
+        self._check(self._L.chomp_mass_setup(self._h, arr, int(mf_kind)))
+
+    def halo_setup(self, profile_dicts, hods, tables):
+        n = self.n_epoch
+        if isinstance(profile_dicts, dict):
+            profile_dicts = [profile_dicts] * n
+        if not isinstance(hods, (list, tuple)):
+            hods = [hods] * n
+        pa = (HaloPar * n)(*[halo_struct(h) for h in profile_dicts])
+        ha = (HodPar * n)(*[hod_struct(h) for h in hods])
+        self._check(self._L.chomp_halo_setup(self._h, pa, ha, int(tables)))
+
+    def halofit_setup(self, dst, src, f1, f2, f3, omega_l, w):
+        self._check(self._L.chomp_halofit_setup(self._h, dst, src, f1, f2, f3,
+                                                omega_l, w))
+
+    # -- Stage E -------------------------------------------------------------
+    def power(self, which, k, epoch0=0, n=None, out=None):
+        """k: numpy array (host path) or torch cuda tensor (device path, async on
+        the context's stream).  Returns [n, nk] in the same kind of container."""
+        n = self.n_epoch - epoch0 if n is None else n
+        if _is_torch(k):
+            import torch
+            assert k.is_cuda and k.dtype == torch.float64 and k.is_contiguous()
+            if out is None:
+                out = torch.empty((n, k.numel()), dtype=torch.float64, device=k.device)
+            self._check(self._L.chomp_power_range(
+                self._h, which, epoch0, n, ctypes.c_void_p(k.data_ptr()), k.numel(),
+                ctypes.c_void_p(out.data_ptr()), DEVICE))
+            return out
+        k = numpy.ascontiguousarray(k, dtype=numpy.float64).ravel()
+        if out is None:
+            out = numpy.empty((n, k.size), dtype=numpy.float64)
+        if k.size:
+            self._check(self._L.chomp_power_range(
+                self._h, which, epoch0, n, ctypes.c_void_p(k.ctypes.data), k.size,
+                ctypes.c_void_p(out.ctypes.data), HOST))
+        return out
+
+    def sigma_r(self, epoch, scale):
+        s = numpy.ascontiguousarray(numpy.atleast_1d(scale), dtype=numpy.float64)
+        out = numpy.empty_like(s)
+        self._check(self._L.chomp_sigma_r(self._h, epoch, s.ctypes.data_as(c_double_p),
+                                          s.size, out.ctypes.data_as(c_double_p)))
+        return out
+
+    def y_nfw(self, epoch, ln_k, mass):
+        a, b = numpy.broadcast_arrays(numpy.asarray(ln_k, dtype=numpy.float64),
+                                      numpy.asarray(mass, dtype=numpy.float64))
+        a = numpy.ascontiguousarray(a).ravel()
+        b = numpy.ascontiguousarray(b).ravel()
+        out = numpy.empty_like(a)
+        self._check(self._L.chomp_y_nfw(self._h, epoch, a.ctypes.data_as(c_double_p),
+                                        b.ctypes.data_as(c_double_p), a.size,
+                                        out.ctypes.data_as(c_double_p)))
+        return out
+
+    def scalars(self, epoch=0):
+        out = numpy.empty(SC_COUNT)
+        self._check(self._L.chomp_get_scalars(self._h, epoch,
+                                              out.ctypes.data_as(c_double_p)))
+        return {name: out[i] for name, i in SC.items()}
+
+    def table(self, name, epoch=0):
+        cfg = self.config
+        n = {"ln_mass": cfg.mass_npoints, "nu": cfg.mass_npoints,
+             "levels": 5 * cfg.halo_npoints}.get(name, cfg.halo_npoints)
+        out = numpy.empty(n)
+        self._check(self._L.chomp_get_table(self._h, epoch, TAB[name],
+                                            out.ctypes.data_as(c_double_p), n))
+        return out
+
+    def eval(self, what, x, epoch=0):
+        """Element-wise lookup; x numpy (any shape) or torch cuda tensor."""
+        if _is_torch(x):
+            return self._map1(self._L.chomp_eval, x, epoch, EV[what])
+        xa = numpy.asarray(x, dtype=numpy.float64)
+        out = self._map1(self._L.chomp_eval, numpy.ascontiguousarray(xa).ravel(),
+                         epoch, EV[what])
+        return out.reshape(xa.shape)
+
+    def halofit_get(self, epoch=0):
+        out = numpy.empty(HF_COUNT)
+        self._check(self._L.chomp_halofit_get(self._h, epoch,
+                                              out.ctypes.data_as(c_double_p)))
+        return out
+
+    def halofit_put(self, coef, epoch=0):
+        c = numpy.ascontiguousarray(coef, dtype=numpy.float64)
+        assert c.size == HF_COUNT
+        self._check(self._L.chomp_halofit_put(self._h, epoch,
+                                              c.ctypes.data_as(c_double_p)))
+
+    def sync(self):
+        self._check(self._L.chomp_sync(self._h))
+
+    # -- projection ------------------------------------------------------------
+    def kernel_setup(self, cosmo_dict, me_z_min, me_z_max, ktheta_min, ktheta_max,
+                     wa, wb, bessel_order):
+        c = cosmo_struct(cosmo_dict)
+        self._check(self._L.chomp_kernel_setup(
+            self._h, ctypes.byref(c), me_z_min, me_z_max, ktheta_min, ktheta_max,
+            ctypes.byref(wa), ctypes.byref(wb), int(bessel_order)))
+
+    def kernel_info(self):
+        out = numpy.empty(KI_COUNT)
+        self._check(self._L.chomp_kernel_info(self._h, out.ctypes.data_as(c_double_p)))
+        return {name: out[i] for name, i in KI.items()}
+
+    def kernel_table(self, name):
+        cfg = self.config
+        n = {"ln_ktheta": cfg.kernel_npoints, "kernel": cfg.kernel_npoints,
+             "levels": cfg.kernel_npoints, "me_z": cfg.cosmo_npoints,
+             "me_chi": cfg.cosmo_npoints, "me_growth": cfg.cosmo_npoints}.get(
+                 name, cfg.window_npoints)
+        out = numpy.empty(n)
+        self._check(self._L.chomp_kernel_table(self._h, KTAB[name],
+                                               out.ctypes.data_as(c_double_p), n))
+        return out
+
+    def _map1(self, fn, x, *pre):
+        """Apply an (in, n, out, mem) entry point to numpy or torch input."""
+        if _is_torch(x):
+            import torch
+            assert x.is_cuda and x.dtype == torch.float64 and x.is_contiguous()
+            out = torch.empty_like(x)
+            self._check(fn(self._h, *pre, ctypes.c_void_p(x.data_ptr()), x.numel(),
+                           ctypes.c_void_p(out.data_ptr()), DEVICE))
+            return out
+        x = numpy.ascontiguousarray(x, dtype=numpy.float64)
+        out = numpy.empty_like(x)
+        if x.size:
+            self._check(fn(self._h, *pre, ctypes.c_void_p(x.ctypes.data), x.size,
+                           ctypes.c_void_p(out.ctypes.data), HOST))
+        return out
+
+    def kernel_eval(self, ln_ktheta):
+        return self._map1(self._L.chomp_kernel_eval, ln_ktheta)
+
+    def window_eval(self, which, chi):
+        return self._map1(self._L.chomp_window_eval, chi, int(which))
+
+    def wtheta(self, which, epoch, k_min, k_max, D_z, theta):
+        return self._map1(self._L.chomp_wtheta, theta, int(which), epoch,
+                          float(k_min), float(k_max), float(D_z))
+
+    def cell(self, which, epoch, D_z, ell):
+        return self._map1(self._L.chomp_cell, ell, int(which), epoch, float(D_z))

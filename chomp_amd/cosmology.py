@@ -1,0 +1,153 @@
+"""cosmology.SingleEpoch / MultiEpoch with the reference's constructor and method
+surface (cosmology.py:25-728, 731-1164), backed by the HIP library.
+
+Numbers with an integral behind them (chi, sigma_8 normalisation, sigma_r, the
+linear spectrum) come from the device; closed-form background functions of an
+arbitrary redshift argument (E, E0, w) are one-line formulas kept on the host, as
+they are in the reference.
+"""
+import numpy
+
+from . import _lib
+from . import defaults
+
+
+def _context(stream=None, device=None):
+    """New device context snapshotting defaults.default_limits/_precision now."""
+    cfg = _lib.make_config(defaults.default_limits, defaults.default_precision)
+    if device is None:
+        device = _lib.current_device()
+    return _lib.Context(cfg, device=device, stream=stream)
+
+
+class SingleEpoch(object):
+    """cosmology.py:25-728.  ``with_bao=True`` (the E&H wiggle transfer function,
+    cosmology.py:474-538) and w0/wa != -1/0 are outside the accelerated scope."""
+
+    def __init__(self, redshift, cosmo_dict=None, with_bao=False, **kws):
+        if redshift < 0.0:
+            redshift = 0.0
+        self._redshift = redshift
+        if cosmo_dict is None:
+            cosmo_dict = defaults.default_cosmo_dict
+        self.cosmo_dict = cosmo_dict
+        for attr, key in (("_omega_m0", "omega_m0"), ("_omega_b0", "omega_b0"),
+                          ("_omega_l0", "omega_l0"), ("_omega_r0", "omega_r0"),
+                          ("_cmb_temp", "cmb_temp"), ("_h", "h"),
+                          ("_sigma_8", "sigma_8"), ("_n", "n_scalar"),
+                          ("_w0", "w0"), ("_wa", "wa")):
+            setattr(self, attr, cosmo_dict[key])          # KeyError like the reference
+        self.H0 = 100.0 / (2.998 * 10 ** 5)
+        if with_bao:
+            raise _lib.ChompScopeError(
+                "with_bao=True (cosmology.py:474-538) is outside the hot-path scope")
+        self._with_bao = with_bao
+        self._k_min = defaults.default_limits['k_min']
+        self._k_max = defaults.default_limits['k_max']
+        self._ctx = None
+        self._sc = None
+
+    # -- device state ----------------------------------------------------------
+    def _dev(self):
+        if self._ctx is None:
+            self._ctx = _context()
+        if self._sc is None:
+            self._ctx.epochs_set(self.cosmo_dict, [self._redshift])
+            self._sc = self._ctx.scalars(0)
+        return self._ctx
+
+    def _scalar(self, name):
+        self._dev()
+        return float(self._sc[name])
+
+    _chi = property(lambda self: self._scalar("chi"))
+    _growth = property(lambda self: self._scalar("growth"))
+    growth_norm = property(lambda self: self._scalar("growth_norm"))
+    _sigma_norm = property(lambda self: self._scalar("sigma_norm"))
+    delta_H = property(lambda self: self._scalar("delta_H"))
+
+    # -- reference surface -----------------------------------------------------
+    def set_redshift(self, redshift):
+        if redshift != self._redshift:
+            self._redshift = redshift
+            self._sc = None
+
+    def get_cosmology(self):
+        return self.cosmo_dict
+
+    def set_cosmology(self, cosmo_dict, redshift=None):
+        if redshift is None:
+            redshift = self._redshift
+        ctx = self._ctx
+        self.__init__(redshift, cosmo_dict)
+        self._ctx = ctx
+
+    def E0(self, redshift):
+        a = 1.0 / (1.0 + redshift)
+        return (self._omega_l0 + self._omega_m0 / (a * a * a) +
+                self._omega_r0 / (a * a * a * a))
+
+    def E(self, redshift):
+        return 1.0 / (self.H0 * numpy.sqrt(self.E0(redshift)))
+
+    def w(self, redshift):
+        a = 1.0 / (1 + redshift)
+        return self._w0 + self._wa * (1 - a)
+
+    def comoving_distance(self):
+        return self._chi
+
+    def luminosity_distance(self):
+        return (1.0 + self._redshift) * self._chi
+
+    def angular_diameter_distance(self):
+        return self._chi / (1.0 + self._redshift)
+
+    def redshift(self):
+        return self._redshift
+
+    def growth_factor(self):
+        return self._growth
+
+    def omega_m(self):
+        return self._scalar("omega_m")
+
+    def omega_l(self):
+        return self._scalar("omega_l")
+
+    def delta_c(self):
+        return self._scalar("delta_c")
+
+    def delta_v(self):
+        return self._scalar("delta_v")
+
+    def rho_crit(self):
+        return self.rho_bar() / self.omega_m()
+
+    def rho_bar(self):
+        return self._scalar("rho_bar")
+
+    def delta_k(self, k):
+        return self._dev().eval("delta_k", numpy.asarray(k, dtype=numpy.float64))
+
+    def linear_power(self, k):
+        ka = numpy.asarray(k, dtype=numpy.float64)
+        return self._dev().power(_lib.P_LIN, ka, 0, 1).reshape(ka.shape)
+
+    def sigma_r(self, scale):
+        s = numpy.asarray(scale, dtype=numpy.float64)
+        out = self._dev().sigma_r(0, s).reshape(s.shape)
+        return float(out) if s.ndim == 0 else out
+
+    def sigma_m(self, mass):
+        scale = (3.0 * numpy.asarray(mass, dtype=numpy.float64) /
+                 (4.0 * numpy.pi * self.rho_bar())) ** (1.0 / 3.0)
+        return self.sigma_r(scale)
+
+    def nu_r(self, scale):
+        sqrt_nu = self.delta_c() / self.sigma_r(scale)
+        return sqrt_nu * sqrt_nu
+
+    def nu_m(self, mass):
+        sqrt_nu = self.delta_c() / self.sigma_m(mass)
+        return sqrt_nu * sqrt_nu

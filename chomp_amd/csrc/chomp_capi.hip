@@ -1,0 +1,576 @@
+// chomp_capi.hip -- C ABI (include/chomp_mi355x.h) over the HIP kernels.
+// Host side only orchestrates: parameter upload, kernel launches on the context's
+// stream, staging of host buffers.  No numerical work of the hot path runs on the
+// CPU (the only host arithmetic is parameter preparation: the 1.05-step candidate
+// mass sequence, erfinv for HODZheng.first_moment_zero, the Tinker parameter
+// splines of a fixed 9-row table).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstddef>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/chomp_mi355x.h"
+#include "chomp_halo_kernels.h"
+#include "chomp_proj_kernels.h"
+
+using namespace chomp;
+
+struct chomp_ctx {
+  chomp_config cfg;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool owns_stream = false;
+  TabLayout L;
+  std::string err;
+
+  // constant tables
+  SiCiTab* d_sici = nullptr;
+  BesselTab* d_j0 = nullptr;
+  BesselTab* d_j2 = nullptr;
+  TinkerTab* d_tinker = nullptr;
+  double* d_gl16 = nullptr;
+  double* d_cand = nullptr;
+
+  // epoch batch
+  size_t n_epoch = 0, cap_epoch = 0;
+  chomp_cosmo* d_cosmo = nullptr;
+  double* d_z = nullptr;
+  Epoch* d_epochs = nullptr;
+  double* d_search = nullptr;
+  double* d_tab = nullptr;
+  chomp_halo_par* d_mass_par = nullptr;
+  chomp_halo_par* d_profile = nullptr;
+  HodDev* d_hod = nullptr;
+  bool have_epochs = false, have_mass = false, have_halo = false;
+  unsigned fam_mask = 0;          // families (F_* bits) with valid splines
+  std::vector<char> have_halofit;
+
+  // staging for host-pointer calls
+  double* d_stage_in = nullptr;
+  double* d_stage_in2 = nullptr;
+  double* d_stage_out = nullptr;
+  size_t cap_in = 0, cap_in2 = 0, cap_out = 0;
+
+  // projection
+  ProjState proj;
+};
+
+namespace {
+
+int fail(chomp_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg;
+  return code;
+}
+
+#define HIPCHK(call)                                                              \
+  do {                                                                            \
+    hipError_t e_ = (call);                                                       \
+    if (e_ != hipSuccess)                                                         \
+      return fail(ctx, CHOMP_ERR_HIP,                                             \
+                  std::string(#call) + ": " + hipGetErrorString(e_));             \
+  } while (0)
+
+template <class T>
+int ensure(chomp_ctx* ctx, T** p, size_t* cap, size_t n) {
+  if (n <= *cap && *p) return CHOMP_OK;
+  if (*p) HIPCHK(hipFree(*p));
+  *p = nullptr;
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T)));
+  *cap = n;
+  return CHOMP_OK;
+}
+
+// erfinv(y) for y in (-1, 1): Newton on erf/erfc (used once per HOD, hod.py:172-175).
+double erfinv_host(double y) {
+  if (y <= -1.0) return -INFINITY;
+  if (y >= 1.0) return INFINITY;
+  if (y == 0.0) return 0.0;
+  const double a = 0.147;
+  const double ln1 = std::log1p(-y * y);
+  const double t = 2.0 / (M_PI * a) + 0.5 * ln1;
+  double x = std::copysign(std::sqrt(std::sqrt(t * t - ln1 / a) - t), y);
+  for (int it = 0; it < 60; ++it) {
+    // residual computed in the tail-accurate form
+    double r;
+    if (y < -0.5) r = std::erfc(-x) - (1.0 + y);
+    else if (y > 0.5) r = (1.0 - y) - std::erfc(x);
+    else r = std::erf(x) - y;
+    const double d = 2.0 / std::sqrt(M_PI) * std::exp(-x * x);
+    const double dx = r / d;
+    x -= dx;
+    if (std::fabs(dx) <= 1e-16 * std::fabs(x)) break;
+  }
+  return x;
+}
+
+int setup_constants(chomp_ctx* ctx) {
+  SiCiTab s;
+  BesselTab j0, j2;
+  fill_tables(&s, &j0, &j2);
+  HIPCHK(hipMalloc(&ctx->d_sici, sizeof(SiCiTab)));
+  HIPCHK(hipMalloc(&ctx->d_j0, sizeof(BesselTab)));
+  HIPCHK(hipMalloc(&ctx->d_j2, sizeof(BesselTab)));
+  HIPCHK(hipMemcpy(ctx->d_sici, &s, sizeof(s), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ctx->d_j0, &j0, sizeof(j0), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ctx->d_j2, &j2, sizeof(j2), hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc(&ctx->d_gl16, 32 * sizeof(double)));
+  HIPCHK(hipMemcpy(ctx->d_gl16, CHOMP_GL16, 32 * sizeof(double), hipMemcpyHostToDevice));
+  // Tinker et al. 2010 parameter table (mass_function.py:450-459), splined in
+  // ln(Delta) exactly as the reference does (:461-470).
+  static const double delta[9] = {200, 300, 400, 600, 800, 1200, 1600, 2400, 3200};
+  static const double par[5][9] = {
+      {0.368, 0.363, 0.385, 0.389, 0.393, 0.365, 0.379, 0.355, 0.327},       // alpha
+      {0.589, 0.585, 0.544, 0.543, 0.564, 0.632, 0.637, 0.673, 0.702},       // beta
+      {0.864, 0.922, 0.987, 1.09, 1.20, 1.34, 1.50, 1.68, 1.81},             // gamma
+      {-0.729, -0.789, -0.910, -1.05, -1.20, -1.26, -1.45, -1.50, -1.49},    // phi
+      {-0.243, -0.261, -0.261, -0.273, -0.278, -0.301, -0.301, -0.319, -0.336}};  // eta
+  TinkerTab tt;
+  double work[18];
+  for (int i = 0; i < 9; ++i) tt.x[i] = std::log(delta[i]);
+  for (int q = 0; q < 5; ++q) spline_build(tt.x, par[q], 9, tt.c[q], work);
+  HIPCHK(hipMalloc(&ctx->d_tinker, sizeof(TinkerTab)));
+  HIPCHK(hipMemcpy(ctx->d_tinker, &tt, sizeof(tt), hipMemcpyHostToDevice));
+  // Candidate masses of the 5 % walk (mass_function.py:161-193), generated by the
+  // same repeated multiply/divide so every candidate is bit-identical to the value
+  // the reference's loop would hold after j steps.
+  std::vector<double> cand(4 * kSearchJ);
+  const double start[4] = {1.0e9, 1.0e9, 1.0e16, 1.0e16};
+  const bool mul[4] = {false, true, true, false};
+  for (int t = 0; t < 4; ++t) {
+    double m = start[t];
+    for (int j = 0; j < kSearchJ; ++j) {
+      cand[t * kSearchJ + j] = m;
+      m = mul[t] ? m * 1.05 : m / 1.05;
+    }
+  }
+  HIPCHK(hipMalloc(&ctx->d_cand, cand.size() * sizeof(double)));
+  HIPCHK(hipMemcpy(ctx->d_cand, cand.data(), cand.size() * sizeof(double),
+                   hipMemcpyHostToDevice));
+  return CHOMP_OK;
+}
+
+int alloc_epochs(chomp_ctx* ctx, size_t n) {
+  if (n <= ctx->cap_epoch) return CHOMP_OK;
+  void* old[] = {ctx->d_cosmo, ctx->d_z, ctx->d_epochs, ctx->d_search, ctx->d_tab,
+                 ctx->d_mass_par, ctx->d_profile, ctx->d_hod};
+  for (void* p : old)
+    if (p) HIPCHK(hipFree(p));
+  HIPCHK(hipMalloc(&ctx->d_cosmo, n * sizeof(chomp_cosmo)));
+  HIPCHK(hipMalloc(&ctx->d_z, n * sizeof(double)));
+  HIPCHK(hipMalloc(&ctx->d_epochs, n * sizeof(Epoch)));
+  HIPCHK(hipMalloc(&ctx->d_search, n * 4 * sizeof(double)));
+  HIPCHK(hipMalloc(&ctx->d_tab, n * (size_t)ctx->L.stride * sizeof(double)));
+  HIPCHK(hipMalloc(&ctx->d_mass_par, n * sizeof(chomp_halo_par)));
+  HIPCHK(hipMalloc(&ctx->d_profile, n * sizeof(chomp_halo_par)));
+  HIPCHK(hipMalloc(&ctx->d_hod, n * sizeof(HodDev)));
+  ctx->cap_epoch = n;
+  return CHOMP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void chomp_default_config(chomp_config* c) {
+  // defaults.py:42-51 and 62-92
+  c->k_min = 0.001; c->k_max = 100.0; c->mass_min = -1; c->mass_max = -1;
+  c->corr_precision = 1.48e-6; c->cosmo_precision = 1.48e-8; c->dNdz_precision = 1.48e-8;
+  c->halo_precision = 1.48e-5; c->kernel_precision = 1.48e-6; c->mass_precision = 1.48e-8;
+  c->window_precision = 1.48e-6; c->global_precision = 1.48e-32;
+  c->corr_npoints = 50; c->cosmo_npoints = 50; c->halo_npoints = 50;
+  c->kernel_npoints = 50; c->kernel_bessel_limit = 8; c->mass_npoints = 50;
+  c->window_npoints = 100; c->divmax = 20;
+}
+
+int chomp_ctx_create(const chomp_config* cfg, int device, void* hip_stream,
+                     chomp_ctx** out) {
+  if (!out) return CHOMP_ERR_ARG;
+  *out = nullptr;
+  chomp_ctx* ctx = new chomp_ctx();
+  if (cfg) ctx->cfg = *cfg; else chomp_default_config(&ctx->cfg);
+  const chomp_config& c = ctx->cfg;
+  auto bad = [&](const char* m) {
+    delete ctx;
+    fprintf(stderr, "chomp_ctx_create: %s\n", m);
+    return CHOMP_ERR_ARG;
+  };
+  if (c.mass_npoints < 4 || c.mass_npoints > 512) return bad("mass_npoints out of [4,512]");
+  if (c.halo_npoints < 6 || c.halo_npoints > 512) return bad("halo_npoints out of [6,512]");
+  if (c.kernel_npoints < 4 || c.kernel_npoints > 512) return bad("kernel_npoints");
+  if (c.window_npoints < 4 || c.window_npoints > 1024) return bad("window_npoints");
+  if (c.cosmo_npoints < 4 || c.cosmo_npoints > 512) return bad("cosmo_npoints");
+  if (c.divmax < 1 || c.divmax > 30) return bad("divmax out of [1,30]");
+  if (!(c.k_min > 0.0) || !(c.k_max > c.k_min)) return bad("k limits");
+  ctx->device = device;
+  ctx->L = make_layout(c.mass_npoints, c.halo_npoints);
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+    delete ctx;
+    fprintf(stderr, "chomp_ctx_create: no usable HIP device %d (%s) -- this library has "
+                    "no CPU fallback\n", device, hipGetErrorString(e));
+    return CHOMP_ERR_HIP;
+  }
+  if (hipSetDevice(device) != hipSuccess) { delete ctx; return CHOMP_ERR_HIP; }
+  if (hip_stream) {
+    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  } else {
+    if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return CHOMP_ERR_HIP; }
+    ctx->owns_stream = true;
+  }
+  int rc = setup_constants(ctx);
+  if (rc != CHOMP_OK) {
+    fprintf(stderr, "chomp_ctx_create: %s\n", ctx->err.c_str());
+    delete ctx;
+    return rc;
+  }
+  *out = ctx;
+  return CHOMP_OK;
+}
+
+void chomp_ctx_destroy(chomp_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  void* ptrs[] = {ctx->d_sici, ctx->d_j0, ctx->d_j2, ctx->d_tinker, ctx->d_gl16,
+                  ctx->d_cand, ctx->d_cosmo, ctx->d_z, ctx->d_epochs, ctx->d_search,
+                  ctx->d_tab, ctx->d_mass_par, ctx->d_profile, ctx->d_hod,
+                  ctx->d_stage_in, ctx->d_stage_in2, ctx->d_stage_out};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  proj_free(ctx->proj);
+  if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* chomp_last_error(chomp_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+int chomp_sync(chomp_ctx* ctx) {
+  if (!ctx) return CHOMP_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return CHOMP_OK;
+}
+
+int chomp_epochs_set(chomp_ctx* ctx, size_t n_epoch, const chomp_cosmo* cosmo,
+                     const double* z) {
+  if (!ctx || !cosmo || !z || n_epoch == 0) return fail(ctx, CHOMP_ERR_ARG, "epochs_set: bad args");
+  for (size_t i = 0; i < n_epoch; ++i) {
+    if (cosmo[i].w0 != -1.0 || cosmo[i].wa != 0.0)
+      return fail(ctx, CHOMP_ERR_SCOPE,
+                  "w0 != -1 or wa != 0: dynamical dark energy (cosmology.py:96-104, "
+                  "odeint growth) is outside the hot-path scope");
+    if (!(cosmo[i].omega_m0 > 0.0) || !(cosmo[i].h > 0.0) || !(cosmo[i].sigma_8 > 0.0))
+      return fail(ctx, CHOMP_ERR_ARG, "epochs_set: omega_m0, h, sigma_8 must be > 0");
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  int rc = alloc_epochs(ctx, n_epoch);
+  if (rc) return rc;
+  ctx->n_epoch = n_epoch;
+  ctx->have_mass = ctx->have_halo = false;
+  ctx->fam_mask = 0;
+  ctx->have_halofit.assign(n_epoch, 0);
+  HIPCHK(hipMemcpyAsync(ctx->d_cosmo, cosmo, n_epoch * sizeof(chomp_cosmo),
+                        hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_z, z, n_epoch * sizeof(double), hipMemcpyHostToDevice,
+                        ctx->stream));
+  // pageable host memory: the async copies above have completed staging on return
+  hipLaunchKernelGGL(k_epoch_init, dim3((unsigned)n_epoch, 2), dim3(1024), 0, ctx->stream,
+                     ctx->cfg, ctx->d_cosmo, ctx->d_z, ctx->d_epochs, ctx->d_search,
+                     ctx->d_cand);
+  HIPCHK(hipGetLastError());
+  ctx->have_epochs = true;
+  return CHOMP_OK;
+}
+
+int chomp_mass_setup(chomp_ctx* ctx, const chomp_halo_par* par, int mf_kind) {
+  if (!ctx || !par) return fail(ctx, CHOMP_ERR_ARG, "mass_setup: bad args");
+  if (!ctx->have_epochs) return fail(ctx, CHOMP_ERR_STATE, "mass_setup before epochs_set");
+  if (mf_kind != CHOMP_MF_ST && mf_kind != CHOMP_MF_TINKER)
+    return fail(ctx, CHOMP_ERR_ARG, "mass_setup: unknown mass function kind");
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t n = ctx->n_epoch;
+  const TabLayout& L = ctx->L;
+  HIPCHK(hipMemcpyAsync(ctx->d_mass_par, par, n * sizeof(chomp_halo_par),
+                        hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_nu_table, dim3(L.NM, (unsigned)n), dim3(256), 0, ctx->stream, ctx->cfg,
+                     L, ctx->d_epochs, ctx->d_search, ctx->d_tab);
+  const size_t sh = (size_t)(2 * L.NM + 8 * (L.NM - 1) + 4 * L.NM + 32 + 8) * sizeof(double);
+  hipLaunchKernelGGL(k_mass_setup, dim3((unsigned)n), dim3(256), sh, ctx->stream, ctx->cfg, L,
+                     ctx->d_epochs, ctx->d_search, ctx->d_tab, ctx->d_mass_par, mf_kind,
+                     ctx->d_tinker, ctx->d_gl16);
+  HIPCHK(hipGetLastError());
+  ctx->have_mass = true;
+  // Knot tables already built stay as they are (the reference's MassFunction.set_halo
+  // does not reset Halo._initialized_h_m / _pp_mm, halo.py:220-235).
+  return CHOMP_OK;
+}
+
+int chomp_halo_setup(chomp_ctx* ctx, const chomp_halo_par* profile,
+                     const chomp_hod_par* hod, unsigned tables) {
+  if (!ctx || !profile || !hod) return fail(ctx, CHOMP_ERR_ARG, "halo_setup: bad args");
+  if (!ctx->have_mass) return fail(ctx, CHOMP_ERR_STATE, "halo_setup before mass_setup");
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t n = ctx->n_epoch;
+  const TabLayout& L = ctx->L;
+  for (size_t i = 0; i < n; ++i)
+    if (profile[i].alpha != -1.0)
+      return fail(ctx, CHOMP_ERR_SCOPE,
+                  "halo alpha != -1: the general-profile transform y_general "
+                  "(halo.py:491-559) is outside the hot-path scope (NFW only)");
+  std::vector<HodDev> hd(n);
+  for (size_t i = 0; i < n; ++i) {
+    const chomp_hod_par& h = hod[i];
+    HodDev& d = hd[i];
+    d.log_M_min = h.log_M_min; d.sigma = h.sigma; d.log_M_0 = h.log_M_0;
+    d.log_M_1p = h.log_M_1p; d.alpha = h.alpha;
+    // hod.py:172-186; the `secon_moment_zero` typo there means second_moment_zero
+    // is never clamped to first_moment_zero.
+    d.first_zero = std::pow(10.0, h.log_M_min +
+                                      h.sigma * erfinv_host(2.0 * ctx->cfg.halo_precision - 1.0));
+    d.second_zero = std::pow(10.0, h.log_M_0);
+    d.safe_norm = std::pow(10.0, h.log_M_min + 1.0 * h.sigma);
+  }
+  HIPCHK(hipMemcpyAsync(ctx->d_profile, profile, n * sizeof(chomp_halo_par),
+                        hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_hod, hd.data(), n * sizeof(HodDev), hipMemcpyHostToDevice,
+                        ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));    // hd is a local buffer
+  // header bits CHOMP_T_* are (1 << F_*) by construction
+  const unsigned fam = tables & 31u;
+  int groups[3] = {-1, -1, -1};
+  int ng = 0;
+  if (fam & ((1u << F_HM) | (1u << F_PPMM))) groups[ng++] = 0;
+  if (fam & ((1u << F_HG) | (1u << F_PPGM))) groups[ng++] = 1;
+  if (fam & (1u << F_PPGG)) groups[ng++] = 2;
+  if (ng == 0) groups[ng++] = 3;     // n_bar only
+  const size_t sh = (size_t)(L.NM + 8 * (L.NM - 1) + 8) * sizeof(double);
+  hipLaunchKernelGGL(k_halo_knots, dim3(L.NK + 1, (unsigned)n, ng), dim3(256), sh, ctx->stream,
+                     ctx->cfg, L, ctx->d_epochs, ctx->d_tab, ctx->d_profile, ctx->d_hod,
+                     ctx->d_sici, groups[0], groups[1], groups[2], fam);
+  const size_t sh2 = (size_t)(16 * L.NK) * sizeof(double);
+  hipLaunchKernelGGL(k_halo_finalize, dim3((unsigned)n), dim3(384), sh2, ctx->stream, ctx->cfg,
+                     L, ctx->d_epochs, ctx->d_tab, ctx->d_profile, ctx->d_hod, fam);
+  HIPCHK(hipGetLastError());
+  ctx->have_halo = true;
+  ctx->fam_mask |= fam;
+  return CHOMP_OK;
+}
+
+static int check_power(chomp_ctx* ctx, int which, size_t epoch0, size_t n) {
+  if (!ctx) return CHOMP_ERR_ARG;
+  if (!ctx->have_epochs) return fail(ctx, CHOMP_ERR_STATE, "power before epochs_set");
+  if (epoch0 + n > ctx->n_epoch || n == 0) return fail(ctx, CHOMP_ERR_ARG, "power: epoch range");
+  const int w = which & 15;
+  const bool hf = (which & CHOMP_P_HALOFIT) != 0;
+  if (w < CHOMP_P_LIN || w > CHOMP_P_GG) return fail(ctx, CHOMP_ERR_ARG, "power: unknown spectrum");
+  if (hf && w == CHOMP_P_LIN) return fail(ctx, CHOMP_ERR_ARG, "power: halofit|lin");
+  unsigned need = 0;
+  if (w == CHOMP_P_MM && !hf) need = (1u << F_HM) | (1u << F_PPMM);
+  if (w == CHOMP_P_GM) need = (1u << F_HM) | (1u << F_HG) | (1u << F_PPGM);
+  if (w == CHOMP_P_GG) need = (1u << F_HG) | (1u << F_PPGG);
+  if ((ctx->fam_mask & need) != need)
+    return fail(ctx, CHOMP_ERR_STATE, "power: knot tables of this spectrum were not built "
+                                      "(chomp_halo_setup families)");
+  if (hf)
+    for (size_t i = epoch0; i < epoch0 + n; ++i)
+      if (!ctx->have_halofit[i])
+        return fail(ctx, CHOMP_ERR_STATE, "power: chomp_halofit_setup not called for epoch");
+  return CHOMP_OK;
+}
+
+int chomp_power_range(chomp_ctx* ctx, int which, size_t epoch0, size_t n, const double* k,
+                      size_t nk, double* out, int mem) {
+  int rc = check_power(ctx, which, epoch0, n);
+  if (rc) return rc;
+  if (!k || !out || nk == 0) return fail(ctx, CHOMP_ERR_ARG, "power: null buffer");
+  HIPCHK(hipSetDevice(ctx->device));
+  const double* dk = k;
+  double* dout = out;
+  if (mem == CHOMP_HOST) {
+    rc = ensure(ctx, &ctx->d_stage_in, &ctx->cap_in, nk);
+    if (rc) return rc;
+    rc = ensure(ctx, &ctx->d_stage_out, &ctx->cap_out, nk * n);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->d_stage_in, k, nk * sizeof(double), hipMemcpyHostToDevice,
+                          ctx->stream));
+    dk = ctx->d_stage_in;
+    dout = ctx->d_stage_out;
+  }
+  const TabLayout& L = ctx->L;
+  unsigned gx = (unsigned)((nk + 255) / 256);
+  if (gx > 2048) gx = 2048;
+  const size_t sh = (size_t)(12 * (L.NK - 1)) * sizeof(double);
+  hipLaunchKernelGGL(k_power, dim3(gx, (unsigned)n), dim3(256), sh, ctx->stream, ctx->cfg, L,
+                     ctx->d_epochs, ctx->d_tab, which, (int)epoch0, dk, nk, dout);
+  HIPCHK(hipGetLastError());
+  if (mem == CHOMP_HOST) {
+    HIPCHK(hipMemcpyAsync(out, dout, nk * n * sizeof(double), hipMemcpyDeviceToHost,
+                          ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  return CHOMP_OK;
+}
+
+int chomp_power(chomp_ctx* ctx, int which, const double* k, size_t nk, double* out, int mem) {
+  if (!ctx) return CHOMP_ERR_ARG;
+  return chomp_power_range(ctx, which, 0, ctx->n_epoch, k, nk, out, mem);
+}
+
+int chomp_sigma_r(chomp_ctx* ctx, size_t epoch, const double* scale, size_t n, double* out) {
+  if (!ctx || !scale || !out || n == 0) return fail(ctx, CHOMP_ERR_ARG, "sigma_r: bad args");
+  if (!ctx->have_epochs || epoch >= ctx->n_epoch) return fail(ctx, CHOMP_ERR_STATE, "sigma_r: epoch");
+  HIPCHK(hipSetDevice(ctx->device));
+  int rc = ensure(ctx, &ctx->d_stage_in, &ctx->cap_in, n);
+  if (rc) return rc;
+  rc = ensure(ctx, &ctx->d_stage_out, &ctx->cap_out, n);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(ctx->d_stage_in, scale, n * sizeof(double), hipMemcpyHostToDevice,
+                        ctx->stream));
+  hipLaunchKernelGGL(k_sigma_r, dim3((unsigned)n), dim3(256), 0, ctx->stream, ctx->cfg,
+                     ctx->d_epochs, (int)epoch, ctx->d_stage_in, ctx->d_stage_out);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, ctx->d_stage_out, n * sizeof(double), hipMemcpyDeviceToHost,
+                        ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return CHOMP_OK;
+}
+
+int chomp_y_nfw(chomp_ctx* ctx, size_t epoch, const double* ln_k, const double* mass, size_t n,
+                double* out) {
+  if (!ctx || !ln_k || !mass || !out || n == 0) return fail(ctx, CHOMP_ERR_ARG, "y_nfw: bad args");
+  if (!ctx->have_halo || epoch >= ctx->n_epoch) return fail(ctx, CHOMP_ERR_STATE, "y_nfw before halo_setup");
+  HIPCHK(hipSetDevice(ctx->device));
+  int rc = ensure(ctx, &ctx->d_stage_in, &ctx->cap_in, n);
+  if (rc) return rc;
+  rc = ensure(ctx, &ctx->d_stage_in2, &ctx->cap_in2, n);
+  if (rc) return rc;
+  rc = ensure(ctx, &ctx->d_stage_out, &ctx->cap_out, n);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(ctx->d_stage_in, ln_k, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_stage_in2, mass, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_y_nfw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                     ctx->d_epochs, (int)epoch, ctx->d_sici, ctx->d_stage_in, ctx->d_stage_in2,
+                     (int)n, ctx->d_stage_out);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, ctx->d_stage_out, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return CHOMP_OK;
+}
+
+int chomp_eval(chomp_ctx* ctx, size_t epoch, int what, const double* x, size_t n, double* out,
+               int mem) {
+  if (!ctx || !x || !out || n == 0) return fail(ctx, CHOMP_ERR_ARG, "eval: bad args");
+  if (what < 0 || what > CHOMP_EV_DELTA_K) return fail(ctx, CHOMP_ERR_ARG, "eval: unknown function");
+  if (!ctx->have_epochs || epoch >= ctx->n_epoch) return fail(ctx, CHOMP_ERR_STATE, "eval: epoch");
+  const bool needs_mass = what <= CHOMP_EV_BIAS_NU;
+  const bool needs_halo = what >= CHOMP_EV_HOD_FIRST && what <= CHOMP_EV_CONCENTRATION;
+  if (needs_mass && !ctx->have_mass) return fail(ctx, CHOMP_ERR_STATE, "eval before mass_setup");
+  if (needs_halo && !ctx->have_halo) return fail(ctx, CHOMP_ERR_STATE, "eval before halo_setup");
+  HIPCHK(hipSetDevice(ctx->device));
+  const double* dx = x;
+  double* dout = out;
+  if (mem == CHOMP_HOST) {
+    int rc = ensure(ctx, &ctx->d_stage_in, &ctx->cap_in, n);
+    if (rc) return rc;
+    rc = ensure(ctx, &ctx->d_stage_out, &ctx->cap_out, n);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->d_stage_in, x, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    dx = ctx->d_stage_in;
+    dout = ctx->d_stage_out;
+  }
+  const TabLayout& L = ctx->L;
+  unsigned gx = (unsigned)((n + 255) / 256);
+  if (gx > 1024) gx = 1024;
+  const size_t sh = (size_t)(L.NM + 8 * (L.NM - 1)) * sizeof(double);
+  hipLaunchKernelGGL(k_eval, dim3(gx), dim3(256), sh, ctx->stream, L, ctx->d_epochs, (int)epoch,
+                     ctx->d_tab, what, dx, (int)n, dout);
+  HIPCHK(hipGetLastError());
+  if (mem == CHOMP_HOST) {
+    HIPCHK(hipMemcpyAsync(out, dout, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  return CHOMP_OK;
+}
+
+int chomp_halofit_get(chomp_ctx* ctx, size_t epoch, double* out) {
+  if (!ctx || !out) return fail(ctx, CHOMP_ERR_ARG, "halofit_get: bad args");
+  if (!ctx->have_epochs || epoch >= ctx->n_epoch) return fail(ctx, CHOMP_ERR_STATE, "halofit_get: epoch");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  Epoch E;
+  HIPCHK(hipMemcpy(&E, ctx->d_epochs + epoch, sizeof(Epoch), hipMemcpyDeviceToHost));
+  std::memcpy(out, &E.hf_f1, CHOMP_HF_COUNT * sizeof(double));
+  return CHOMP_OK;
+}
+
+int chomp_halofit_put(chomp_ctx* ctx, size_t epoch, const double* in) {
+  if (!ctx || !in) return fail(ctx, CHOMP_ERR_ARG, "halofit_put: bad args");
+  if (!ctx->have_epochs || epoch >= ctx->n_epoch) return fail(ctx, CHOMP_ERR_STATE, "halofit_put: epoch");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  char* dst = reinterpret_cast<char*>(ctx->d_epochs + epoch) + offsetof(Epoch, hf_f1);
+  HIPCHK(hipMemcpy(dst, in, CHOMP_HF_COUNT * sizeof(double), hipMemcpyHostToDevice));
+  ctx->have_halofit[epoch] = 1;
+  return CHOMP_OK;
+}
+
+int chomp_get_scalars(chomp_ctx* ctx, size_t epoch, double* out) {
+  if (!ctx || !out) return fail(ctx, CHOMP_ERR_ARG, "get_scalars: bad args");
+  if (!ctx->have_epochs || epoch >= ctx->n_epoch) return fail(ctx, CHOMP_ERR_STATE, "get_scalars: epoch");
+  HIPCHK(hipSetDevice(ctx->device));
+  Epoch E;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(&E, ctx->d_epochs + epoch, sizeof(Epoch), hipMemcpyDeviceToHost));
+  for (int i = 0; i < CHOMP_SC_COUNT; ++i) out[i] = 0.0;
+  out[CHOMP_SC_Z] = E.z; out[CHOMP_SC_CHI] = E.chi; out[CHOMP_SC_GROWTH] = E.growth;
+  out[CHOMP_SC_OMEGA_M] = E.omega_m_z; out[CHOMP_SC_OMEGA_L] = E.omega_l_z;
+  out[CHOMP_SC_DELTA_C] = E.delta_c; out[CHOMP_SC_DELTA_V] = E.delta_v;
+  out[CHOMP_SC_RHO_BAR] = E.rho_bar; out[CHOMP_SC_SIGMA_NORM] = E.sigma_norm;
+  out[CHOMP_SC_LN_MASS_MIN] = E.ln_mass_min; out[CHOMP_SC_LN_MASS_MAX] = E.ln_mass_max;
+  out[CHOMP_SC_NU_MIN] = E.nu_min; out[CHOMP_SC_NU_MAX] = E.nu_max;
+  out[CHOMP_SC_M_STAR] = E.m_star; out[CHOMP_SC_F_NORM] = E.f_norm;
+  out[CHOMP_SC_BIAS_NORM] = E.bias_norm; out[CHOMP_SC_N_BAR] = E.n_bar;
+  out[CHOMP_SC_N_BAR_OVER_RHO_BAR] = E.n_bar_over_rho_bar;
+  out[CHOMP_SC_N_SEARCH] = (double)E.n_search; out[CHOMP_SC_MF_DELTA_V] = E.mf_delta_v;
+  out[CHOMP_SC_T_ALPHA] = E.t_alpha; out[CHOMP_SC_T_BETA] = E.t_beta;
+  out[CHOMP_SC_T_GAMMA] = E.t_gamma; out[CHOMP_SC_T_PHI] = E.t_phi;
+  out[CHOMP_SC_T_ETA] = E.t_eta; out[CHOMP_SC_GROWTH_NORM] = E.growth_norm;
+  out[CHOMP_SC_DELTA_H] = E.delta_H; out[CHOMP_SC_HF_K_S] = E.hf_k_s;
+  out[CHOMP_SC_HF_N_EFF] = E.hf_n_eff; out[CHOMP_SC_HF_C] = E.hf_C;
+  return CHOMP_OK;
+}
+
+int chomp_get_table(chomp_ctx* ctx, size_t epoch, int table, double* out, size_t n) {
+  if (!ctx || !out) return fail(ctx, CHOMP_ERR_ARG, "get_table: bad args");
+  if (!ctx->have_mass || epoch >= ctx->n_epoch) return fail(ctx, CHOMP_ERR_STATE, "get_table before mass_setup");
+  const TabLayout& L = ctx->L;
+  int off = -1;
+  size_t len = 0;
+  switch (table) {
+    case CHOMP_TAB_LN_MASS: off = L.off_ln_mass; len = L.NM; break;
+    case CHOMP_TAB_NU: off = L.off_nu; len = L.NM; break;
+    case CHOMP_TAB_H_M: off = L.off_knot[F_HM]; len = L.NK; break;
+    case CHOMP_TAB_PP_MM: off = L.off_knot[F_PPMM]; len = L.NK; break;
+    case CHOMP_TAB_H_G: off = L.off_knot[F_HG]; len = L.NK; break;
+    case CHOMP_TAB_PP_GM: off = L.off_knot[F_PPGM]; len = L.NK; break;
+    case CHOMP_TAB_PP_GG: off = L.off_knot[F_PPGG]; len = L.NK; break;
+    case CHOMP_TAB_LEVELS: off = L.off_levels; len = 5 * (size_t)L.NK; break;
+    case CHOMP_TAB_HF_LN_SIGMA2: off = L.off_hf_lns2; len = L.NK; break;
+    default: return fail(ctx, CHOMP_ERR_ARG, "get_table: unknown table");
+  }
+  if (n != len) return fail(ctx, CHOMP_ERR_ARG, "get_table: length mismatch");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(out, ctx->d_tab + epoch * (size_t)L.stride + off, len * sizeof(double),
+                   hipMemcpyDeviceToHost));
+  return CHOMP_OK;
+}
+
+#include "chomp_capi_proj.inc"
+
+}  // extern "C"

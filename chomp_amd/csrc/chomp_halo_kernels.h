@@ -1,0 +1,723 @@
+// chomp_halo_kernels.h -- HIP kernels of the halo-model path (gfx950).
+//
+// Stage K (tables, per epoch = one (cosmology, z) pair):
+//   k_epoch_init    SingleEpoch.__init__ (cosmology.py:39-119) + the mass-limit
+//                   search of MassFunction._set_mass_limits (mass_function.py:160-203)
+//   k_nu_table      MassFunction._initialize_splines nu_m loop (mass_function.py:205-210)
+//   k_mass_setup    splines, m_star, f/bias normalisation (mass_function.py:212-241,
+//                   Tinker 532-564)
+//   k_halo_knots    n_bar (halo.py:674-700) and the 50-knot integrals h_m, pp_mm,
+//                   h_g, pp_gm, pp_gg (halo.py:904-1086)
+//   k_halo_finalize normalisations + not-a-knot splines over ln k (halo.py:916-918,
+//                   959-961, 983-986, 1026-1029, 1072-1075)
+// Stage E (grid evaluation):
+//   k_power         Halo.linear_power/power_mm/power_gm/power_gg (halo.py:266-439),
+//                   HaloFit.power_* (halo.py:1325-1413)
+//
+// Execution shape: one integral (or a pair sharing nodes) per group of wavefronts;
+// tables (per-epoch splines, Si/Ci Chebyshev coefficients, Gauss nodes) are staged
+// in LDS; reductions are wavefront __shfl_xor butterflies.  No MFMA: there is no
+// dense contraction anywhere on this path.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/chomp_mi355x.h"
+#include "chomp_math.h"
+#include "chomp_romberg.h"
+
+namespace chomp {
+
+// Per-epoch table block (doubles), offsets fixed by the context's point counts.
+struct TabLayout {
+  int NM, NK;
+  int off_ln_mass, off_nu, off_nu_pp, off_lnm_pp;
+  int off_knot[5], off_kpp[5];
+  int off_levels, off_hf_lns2, off_misc;   // misc[0] = n_bar / rho_bar (raw integral)
+  int stride;
+};
+
+inline TabLayout make_layout(int NM, int NK) {
+  TabLayout L;
+  L.NM = NM;
+  L.NK = NK;
+  int o = 0;
+  L.off_ln_mass = o; o += NM;
+  L.off_nu = o; o += NM;
+  L.off_nu_pp = o; o += 4 * (NM - 1);
+  L.off_lnm_pp = o; o += 4 * (NM - 1);
+  for (int f = 0; f < 5; ++f) { L.off_knot[f] = o; o += NK; }
+  for (int f = 0; f < 5; ++f) { L.off_kpp[f] = o; o += 4 * (NK - 1); }
+  L.off_levels = o; o += 5 * NK;
+  L.off_hf_lns2 = o; o += NK;
+  L.off_misc = o; o += 8;
+  L.stride = (o + 7) & ~7;
+  return L;
+}
+
+// Families: index into off_knot / off_kpp.
+enum { F_HM = 0, F_PPMM = 1, F_HG = 2, F_PPGM = 3, F_PPGG = 4 };
+
+constexpr int kSearchJ = 2048;        // candidates per walking direction
+constexpr int kEpochDoubles = (int)(sizeof(Epoch) / sizeof(double));
+static_assert(sizeof(Epoch) % sizeof(double) == 0, "Epoch must be 8-byte granular");
+
+// Cooperative copy of POD blocks as doubles.
+__device__ __forceinline__ void copy_doubles(double* dst, const double* src, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+
+// nu(M) = (delta_c / sigma(R(M)))^2, cosmology.py:662-699, with the whole block on
+// one Romberg integral.
+template <int NW>
+__device__ __forceinline__ double nu_of_mass_block(const Epoch& E, double mass,
+                                                   const chomp_config& cfg, double* red) {
+  const double R = scale_of_mass(E, mass);
+  double lo, hi;
+  sigma_limits(E, R, &lo, &hi);
+  SigmaIntegrand f{&E, R};
+  const double s2 = romberg1<NW>(f, lo, hi, cfg.global_precision, cfg.cosmo_precision,
+                                 cfg.divmax, red);
+  const double sq = E.delta_c / sqrt(s2);
+  return sq * sq;
+}
+
+// ---------------------------------------------------------------------------
+// k_epoch_init: grid (n_epoch, 2), block 1024.  blockIdx.y = side of the mass
+// range being searched (0: mass_min, 1: mass_max).
+//
+// The reference walks mass_min (from 1e9) and mass_max (from 1e16) in 5 % steps
+// until nu(M) lands in 0.1(1 +- 0.05) / 50(1 +- 0.05), one sigma(R) Romberg per
+// step (57 steps at z=0, 306 at z=1.5).  nu(M) is monotone, so the step the walk
+// stops at is the first index j of the (bit-identical, host-tabulated) candidate
+// sequence M_0 * 1.05^(-+j) whose nu satisfies the band test; it is found here by a
+// bracketing secant search on ln nu (4-6 sigma integrals), every integral spread
+// over the block's 16 wavefronts.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_epoch_init(
+    chomp_config cfg, const chomp_cosmo* __restrict__ cosmo, const double* __restrict__ zin,
+    Epoch* __restrict__ epochs, double* __restrict__ search, const double* __restrict__ cand) {
+  __shared__ Epoch E;
+  __shared__ double red[32];
+  const int e = blockIdx.x, side = blockIdx.y;
+  if (threadIdx.x == 0) {
+    double* p = reinterpret_cast<double*>(&E);
+    for (int i = 0; i < kEpochDoubles; ++i) p[i] = 0.0;
+    const chomp_cosmo c = cosmo[e];
+    E.om0 = c.omega_m0; E.ob0 = c.omega_b0; E.ol0 = c.omega_l0; E.or0 = c.omega_r0;
+    E.tcmb = c.cmb_temp; E.h = c.h; E.sigma8 = c.sigma_8; E.ns = c.n_scalar;
+    E.z = zin[e];
+    epoch_background(E, cfg.cosmo_precision, cfg.k_min, cfg.k_max);
+  }
+  __syncthreads();
+  {   // sigma_8 normalisation, cosmology.py:118-119
+    double lo, hi;
+    sigma_limits(E, 8.0, &lo, &hi);
+    SigmaIntegrand f{&E, 8.0};
+    const double s2 = romberg1<16>(f, lo, hi, cfg.global_precision, cfg.cosmo_precision,
+                                   cfg.divmax, red);
+    __syncthreads();
+    if (threadIdx.x == 0) E.sigma_norm = E.sigma8 * E.growth / sqrt(s2);
+    __syncthreads();
+  }
+  if (side == 0) {   // comoving distance, cosmology.py:106-110
+    EIntegrand f{E.om0, E.ol0, E.or0, E.H0};
+    const double chi = romberg1<16>(f, 0.0, E.z, cfg.global_precision,
+                                    cfg.cosmo_precision, cfg.divmax, red);
+    __syncthreads();
+    if (threadIdx.x == 0) E.chi = chi;
+    __syncthreads();
+  }
+  double ln_mass;
+  int n_eval = 0;
+  if (cfg.mass_min > 0.0 && cfg.mass_max > 0.0) {          // mass_function.py:163-170
+    ln_mass = log(side == 0 ? cfg.mass_min : cfg.mass_max);
+  } else {
+    const double thr_lo = (side == 0 ? 0.1 : 50.0) * (1.0 - 0.05);
+    const double thr_hi = (side == 0 ? 0.1 : 50.0) * (1.0 + 0.05);
+    // cand: [0] min-side divide, [1] min-side multiply, [2] max-side multiply,
+    //       [3] max-side divide; index 0 of each is the starting mass.
+    const double* down = cand + (side == 0 ? 0 : 3) * kSearchJ;
+    const double* up = cand + (side == 0 ? 1 : 2) * kSearchJ;
+    const double nu0 = nu_of_mass_block<16>(E, down[0], cfg, red);
+    n_eval = 1;
+    double mass = down[0];
+    int dir = 0;
+    if (thr_hi < nu0) dir = -1; else if (thr_lo > nu0) dir = +1;
+    if (dir != 0) {
+      const double* tab = dir < 0 ? down : up;
+      const double thr = dir < 0 ? thr_hi : thr_lo;
+      int jl = 0, jh = -1;
+      double tl = dir < 0 ? log(nu0 / thr) : log(thr / nu0);
+      double th = 0.0;
+      double d = (side == 0 ? 0.25 : 0.7) * 0.04879;     // guess of d ln(nu) per step
+      for (int it = 0; it < 4 * kSearchJ; ++it) {
+        int jp;
+        if (jh < 0) {
+          double want = ceil(tl / d);
+          if (!(want >= 1.0)) want = 1.0;
+          if (want > 256.0) want = 256.0;
+          jp = jl + (int)want;
+          if (jp > kSearchJ - 1) jp = kSearchJ - 1;
+        } else {
+          if (jh == jl + 1) break;
+          const double dd = (tl - th) / (double)(jh - jl);
+          double want = ceil(tl / dd);
+          if (!(want >= 1.0)) want = 1.0;
+          if (want > (double)(jh - jl - 1)) want = (double)(jh - jl - 1);
+          jp = jl + (int)want;
+        }
+        const double nu = nu_of_mass_block<16>(E, tab[jp], cfg, red);
+        ++n_eval;
+        const bool pred = dir < 0 ? !(thr < nu) : !(thr > nu);
+        const double tp = dir < 0 ? log(nu / thr) : log(thr / nu);
+        if (pred) {
+          jh = jp;
+          th = tp;
+        } else {
+          if (jh < 0) {
+            const double dn = (tl - tp) / (double)(jp - jl);
+            d = dn > 1e-6 ? dn : 1e-6;
+          }
+          jl = jp;
+          tl = tp;
+          if (jh < 0 && jp == kSearchJ - 1) { jh = jp; break; }   // table exhausted
+        }
+      }
+      if (jh < 0) jh = jl;
+      mass = tab[jh];
+    }
+    ln_mass = log(mass);
+  }
+  if (threadIdx.x == 0) {
+    search[(e * 2 + side) * 2 + 0] = ln_mass;
+    search[(e * 2 + side) * 2 + 1] = (double)n_eval;
+  }
+  if (side == 0) {
+    __syncthreads();
+    copy_doubles(reinterpret_cast<double*>(&epochs[e]), reinterpret_cast<const double*>(&E),
+                 kEpochDoubles);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_nu_table: grid (NM, n_epoch), block 256: nu_i = nu_m(exp(ln_mass_i)).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_nu_table(chomp_config cfg, TabLayout L,
+                                                  const Epoch* __restrict__ epochs,
+                                                  const double* __restrict__ search,
+                                                  double* __restrict__ tab) {
+  __shared__ Epoch E;
+  __shared__ double red[8];
+  const int i = blockIdx.x, e = blockIdx.y;
+  copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
+               kEpochDoubles);
+  __syncthreads();
+  const double ln_lo = search[(e * 2 + 0) * 2], ln_hi = search[(e * 2 + 1) * 2];
+  const double lnm = linspace_at(ln_lo, ln_hi, L.NM, i);
+  const double nu = nu_of_mass_block<4>(E, exp(lnm), cfg, red);
+  if (threadIdx.x == 0) {
+    double* t = tab + (size_t)e * L.stride;
+    t[L.off_ln_mass + i] = lnm;
+    t[L.off_nu + i] = nu;
+  }
+}
+
+// Tinker10 parameter splines (mass_function.py:450-470): x[9] then 5 x 32 pp
+// coefficients (alpha, beta, gamma, phi, eta), built on the host at context
+// creation with the same spline_build.
+struct TinkerTab {
+  double x[9];
+  double c[5][32];
+};
+
+struct FnuLn {          // f(nu) d nu = f(e^t) e^t dt
+  const Epoch* e;
+  __device__ __forceinline__ double operator()(double t) const {
+    const double nu = exp(t);
+    return f_nu(*e, nu) * nu;
+  }
+};
+struct FnuBiasLn {
+  const Epoch* e;
+  __device__ __forceinline__ double operator()(double t) const {
+    const double nu = exp(t);
+    return f_nu(*e, nu) * bias_nu(*e, nu) * nu;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// k_mass_setup: grid n_epoch, block 256.  Dynamic LDS: see carve-up below.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mass_setup(
+    chomp_config cfg, TabLayout L, Epoch* __restrict__ epochs,
+    const double* __restrict__ search, double* __restrict__ tab,
+    const chomp_halo_par* __restrict__ par, int mf_kind,
+    const TinkerTab* __restrict__ tinker, const double* __restrict__ gl16) {
+  extern __shared__ __align__(16) double sm[];
+  __shared__ Epoch E;
+  const int NM = L.NM;
+  double* x_lnm = sm;                    // [NM]
+  double* y_nu = x_lnm + NM;             // [NM]
+  double* c_nu = y_nu + NM;              // [4(NM-1)]
+  double* c_lnm = c_nu + 4 * (NM - 1);   // [4(NM-1)]
+  double* work = c_lnm + 4 * (NM - 1);   // [4NM]
+  double* gl = work + 4 * NM;            // [32]
+  double* red = gl + 32;                 // [8]
+  const int e = blockIdx.x;
+  double* t = tab + (size_t)e * L.stride;
+  copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
+               kEpochDoubles);
+  copy_doubles(x_lnm, t + L.off_ln_mass, NM);
+  copy_doubles(y_nu, t + L.off_nu, NM);
+  copy_doubles(gl, gl16, 32);
+  __syncthreads();
+  if (threadIdx.x == 0) spline_build(x_lnm, y_nu, NM, c_nu, work);             // nu(ln M)
+  if (threadIdx.x == 64) spline_build(y_nu, x_lnm, NM, c_lnm, work + 2 * NM);  // ln M(nu)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const chomp_halo_par hp = par[e];
+    E.ln_mass_min = search[(e * 2 + 0) * 2];
+    E.ln_mass_max = search[(e * 2 + 1) * 2];
+    E.n_search = (int)(search[(e * 2 + 0) * 2 + 1] + search[(e * 2 + 1) * 2 + 1]);
+    E.nu_min = 1.001 * y_nu[0];                       // mass_function.py:212-213
+    E.nu_max = 0.999 * y_nu[NM - 1];
+    E.m_star = exp(spline_eval(y_nu, c_lnm, NM, 1.0));   // :223
+    E.stq = hp.stq;
+    E.st_a = hp.st_little_a;
+    E.mf_delta_v = (hp.delta_v == -1.0) ? E.delta_v : hp.delta_v;
+    E.mf_kind = mf_kind;
+    E.f_norm = 1.0;
+    E.bias_norm = 1.0;
+    if (mf_kind == CHOMP_MF_TINKER) {                 // mass_function.py:547-564
+      const double ld = log(E.mf_delta_v);
+      const double opz = 1.0 + E.z;
+      E.t_alpha = spline_eval(tinker->x, tinker->c[0], 9, ld);
+      E.t_beta = spline_eval(tinker->x, tinker->c[1], 9, ld) * pow(opz, 0.20);
+      E.t_gamma = spline_eval(tinker->x, tinker->c[2], 9, ld) * pow(opz, -0.01);
+      E.t_phi = spline_eval(tinker->x, tinker->c[3], 9, ld) * pow(opz, -0.08);
+      E.t_eta = spline_eval(tinker->x, tinker->c[4], 9, ld) * pow(opz, 0.27);
+      tinker_bias_constants(E);
+    }
+  }
+  __syncthreads();
+  // Normalisations (mass_function.py:225-241; Tinker: bias only, :532-545).  The
+  // reference integrates in linear nu with Romberg to rtol 1.48e-8 (8193 nodes);
+  // the integrand is analytic, so 8 x 16 Gauss-Legendre nodes in ln nu give the
+  // same number to ~4e-11.
+  int flip = 0;
+  const double a = log(E.nu_min), b = log(E.nu_max);
+  if (mf_kind == CHOMP_MF_ST) {
+    FnuLn f{&E};
+    const double norm = gauss_panels<4>(f, a, b, 8, gl, red, flip);
+    __syncthreads();
+    if (threadIdx.x == 0) E.f_norm = 1.0 / norm;
+    __syncthreads();
+  }
+  {
+    FnuBiasLn f{&E};
+    const double norm = gauss_panels<4>(f, a, b, 8, gl, red, flip);
+    __syncthreads();
+    if (threadIdx.x == 0) E.bias_norm = 1.0 / norm;
+    __syncthreads();
+  }
+  copy_doubles(reinterpret_cast<double*>(&epochs[e]), reinterpret_cast<const double*>(&E),
+               kEpochDoubles);
+  copy_doubles(t + L.off_nu_pp, c_nu, 4 * (NM - 1));
+  copy_doubles(t + L.off_lnm_pp, c_lnm, 4 * (NM - 1));
+}
+
+// ---------------------------------------------------------------------------
+// Halo integrands over ln nu (halo.py:702-707, 922-927, 964-969, 989-994,
+// 1032-1041, 1078-1086).  The reference multiplies each integrand by a constant
+// `norm` and divides it out again; it cancels in the relative stopping test and is
+// omitted.
+// ---------------------------------------------------------------------------
+struct HaloCtx {
+  const Epoch* e;
+  const SiCiTab* sici;
+  const double* nu_knots;    // [NM]  knots of ln M(nu)
+  const double* lnm_pp;      // [4(NM-1)]
+  int NM;
+  double ln_k;
+};
+
+struct IntegrandMM {       // out[0] = h_m, out[1] = pp_mm (x rho_bar)
+  HaloCtx c;
+  __device__ __forceinline__ void operator()(double ln_nu, double (&out)[2]) const {
+    const double nu = exp(ln_nu);
+    const double lnm = spline_eval(c.nu_knots, c.lnm_pp, c.NM, nu);
+    const double y = y_nfw(*c.e, *c.sici, c.ln_k, lnm);
+    const double nf = nu * f_nu(*c.e, nu);
+    out[0] = nf * bias_nu(*c.e, nu) * y;
+    out[1] = nf * exp(lnm) * y * y;
+  }
+};
+
+struct IntegrandGM {       // out[0] = h_g, out[1] = pp_gm
+  HaloCtx c;
+  __device__ __forceinline__ void operator()(double ln_nu, double (&out)[2]) const {
+    const double nu = exp(ln_nu);
+    const double lnm = spline_eval(c.nu_knots, c.lnm_pp, c.NM, nu);
+    const double mass = exp(lnm);
+    const double y = y_nfw(*c.e, *c.sici, c.ln_k, lnm);
+    const double nf = nu * f_nu(*c.e, nu);
+    const double n1 = zheng_first(*c.e, mass);
+    out[0] = nf * bias_nu(*c.e, nu) * y * n1 / mass;
+    out[1] = (n1 < 1.0) ? nf * n1 * y : nf * n1 * y * y;
+  }
+};
+
+struct IntegrandGG {       // out[0] = pp_gg
+  HaloCtx c;
+  __device__ __forceinline__ void operator()(double ln_nu, double (&out)[1]) const {
+    const double nu = exp(ln_nu);
+    const double lnm = spline_eval(c.nu_knots, c.lnm_pp, c.NM, nu);
+    const double mass = exp(lnm);
+    const double y = y_nfw(*c.e, *c.sici, c.ln_k, lnm);
+    const double nf = nu * f_nu(*c.e, nu);
+    const double n2 = zheng_second(*c.e, mass);
+    out[0] = (n2 < 1.0) ? nf * n2 * y / mass : nf * n2 * y * y / mass;
+  }
+};
+
+struct IntegrandNbar {     // halo.py:702-707
+  HaloCtx c;
+  __device__ __forceinline__ double operator()(double ln_nu) const {
+    const double nu = exp(ln_nu);
+    const double mass = exp(spline_eval(c.nu_knots, c.lnm_pp, c.NM, nu));
+    return nu * zheng_first(*c.e, mass) * f_nu(*c.e, nu) / mass;
+  }
+};
+
+// HOD-derived constants (hod.py:172-186) are computed on the host (erfinv) and
+// passed in; the lower limits of the HOD integrals follow halo.py:935-939,
+// 1002-1006.
+struct HodDev {
+  double log_M_min, sigma, log_M_0, log_M_1p, alpha;
+  double first_zero, second_zero, safe_norm;
+};
+
+// Halo-profile and HOD constants of one epoch (Halo.__init__, halo.py:71-88; the
+// lower limits of the HOD integrals, halo.py:935-939, 1002-1006).  nu_pp: pp
+// coefficients of nu(ln M) on the uniform ln M grid starting at lnm0.
+__device__ __forceinline__ void apply_halo_hod(Epoch& E, const chomp_halo_par& hp,
+                                               const HodDev& h, const double* nu_pp,
+                                               double lnm0, int NM) {
+  halo_constants(E, hp.c0, hp.beta, hp.delta_v);
+  E.hod_log_M_min = h.log_M_min; E.hod_sigma = h.sigma; E.hod_log_M_0 = h.log_M_0;
+  E.hod_log_M_1p = h.log_M_1p; E.hod_alpha = h.alpha;
+  E.hod_first_zero = h.first_zero; E.hod_second_zero = h.second_zero;
+  E.hod_safe_norm = h.safe_norm;
+  E.hod_M0 = pow(10.0, h.log_M_0);
+  E.hod_M1p = pow(10.0, h.log_M_1p);
+  const double dlnm = (E.ln_mass_max - E.ln_mass_min) / (double)(NM - 1);
+  double nu1 = E.nu_min, nu2 = E.nu_min;
+  if (h.first_zero > -1.0 && h.first_zero > exp(E.ln_mass_min))
+    nu1 = spline_eval_uniform(lnm0, dlnm, nu_pp, NM, log(h.first_zero));
+  if (h.second_zero > -1.0 && h.second_zero > exp(E.ln_mass_min))
+    nu2 = spline_eval_uniform(lnm0, dlnm, nu_pp, NM, log(h.second_zero));
+  E.ln_nu_lo_first = log(nu1);
+  E.ln_nu_lo_second = log(nu2);
+}
+
+// ---------------------------------------------------------------------------
+// k_halo_knots: grid (NK + 1, n_epoch, n_groups), block 256 (4 wavefronts per
+// integral pair).  blockIdx.x < NK: knot ln k_i of group groups[blockIdx.z]
+// (0: h_m + pp_mm, 1: h_g + pp_gm, 2: pp_gg).  blockIdx.x == NK, blockIdx.z == 0:
+// the n_bar integral of the epoch.  The epoch array is read-only here; the halo/
+// HOD constants each block derives in LDS are written back by k_halo_finalize.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_halo_knots(
+    chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs,
+    double* __restrict__ tab, const chomp_halo_par* __restrict__ profile,
+    const HodDev* __restrict__ hod, const SiCiTab* __restrict__ sici_g, int g0, int g1,
+    int g2, unsigned mask) {
+  extern __shared__ __align__(16) double sm[];
+  __shared__ Epoch E;
+  __shared__ SiCiTab S;
+  const int NM = L.NM, NK = L.NK;
+  double* nu_knots = sm;                    // [NM]
+  double* lnm_pp = nu_knots + NM;           // [4(NM-1)]
+  double* nu_pp = lnm_pp + 4 * (NM - 1);    // [4(NM-1)]
+  double* red = nu_pp + 4 * (NM - 1);       // [8]
+  const int ik = blockIdx.x, e = blockIdx.y;
+  const int group = blockIdx.z == 0 ? g0 : (blockIdx.z == 1 ? g1 : g2);
+  if (ik == NK && blockIdx.z != 0) return;
+  if (ik < NK && (group < 0 || group > 2)) return;
+  double* t = tab + (size_t)e * L.stride;
+  copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
+               kEpochDoubles);
+  copy_doubles(reinterpret_cast<double*>(&S), reinterpret_cast<const double*>(sici_g),
+               (int)(sizeof(SiCiTab) / sizeof(double)));
+  copy_doubles(nu_knots, t + L.off_nu, NM);
+  copy_doubles(lnm_pp, t + L.off_lnm_pp, 4 * (NM - 1));
+  copy_doubles(nu_pp, t + L.off_nu_pp, 4 * (NM - 1));
+  __syncthreads();
+  if (threadIdx.x == 0) apply_halo_hod(E, profile[e], hod[e], nu_pp, t[L.off_ln_mass], NM);
+  __syncthreads();
+  const double ln_nu_max = log(E.nu_max);
+  HaloCtx c{&E, &S, nu_knots, lnm_pp, NM, 0.0};
+  if (ik == NK) {
+    IntegrandNbar f{c};
+    const double v = romberg1<4>(f, E.ln_nu_lo_first, ln_nu_max, cfg.global_precision,
+                                 cfg.halo_precision, cfg.divmax, red);
+    if (threadIdx.x == 0) t[L.off_misc] = v;
+    return;
+  }
+  c.ln_k = linspace_at(log(cfg.k_min), log(cfg.k_max), NK, ik);     // halo.py:52-54
+  double* lev = t + L.off_levels;
+  if (group == 0) {
+    IntegrandMM f{c};
+    const RombergOut<2> r = romberg_group<4, 2>(f, log(E.nu_min), ln_nu_max,
+                                                cfg.global_precision, cfg.halo_precision,
+                                                cfg.divmax, red);
+    if (threadIdx.x == 0) {
+      if (mask & (1u << F_HM)) {
+        t[L.off_knot[F_HM] + ik] = r.value[0];
+        lev[F_HM * NK + ik] = (double)r.level[0];
+      }
+      if (mask & (1u << F_PPMM)) {
+        t[L.off_knot[F_PPMM] + ik] = r.value[1];
+        lev[F_PPMM * NK + ik] = (double)r.level[1];
+      }
+    }
+  } else if (group == 1) {
+    IntegrandGM f{c};
+    const RombergOut<2> r = romberg_group<4, 2>(f, E.ln_nu_lo_first, ln_nu_max,
+                                                cfg.global_precision, cfg.halo_precision,
+                                                cfg.divmax, red);
+    if (threadIdx.x == 0) {
+      if (mask & (1u << F_HG)) {
+        t[L.off_knot[F_HG] + ik] = r.value[0];
+        lev[F_HG * NK + ik] = (double)r.level[0];
+      }
+      if (mask & (1u << F_PPGM)) {
+        t[L.off_knot[F_PPGM] + ik] = r.value[1];
+        lev[F_PPGM * NK + ik] = (double)r.level[1];
+      }
+    }
+  } else {
+    IntegrandGG f{c};
+    const RombergOut<1> r = romberg_group<4, 1>(f, E.ln_nu_lo_second, ln_nu_max,
+                                                cfg.global_precision, cfg.halo_precision,
+                                                cfg.divmax, red);
+    if (threadIdx.x == 0) {
+      t[L.off_knot[F_PPGG] + ik] = r.value[0];
+      lev[F_PPGG * NK + ik] = (double)r.level[0];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_halo_finalize: grid n_epoch, block 384 (6 wavefronts).  Lane 0 of wavefront
+// f < 5 normalises family f and builds its not-a-knot spline over ln k; lane 0 of
+// wavefront 5 writes the epoch's halo/HOD constants and n_bar back.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(384) void k_halo_finalize(
+    chomp_config cfg, TabLayout L, Epoch* __restrict__ epochs, double* __restrict__ tab,
+    const chomp_halo_par* __restrict__ profile, const HodDev* __restrict__ hod,
+    unsigned fam_mask) {
+  extern __shared__ __align__(16) double sm[];
+  const int NK = L.NK;
+  double* xk = sm;                      // [NK]
+  double* work = xk + NK;               // [5][3NK]
+  const int e = blockIdx.x;
+  double* t = tab + (size_t)e * L.stride;
+  for (int i = threadIdx.x; i < NK; i += blockDim.x)
+    xk[i] = linspace_at(log(cfg.k_min), log(cfg.k_max), NK, i);
+  __syncthreads();
+  const int f = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) != 0) return;
+  const double nbr = t[L.off_misc];                    // n_bar / rho_bar
+  if (f == 5) {
+    Epoch E = epochs[e];
+    apply_halo_hod(E, profile[e], hod[e], t + L.off_nu_pp, t[L.off_ln_mass], L.NM);
+    E.n_bar_over_rho_bar = nbr;                        // halo.py:692-700
+    E.n_bar = nbr * E.rho_bar;
+    epochs[e] = E;
+    return;
+  }
+  if (!((fam_mask >> f) & 1u)) return;
+  const double rho_bar = epochs[e].rho_bar;            // not modified by wavefront 5
+  const double n_bar = nbr * rho_bar;
+  double scale = 1.0;
+  if (f == F_PPMM) scale = 1.0 / rho_bar;                       // halo.py:983
+  else if (f == F_HG) scale = 1.0 / nbr;                        // :959
+  else if (f == F_PPGM) scale = 1.0 / n_bar;                    // :1072
+  else if (f == F_PPGG) scale = rho_bar / (n_bar * n_bar);      // :1026
+  double* y = work + f * 3 * NK;
+  double* w = y + NK;
+  for (int i = 0; i < NK; ++i) {
+    y[i] = t[L.off_knot[f] + i] * scale;
+    t[L.off_knot[f] + i] = y[i];
+  }
+  spline_build(xk, y, NK, t + L.off_kpp[f], w);
+}
+
+// ---------------------------------------------------------------------------
+// Stage E.  grid (ceil(nk / (256*KPT)), n_epoch), block 256.  Each block stages
+// its epoch's scalars and the pp-coefficients of the (up to 3) knot splines it
+// needs in LDS, then streams k -> P with coalesced 8-byte accesses.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double halofit_mm(const Epoch& E, double k) {
+  // halo.py:1339-1360
+  const double lk = log(k);
+  const double dk = delta_k_ln(E, lk, k);
+  const double y = k / E.hf_k_s;
+  const double d2q = dk * (pow(1.0 + dk, E.hf_beta_n) / (1.0 + E.hf_alpha_n * dk) *
+                           exp(-(y / 4.0 + y * y / 8.0)));
+  const double d2h = (E.hf_a_n * pow(y, 3.0 * E.hf_f1) /
+                      (1.0 + E.hf_b_n * pow(y, E.hf_f2) +
+                       pow(E.hf_c_n * E.hf_f3 * y, 3.0 - E.hf_gamma_n))) /
+                     (1.0 + E.hf_mu_n / y + E.hf_nu_n / (y * y));
+  return 2.0 * kPi * kPi / (k * k * k) * (d2q + d2h);
+}
+
+__global__ __launch_bounds__(256) void k_power(chomp_config cfg, TabLayout L,
+                                               const Epoch* __restrict__ epochs,
+                                               const double* __restrict__ tab, int which,
+                                               int epoch0, const double* __restrict__ k,
+                                               size_t nk, double* __restrict__ out) {
+  extern __shared__ __align__(16) double sm[];
+  __shared__ Epoch E;
+  const int NK = L.NK;
+  const int e = epoch0 + blockIdx.y;
+  const bool halofit = (which & CHOMP_P_HALOFIT) != 0;
+  const int w = which & 15;
+  int fa = F_HM, fb = F_HM, fp = F_PPMM;
+  if (w == CHOMP_P_GM) { fa = F_HG; fb = F_HM; fp = F_PPGM; }
+  else if (w == CHOMP_P_GG) { fa = F_HG; fb = F_HG; fp = F_PPGG; }
+  double* ca = sm;
+  double* cb = ca + 4 * (NK - 1);
+  double* cp = cb + 4 * (NK - 1);
+  const double* t = tab + (size_t)e * L.stride;
+  copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
+               kEpochDoubles);
+  if (w != CHOMP_P_LIN && !(halofit && w == CHOMP_P_MM)) {
+    copy_doubles(ca, t + L.off_kpp[fa], 4 * (NK - 1));
+    copy_doubles(cb, t + L.off_kpp[fb], 4 * (NK - 1));
+    copy_doubles(cp, t + L.off_kpp[fp], 4 * (NK - 1));
+  }
+  __syncthreads();
+  const double x0 = log(cfg.k_min), x1 = log(cfg.k_max);
+  const double dx = (x1 - x0) / (double)(NK - 1);
+  double c_lo = 0.0;
+  if (w != CHOMP_P_LIN && !halofit) {
+    // k < k_min: P_lin(k) * (h_a h_b + pp / P_lin)|_{k_min}   (halo.py:314-317)
+    const double ha = pp_poly(ca, 0, 0.0), hb = pp_poly(cb, 0, 0.0), p0 = pp_poly(cp, 0, 0.0);
+    c_lo = ha * hb + p0 / linear_power(E, cfg.k_min);
+  }
+  double* o = out + (size_t)blockIdx.y * nk;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nk;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const double kv = k[i];
+    double r;
+    if (w == CHOMP_P_LIN) {
+      r = linear_power(E, kv);
+    } else if (halofit) {
+      const double pmm = halofit_mm(E, kv);
+      if (w == CHOMP_P_MM) {
+        r = pmm;
+      } else {
+        double ha = 0.0, hb = 0.0, pp = 0.0;            // halo.py:649-672 range rule
+        if (kv >= cfg.k_min && kv <= cfg.k_max) {
+          const double lk = log(kv);
+          ha = spline_eval_uniform(x0, dx, ca, NK, lk);
+          hb = spline_eval_uniform(x0, dx, cb, NK, lk);
+          pp = spline_eval_uniform(x0, dx, cp, NK, lk);
+        }
+        r = pmm * ha * hb + pp;
+      }
+    } else if (kv < cfg.k_min) {
+      r = linear_power(E, kv) * c_lo;
+    } else if (kv <= cfg.k_max) {
+      const double lk = log(kv);
+      const double ha = spline_eval_uniform(x0, dx, ca, NK, lk);
+      const double hb = spline_eval_uniform(x0, dx, cb, NK, lk);
+      const double pp = spline_eval_uniform(x0, dx, cp, NK, lk);
+      const double plin = 2.0 * kPi * kPi * delta_k_ln(E, lk, kv) / (kv * kv * kv);
+      r = plin * ha * hb + pp;
+    } else {
+      r = 0.0;
+    }
+    o[i] = r;
+  }
+}
+
+// sigma_r at arbitrary scales (SingleEpoch.sigma_r): grid n, block 256.
+__global__ __launch_bounds__(256) void k_sigma_r(chomp_config cfg,
+                                                 const Epoch* __restrict__ epochs, int e,
+                                                 const double* __restrict__ scale,
+                                                 double* __restrict__ out) {
+  __shared__ Epoch E;
+  __shared__ double red[8];
+  copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
+               kEpochDoubles);
+  __syncthreads();
+  const double R = scale[blockIdx.x];
+  double lo, hi;
+  sigma_limits(E, R, &lo, &hi);
+  SigmaIntegrand f{&E, R};
+  const double s2 = romberg1<4>(f, lo, hi, cfg.global_precision, cfg.cosmo_precision,
+                                cfg.divmax, red);
+  if (threadIdx.x == 0) out[blockIdx.x] = sqrt(s2);
+}
+
+// Halo.y (NFW) at (ln k, M) pairs.
+__global__ void k_y_nfw(const Epoch* __restrict__ epochs, int e,
+                        const SiCiTab* __restrict__ sici_g, const double* __restrict__ ln_k,
+                        const double* __restrict__ mass, int n, double* __restrict__ out) {
+  __shared__ Epoch E;
+  __shared__ SiCiTab S;
+  copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
+               kEpochDoubles);
+  copy_doubles(reinterpret_cast<double*>(&S), reinterpret_cast<const double*>(sici_g),
+               (int)(sizeof(SiCiTab) / sizeof(double)));
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = y_nfw(E, S, ln_k[i], log(mass[i]));
+}
+
+// Element-wise accessors of one epoch's tables (the public lookup methods of
+// MassFunction / HOD / Halo: mass_function.py:243-346, hod.py:189-230,
+// halo.py:441-463).
+__global__ void k_eval(TabLayout L, const Epoch* __restrict__ epochs, int e,
+                       const double* __restrict__ tab, int what,
+                       const double* __restrict__ x, int n, double* __restrict__ out) {
+  extern __shared__ __align__(16) double sm[];
+  __shared__ Epoch E;
+  const int NM = L.NM;
+  double* nu_knots = sm;
+  double* lnm_pp = nu_knots + NM;
+  double* nu_pp = lnm_pp + 4 * (NM - 1);
+  const double* t = tab + (size_t)e * L.stride;
+  copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
+               kEpochDoubles);
+  copy_doubles(nu_knots, t + L.off_nu, NM);
+  copy_doubles(lnm_pp, t + L.off_lnm_pp, 4 * (NM - 1));
+  copy_doubles(nu_pp, t + L.off_nu_pp, 4 * (NM - 1));
+  __syncthreads();
+  const double dlnm = (E.ln_mass_max - E.ln_mass_min) / (double)(NM - 1);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const double v = x[i];
+    double r = 0.0;
+    switch (what) {
+      case CHOMP_EV_NU_OF_MASS: r = spline_eval_uniform(E.ln_mass_min, dlnm, nu_pp, NM, log(v)); break;
+      case CHOMP_EV_LN_MASS_OF_NU: r = spline_eval(nu_knots, lnm_pp, NM, v); break;
+      case CHOMP_EV_F_NU: r = f_nu(E, v); break;
+      case CHOMP_EV_BIAS_NU: r = bias_nu(E, v); break;
+      case CHOMP_EV_HOD_FIRST: r = zheng_first(E, v); break;
+      case CHOMP_EV_HOD_SECOND: r = zheng_second(E, v); break;
+      case CHOMP_EV_HOD_CENTRAL: r = zheng_central(E, v); break;
+      case CHOMP_EV_HOD_SATELLITE: r = zheng_satellite(E, v); break;
+      case CHOMP_EV_VIRIAL_RADIUS: r = exp((E.ln_rv_const + log(v)) * (1.0 / 3.0)); break;
+      case CHOMP_EV_CONCENTRATION: r = exp(E.ln_c_const + E.beta * log(v)); break;
+      case CHOMP_EV_DELTA_K: r = delta_k_ln(E, log(v), v); break;
+      default: r = 0.0;
+    }
+    out[i] = r;
+  }
+}
+
+}  // namespace chomp

@@ -1,0 +1,500 @@
+// chomp_math.h -- fp64 building blocks shared by every kernel of the hot path:
+// special functions (Si/Ci, J0, J2), not-a-knot cubic splines, the Eisenstein-Hu
+// linear spectrum, mass-function / HOD / NFW pieces.  Everything here is plain
+// arithmetic on doubles (CHOMP_HD = __host__ __device__) so the same code can be
+// checked on the CPU by tests/hostcheck without a GPU; the product only ever runs
+// it inside HIP kernels.
+#pragma once
+
+#include <math.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define CHOMP_HD __host__ __device__ __forceinline__
+#else
+#define CHOMP_HD inline
+#endif
+
+#include "special_tables.h"
+
+namespace chomp {
+
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kHalfPi = 1.57079632679489661923;
+constexpr double kE = 2.71828182845904523536;
+
+// ---------------------------------------------------------------------------
+// Special-function tables as one POD block: uploaded once per context, staged in
+// LDS by the kernels that need them.
+// ---------------------------------------------------------------------------
+struct SiCiTab {
+  double si_ser[CHOMP_SICI_NSER];
+  double ci_ser[CHOMP_SICI_NSER];
+  double f[CHOMP_FG_NINT][CHOMP_FG_NCOEF];
+  double g[CHOMP_FG_NINT][CHOMP_FG_NCOEF];
+};
+struct BesselTab {
+  double cheb[8][CHOMP_J0_NCOEF];   // J0 and J2 have the same table shape
+  double p[CHOMP_J0_NHANKEL];
+  double xq[CHOMP_J0_NHANKEL];
+};
+static_assert(CHOMP_J0_NCOEF == CHOMP_J2_NCOEF, "table shape");
+static_assert(CHOMP_J0_NHANKEL == CHOMP_J2_NHANKEL, "table shape");
+
+inline void fill_tables(SiCiTab* s, BesselTab* j0, BesselTab* j2) {
+  for (int i = 0; i < CHOMP_SICI_NSER; ++i) {
+    s->si_ser[i] = CHOMP_SI_SER[i];
+    s->ci_ser[i] = CHOMP_CI_SER[i];
+  }
+  for (int j = 0; j < CHOMP_FG_NINT; ++j)
+    for (int i = 0; i < CHOMP_FG_NCOEF; ++i) {
+      s->f[j][i] = CHOMP_AUX_F[j][i];
+      s->g[j][i] = CHOMP_AUX_G[j][i];
+    }
+  for (int j = 0; j < 8; ++j)
+    for (int i = 0; i < CHOMP_J0_NCOEF; ++i) {
+      j0->cheb[j][i] = CHOMP_J0_CHEB[j][i];
+      j2->cheb[j][i] = CHOMP_J2_CHEB[j][i];
+    }
+  for (int i = 0; i < CHOMP_J0_NHANKEL; ++i) {
+    j0->p[i] = CHOMP_J0_P[i];
+    j0->xq[i] = CHOMP_J0_XQ[i];
+    j2->p[i] = CHOMP_J2_P[i];
+    j2->xq[i] = CHOMP_J2_XQ[i];
+  }
+}
+
+// Clenshaw sum of c[0..n-1] in Chebyshev polynomials of t in [-1, 1].
+template <int N>
+CHOMP_HD double cheb_eval(const double* c, double t) {
+  double b1 = 0.0, b2 = 0.0;
+  const double t2 = 2.0 * t;
+#pragma unroll
+  for (int k = N - 1; k >= 1; --k) {
+    const double b0 = fma(t2, b1, c[k] - b2);
+    b2 = b1;
+    b1 = b0;
+  }
+  return fma(t, b1, c[0] - b2);
+}
+
+// Si(x), Ci(x) for x > 0, given s = sin x and c = cos x (only used when x >= 4).
+// Replaces scipy.special.sici at halo.py:578-579.
+CHOMP_HD void sici_sc(double x, double s, double c, const SiCiTab& T, double* si,
+                      double* ci) {
+  if (x < 4.0) {
+    const double x2 = x * x;
+    double ps = T.si_ser[CHOMP_SICI_NSER - 1], pc = T.ci_ser[CHOMP_SICI_NSER - 1];
+#pragma unroll
+    for (int k = CHOMP_SICI_NSER - 2; k >= 0; --k) {
+      ps = fma(ps, x2, T.si_ser[k]);
+      pc = fma(pc, x2, T.ci_ser[k]);
+    }
+    *si = x * ps;
+    *ci = CHOMP_EULER_GAMMA + log(x) + x2 * pc;
+  } else {
+    const double u = 4.0 / x;
+    int j = (int)(8.0 * u);
+    j = j > 7 ? 7 : j;
+    const double t = 16.0 * u - (double)(2 * j + 1);
+    const double F = cheb_eval<CHOMP_FG_NCOEF>(T.f[j], t);
+    const double G = cheb_eval<CHOMP_FG_NCOEF>(T.g[j], t);
+    const double f = F / x, g = G / (x * x);
+    *si = kHalfPi - f * c - g * s;
+    *ci = f * s - g * c;
+  }
+}
+
+CHOMP_HD void sici(double x, const SiCiTab& T, double* si, double* ci) {
+  double s = 0.0, c = 1.0;
+  if (x >= 4.0) {
+    s = sin(x);
+    c = cos(x);
+  }
+  sici_sc(x, s, c, T, si, ci);
+}
+
+// J_n(x), n = 0 or 2 (ORDER selects the Hankel phase), x >= 0.
+// Replaces scipy.special.j0 / jn(2, .) at kernel.py:712, 839.
+template <int ORDER>
+CHOMP_HD double bessel_j(double x, const BesselTab& T) {
+  x = fabs(x);
+  if (x < 32.0) {
+    int j = (int)(0.25 * x);
+    j = j > 7 ? 7 : j;
+    const double t = 0.5 * x - (double)(2 * j + 1);
+    return cheb_eval<CHOMP_J0_NCOEF>(T.cheb[j], t);
+  }
+  const double r = 32.0 / x;
+  const double t = 2.0 * r * r - 1.0;
+  const double P = cheb_eval<CHOMP_J0_NHANKEL>(T.p, t);
+  const double Q = cheb_eval<CHOMP_J0_NHANKEL>(T.xq, t) / x;
+  const double chi = x - (0.5 * ORDER + 0.25) * kPi;
+  return sqrt(2.0 / (kPi * x)) * (P * cos(chi) - Q * sin(chi));
+}
+
+// ---------------------------------------------------------------------------
+// Not-a-knot cubic interpolating spline == FITPACK InterpolatedUnivariateSpline
+// (k=3) used at ~25 reference sites (e.g. mass_function.py:217-220,
+// halo.py:918, 985, kernel.py:311, 646).  Piecewise-polynomial form:
+//   s(x) = c[4i] + c[4i+1] d + c[4i+2] d^2 + c[4i+3] d^3,  d = x - x[i],
+// interval i = 0..n-2; outside the knots the end pieces extrapolate, as FITPACK
+// (ext=0) does.
+// ---------------------------------------------------------------------------
+// Serial build (one thread).  `work` needs 2n doubles.  n >= 4.
+CHOMP_HD void spline_build(const double* x, const double* y, int n, double* c,
+                           double* work) {
+  double* diag = work;      // modified diagonal
+  double* s = work + n;     // rhs -> slopes
+  const double h0 = x[1] - x[0], h1 = x[2] - x[1];
+  const double d0 = (y[1] - y[0]) / h0, d1 = (y[2] - y[1]) / h1;
+  // row 0 (not-a-knot): h1 s0 + (h0+h1) s1 = rhs
+  double b0 = h1, c0 = h0 + h1;
+  double r0 = ((3.0 * h0 + 2.0 * h1) * h1 * d0 + h0 * h0 * d1) / (h0 + h1);
+  diag[0] = b0;
+  s[0] = r0;
+  double cprev = c0;   // super-diagonal of the previous row
+  for (int i = 1; i < n - 1; ++i) {
+    const double hl = x[i] - x[i - 1], hr = x[i + 1] - x[i];
+    const double dl = (y[i] - y[i - 1]) / hl, dr = (y[i + 1] - y[i]) / hr;
+    const double a = hr;                   // sub-diagonal
+    const double b = 2.0 * (hl + hr);      // diagonal
+    const double cc = hl;                  // super-diagonal
+    const double r = 3.0 * (hr * dl + hl * dr);
+    const double m = a / diag[i - 1];
+    diag[i] = b - m * cprev;
+    s[i] = r - m * s[i - 1];
+    cprev = cc;
+  }
+  {
+    const int i = n - 1;
+    const double hl = x[n - 1] - x[n - 2], hll = x[n - 2] - x[n - 3];
+    const double dl = (y[n - 1] - y[n - 2]) / hl, dll = (y[n - 2] - y[n - 3]) / hll;
+    const double a = hl + hll;             // sub-diagonal
+    const double b = hll;                  // diagonal
+    const double r = (hl * hl * dll + (2.0 * hll + 3.0 * hl) * hll * dl) / (hll + hl);
+    const double m = a / diag[i - 1];
+    diag[i] = b - m * cprev;
+    s[i] = r - m * s[i - 1];
+  }
+  // back substitution; super-diagonals: row 0 -> c0, row i -> x[i]-x[i-1]
+  s[n - 1] = s[n - 1] / diag[n - 1];
+  for (int i = n - 2; i >= 0; --i) {
+    const double sup = (i == 0) ? c0 : (x[i] - x[i - 1]);
+    s[i] = (s[i] - sup * s[i + 1]) / diag[i];
+  }
+  for (int i = 0; i < n - 1; ++i) {
+    const double h = x[i + 1] - x[i];
+    const double d = (y[i + 1] - y[i]) / h;
+    c[4 * i + 0] = y[i];
+    c[4 * i + 1] = s[i];
+    c[4 * i + 2] = (3.0 * d - 2.0 * s[i] - s[i + 1]) / h;
+    c[4 * i + 3] = (s[i] + s[i + 1] - 2.0 * d) / (h * h);
+  }
+}
+
+CHOMP_HD double pp_poly(const double* c, int i, double d) {
+  const double* q = c + 4 * i;
+  return fma(fma(fma(q[3], d, q[2]), d, q[1]), d, q[0]);
+}
+
+// Evaluate on arbitrary (increasing) knots: binary search for the interval.
+CHOMP_HD double spline_eval(const double* x, const double* c, int n, double xv) {
+  int lo = 0, hi = n - 2;   // interval index range
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (xv >= x[mid]) lo = mid; else hi = mid - 1;
+  }
+  return pp_poly(c, lo, xv - x[lo]);
+}
+
+// Evaluate on uniform knots x_i = x0 + i*dx.
+CHOMP_HD double spline_eval_uniform(double x0, double dx, const double* c, int n,
+                                    double xv) {
+  int i = (int)floor((xv - x0) / dx);
+  i = i < 0 ? 0 : (i > n - 2 ? n - 2 : i);
+  return pp_poly(c, i, xv - (x0 + dx * (double)i));
+}
+
+// numpy.linspace(a, b, n)[i]
+CHOMP_HD double linspace_at(double a, double b, int n, int i) {
+  if (i == n - 1) return b;
+  return a + (double)i * ((b - a) / (double)(n - 1));
+}
+
+// ---------------------------------------------------------------------------
+// Per-epoch state (one cosmology.SingleEpoch + MassFunction + Halo).
+// ---------------------------------------------------------------------------
+struct Epoch {
+  // inputs (cosmo_dict, redshift)
+  double om0, ob0, ol0, or0, tcmb, h, sigma8, ns, z;
+  // derived background (cosmology.py:39-119, 375-447)
+  double H0, delta_H, growth_norm, growth, sigma_norm, chi;
+  double E0z, omega_m_z, omega_l_z, delta_c, delta_v, rho_bar;
+  // Eisenstein-Hu constants (cosmology.py:460-466)
+  double eh_theta, eh_s, eh_alpha, eh_omh;
+  // Delta^2(k) = amp * exp((3+n) (ln k - ln H0)) * T(k)^2
+  double amp, ln_H0;
+  double k_min, k_max;
+  int flat, open, closed, mf_kind;
+  // mass function (mass_function.py)
+  double stq, st_a, mf_delta_v;
+  double ln_mass_min, ln_mass_max, nu_min, nu_max, m_star, f_norm, bias_norm;
+  double t_alpha, t_beta, t_gamma, t_phi, t_eta;     // Tinker f(nu)
+  double tb_A, tb_a, tb_C, tb_dca;                   // Tinker bias constants
+  int n_search, pad0;
+  // halo profile (halo.py:71-83, 873-902)
+  double c0, beta, prof_delta_v, ln_rv_const, ln_c_const;
+  // HOD (hod.py:156-186)
+  double hod_log_M_min, hod_sigma, hod_log_M_0, hod_log_M_1p, hod_alpha;
+  double hod_first_zero, hod_second_zero, hod_safe_norm, hod_M0, hod_M1p;
+  double ln_nu_lo_first, ln_nu_lo_second;
+  double n_bar_over_rho_bar, n_bar;
+  // HaloFit (halo.py:1261-1319)
+  double hf_f1, hf_f2, hf_f3, hf_k_s, hf_n_eff, hf_C, hf_a_n, hf_b_n, hf_c_n,
+      hf_gamma_n, hf_alpha_n, hf_beta_n, hf_mu_n, hf_nu_n;
+  double pad_[2];
+};
+static_assert(sizeof(Epoch) % 16 == 0, "Epoch must keep LDS carve-ups 16-byte aligned");
+
+// cosmology.py:165-178
+CHOMP_HD double E0_of(double om0, double ol0, double or0, double z) {
+  const double a = 1.0 / (1.0 + z);
+  return ol0 + om0 / (a * a * a) + or0 / (a * a * a * a);
+}
+
+// cosmology.py:215-231 (always returned by growth_factor_eval, :326)
+CHOMP_HD double growth_approx(double om0, double ol0, double a) {
+  const double om = om0 / (a * a * a);
+  const double denom = ol0 + om;
+  const double Omega_m = om / denom;
+  const double Omega_L = ol0 / denom;
+  const double coeff = 5.0 * Omega_m / (2.0 / a);
+  const double term1 = Omega_m * (4.0 / 7.0);
+  const double term3 = (1.0 + 0.5 * Omega_m) * (1.0 + Omega_L / 70.0);
+  return coeff / (term1 - Omega_L + term3);
+}
+
+// SingleEpoch.__init__ minus the two integrals (chi, sigma_norm).
+CHOMP_HD void epoch_background(Epoch& e, double cosmo_precision, double k_min,
+                               double k_max) {
+  if (e.z < 0.0) e.z = 0.0;
+  e.H0 = 100.0 / (2.998 * 100000.0);
+  e.ln_H0 = log(e.H0);
+  const double tot = e.om0 + e.ol0 + e.or0;
+  e.flat = (tot <= 1.0 + cosmo_precision && tot >= 1.0 - cosmo_precision) ? 1 : 0;
+  e.open = (tot <= 1.0 - cosmo_precision) ? 1 : 0;
+  e.closed = (tot > 1.0 + cosmo_precision) ? 1 : 0;
+  e.k_min = k_min;
+  e.k_max = k_max;
+  e.delta_H = 1.94e-5 * pow(e.om0, -0.785 - 0.05 * log(e.om0)) *
+              exp(-0.95 * (e.ns - 1.0) - 0.169 * (e.ns - 1.0) * (e.ns - 1.0));
+  e.growth_norm = growth_approx(e.om0, e.ol0, 1.0);
+  e.growth = growth_approx(e.om0, e.ol0, 1.0 / (1.0 + e.z)) / e.growth_norm;
+  e.E0z = E0_of(e.om0, e.ol0, e.or0, e.z);
+  const double opz = 1.0 + e.z;
+  e.omega_m_z = e.om0 * (opz * opz * opz) / e.E0z;
+  e.omega_l_z = e.ol0 / e.E0z;
+  double dc = 0.15 * pow(12.0 * kPi, 2.0 / 3.0);      // cosmology.py:393-407
+  double dv = 178.0;                                  // :409-423
+  if (e.open) {
+    dc *= pow(e.omega_m_z, 0.0185);
+    dv /= pow(e.omega_m_z, 0.7);
+  }
+  if (e.flat && e.om0 < 1.0001) {
+    dc *= pow(e.omega_m_z, 0.0055);
+    dv /= pow(e.omega_m_z, 0.55);
+  }
+  e.delta_c = dc;
+  e.delta_v = dv / e.growth;
+  e.rho_bar = (1.879 / (1.989) * (3.086 * 3.086 * 3.086) * 1e10 * e.E0z) *
+              e.omega_m_z;                            // :437-447
+  // Eisenstein-Hu constants; (Omb2)**(3/4) is **0 under Python 2 -> sqrt(11).
+  const double Omh2 = e.om0 * e.h * e.h;
+  const double ratio = e.ob0 / e.om0;
+  e.eh_theta = e.tcmb / 2.7;
+  e.eh_s = 44.5 * log(9.83 / Omh2) / sqrt(1.0 + 10.0 * 1.0);
+  e.eh_alpha = 1.0 - 0.328 * log(431.0 * Omh2) * ratio +
+               0.38 * log(22.3 * Omh2) * ratio * ratio;
+  e.eh_omh = e.om0 * e.h;
+  e.sigma_norm = 1.0;
+  e.amp = e.delta_H * e.delta_H / e.h * (e.growth * e.growth);
+}
+
+// cosmology.py:449-472
+CHOMP_HD double eh_transfer(const Epoch& e, double k) {
+  const double t = 1.0 + 0.43 * k * e.eh_s;
+  const double t2 = t * t;
+  const double Gamma_eff = e.eh_omh * (e.eh_alpha + (1.0 - e.eh_alpha) / (t2 * t2));
+  const double q = k * e.eh_theta / Gamma_eff;
+  const double L0 = log(2.0 * kE + 1.8 * q);
+  const double C0 = 14.2 + 731.0 / (1.0 + 62.5 * q);
+  return L0 / (L0 + C0 * q * q);
+}
+
+// Delta^2(k) = k^3 P(k)/(2 pi^2), cosmology.py:574-587, from ln k.
+CHOMP_HD double delta_k_ln(const Epoch& e, double ln_k, double k) {
+  const double T = eh_transfer(e, k);
+  return e.amp * e.sigma_norm * e.sigma_norm * exp((3.0 + e.ns) * (ln_k - e.ln_H0)) *
+         T * T;
+}
+
+// linear_power(k), cosmology.py:589-600
+CHOMP_HD double linear_power(const Epoch& e, double k) {
+  if (!(k > 1e-16)) return 1e-16;
+  const double lk = log(k);
+  return 2.0 * kPi * kPi * delta_k_ln(e, lk, k) / (k * k * k);
+}
+
+// sigma_r limits, cosmology.py:611-632
+CHOMP_HD void sigma_limits(const Epoch& e, double scale, double* ln_lo, double* ln_hi) {
+  double k_min = e.k_min, k_max = e.k_max;
+  const double need_min = 1.0 / scale / 10.0;
+  const double need_max = 1.0 / scale * 14.0662;
+  if (need_min <= k_min && need_min > e.k_min / 100.0) k_min = need_min;
+  else if (need_min <= k_min && need_min <= e.k_min / 100.0) k_min = e.k_min / 100.0;
+  if (need_max >= k_max && need_max < e.k_max * 100.0) k_max = need_max;
+  else if (need_max >= k_max && need_max >= e.k_max * 100.0) k_max = e.k_max * 100.0;
+  *ln_lo = log(k_min);
+  *ln_hi = log(k_max);
+}
+
+// Integrand of sigma^2(R) over ln k divided by 2 pi^2 (cosmology.py:644-660):
+// dk P W^2 k^2 / (2 pi^2) = Delta^2(k) W(kR)^2.
+struct SigmaIntegrand {
+  const Epoch* e;
+  double scale;
+  CHOMP_HD double operator()(double ln_k) const {
+    const double k = exp(ln_k);
+    const double kR = scale * k;
+    double s, c;
+#if defined(__HIP_DEVICE_COMPILE__)
+    sincos(kR, &s, &c);
+#else
+    s = sin(kR); c = cos(kR);
+#endif
+    const double kR2 = kR * kR;
+    const double W = 3.0 * (s / (kR2 * kR) - c / kR2);
+    return delta_k_ln(*e, ln_k, k) * W * W;
+  }
+};
+
+// HaloFit sigma^2(R) with a Gaussian filter, halo.py:1321-1323.
+struct HalofitSigmaIntegrand {
+  const Epoch* e;
+  double R;
+  CHOMP_HD double operator()(double ln_k) const {
+    const double k = exp(ln_k);
+    return delta_k_ln(*e, ln_k, k) * exp(-k * k * R * R);
+  }
+};
+
+// E(z) = c/H(z), cosmology.py:153-163
+struct EIntegrand {
+  double om0, ol0, or0, H0;
+  CHOMP_HD double operator()(double z) const {
+    return 1.0 / (H0 * sqrt(E0_of(om0, ol0, or0, z)));
+  }
+};
+
+CHOMP_HD double scale_of_mass(const Epoch& e, double mass) {     // cosmology.py:671
+  return pow(3.0 * mass / (4.0 * kPi * e.rho_bar), 1.0 / 3.0);
+}
+
+// ---------------------------------------------------------------------------
+// Mass function f(nu), b(nu): Sheth-Tormen (mass_function.py:243-255, 290-302)
+// and Tinker10 (:494-530).
+// ---------------------------------------------------------------------------
+CHOMP_HD double f_nu(const Epoch& e, double nu) {
+  if (e.mf_kind == 0) {
+    const double np_ = nu * e.st_a;
+    return e.f_norm * (1.0 + pow(np_, -1.0 * e.stq)) * sqrt(np_) * exp(-0.5 * np_) / nu;
+  }
+  const double sq = sqrt(nu);
+  return e.t_alpha * (1.0 + pow(e.t_beta * sq, -2.0 * e.t_phi)) * pow(nu, e.t_eta) *
+         exp(-e.t_gamma * nu / 2.0) / sq;
+}
+
+CHOMP_HD double bias_nu(const Epoch& e, double nu) {
+  if (e.mf_kind == 0) {
+    const double np_ = nu * e.st_a;
+    return e.bias_norm * (1.0 + (np_ - 1.0) / e.delta_c +
+                          2.0 * e.stq / (e.delta_c * (1.0 + pow(np_, e.stq))));
+  }
+  const double sq = sqrt(nu);
+  const double sa = pow(sq, e.tb_a);
+  return e.bias_norm * (1.0 - e.tb_A * sa / (sa + e.tb_dca) + 0.183 * pow(sq, 1.5) +
+                        e.tb_C * pow(sq, 2.4));
+}
+
+// Tinker bias constants from delta_v (mass_function.py:521-528).
+CHOMP_HD void tinker_bias_constants(Epoch& e) {
+  const double y = log10(e.mf_delta_v);
+  const double ex = exp(-pow(4.0 / y, 4.0));
+  e.tb_A = 1.0 + 0.24 * y * ex;
+  e.tb_a = 0.44 * y - 0.88;
+  e.tb_C = 0.019 + 0.107 * y + 0.19 * ex;
+  e.tb_dca = pow(e.delta_c, e.tb_a);
+}
+
+// ---------------------------------------------------------------------------
+// Zheng07 HOD moments (hod.py:189-230).
+// ---------------------------------------------------------------------------
+CHOMP_HD double zheng_central(const Epoch& e, double mass) {
+  const double lm = log10(mass);
+  if (e.hod_sigma <= 0.0) return lm > e.hod_log_M_min ? 1.0 : 0.0;
+  return 0.5 * (1.0 + erf((lm - e.hod_log_M_min) / e.hod_sigma));
+}
+CHOMP_HD double zheng_satellite(const Epoch& e, double mass) {
+  const double diff = mass - e.hod_M0;
+  if (!(diff > 0.0)) return 0.0;
+  return zheng_central(e, mass) * pow(diff / e.hod_M1p, e.hod_alpha);
+}
+CHOMP_HD double zheng_first(const Epoch& e, double mass) {
+  return zheng_central(e, mass) + zheng_satellite(e, mass);
+}
+CHOMP_HD double zheng_second(const Epoch& e, double mass) {
+  const double ns = zheng_satellite(e, mass);
+  return (2.0 + ns) * ns;
+}
+
+// ---------------------------------------------------------------------------
+// NFW profile transform y(k, M), halo.py:561-585.  The reference evaluates
+// ln r_v and ln c through splines of exactly linear functions of ln M
+// (halo.py:839-855, 873-902); they are evaluated in closed form here.
+// ---------------------------------------------------------------------------
+CHOMP_HD double y_nfw(const Epoch& e, const SiCiTab& T, double ln_k, double ln_mass) {
+  const double ln_c = e.ln_c_const + e.beta * ln_mass;
+  const double ln_rv = (e.ln_rv_const + ln_mass) * (1.0 / 3.0);
+  const double con = exp(ln_c);
+  const double cp = 1.0 + con;
+  const double z = exp(ln_k + ln_rv - ln_c);
+  const double cz = con * z;
+  double sz, cz_c, scz, ccz;
+#if defined(__HIP_DEVICE_COMPILE__)
+  sincos(z, &sz, &cz_c);
+  sincos(cz, &scz, &ccz);
+#else
+  sz = sin(z); cz_c = cos(z); scz = sin(cz); ccz = cos(cz);
+#endif
+  // sin/cos of (1+c) z by angle addition
+  const double s_cp = sz * ccz + cz_c * scz;
+  const double c_cp = cz_c * ccz - sz * scz;
+  double si_z, ci_z, si_cz, ci_cz;
+  sici_sc(z, sz, cz_c, T, &si_z, &ci_z);
+  sici_sc(cp * z, s_cp, c_cp, T, &si_cz, &ci_cz);
+  const double rho_km = cz_c * (ci_cz - ci_z) + sz * (si_cz - si_z) - scz / (cp * z);
+  const double mass_k = log(cp) - con / cp;
+  return rho_km / mass_k;
+}
+
+// Halo constants from the profile halo_dict (halo.py:71-83, 873-902).
+CHOMP_HD void halo_constants(Epoch& e, double c0_in, double beta, double delta_v_in) {
+  e.c0 = c0_in / (1.0 + e.z);
+  e.beta = beta;
+  e.prof_delta_v = (delta_v_in == -1.0) ? e.delta_v : delta_v_in;
+  e.ln_rv_const = log(3.0 / (4.0 * kPi * e.prof_delta_v * e.rho_bar));
+  e.ln_c_const = log(e.c0) - e.beta * log(e.m_star);
+}
+
+}  // namespace chomp

@@ -1,0 +1,103 @@
+"""Batched (k, z) grids and their multi-GPU sharding.
+
+The reference sweeps a (k, z) grid by calling halo.set_redshift(z) and
+power_mm(k_array) once per z; every z rebuilds ~400 Romberg
+integrals in Python.  Here the z-axis (or a list of cosmologies: the
+SimulationDesign axis, simulation_design.py:116-155) is a batch of "epochs" whose
+tables are built by the same kernel launches, and Stage E evaluates the whole grid.
+
+Multi-GPU (one process per GPU, torch.distributed / RCCL): epochs are independent,
+so rank r builds and evaluates epochs r, r+W, r+2W, ... (interleaved: the set-up
+cost grows with z) and ONE all-gather of the padded row blocks re-assembles the
+spectrum on every rank.  No other collective is needed.
+"""
+import numpy
+
+from . import _lib
+from . import cosmology
+from . import defaults
+from . import hod as hod_mod
+
+_WHICH = {"linear_power": (_lib.P_LIN, 0), "power_mm": (_lib.P_MM, _lib.FAM_MM),
+          "power_gm": (_lib.P_GM, _lib.FAM_GM), "power_mg": (_lib.P_GM, _lib.FAM_GM),
+          "power_gg": (_lib.P_GG, _lib.FAM_GG)}
+
+
+def shard_indices(n, rank, world):
+    """Epoch indices of `rank`: interleaved so high-z (expensive) rows spread."""
+    return list(range(rank, n, world))
+
+
+def rows_per_rank(n, world):
+    return (n + world - 1) // world
+
+
+def unshard_order(n, world):
+    """Positions, in the gathered [world * rows_per_rank] layout, of epochs 0..n-1."""
+    rpr = rows_per_rank(n, world)
+    return [(i % world) * rpr + i // world for i in range(n)]
+
+
+class HaloGrid(object):
+    """P(k, z) for a batch of epochs on one GPU (or this rank's shard of it).
+
+    z: 1-D array of redshifts (one epoch each); cosmo_dict: one dict or a list of
+    dicts (one per epoch); mass_function: 'st' or 'tinker'; halo_dict, hod_dict:
+    one dict (or list).  Every epoch follows the reference's construction order
+    Halo(z, HODZheng(hod_dict), SingleEpoch(z, cosmo_dict), MassFunction(...)).
+    """
+
+    def __init__(self, z, cosmo_dict=None, halo_dict=None, hod_dict=None,
+                 mass_function="st", device=None, stream=None, rank=0, world=1):
+        self.z_all = numpy.atleast_1d(numpy.asarray(z, dtype=numpy.float64))
+        self.n_all = self.z_all.size
+        self.rank, self.world = rank, world
+        self.idx = shard_indices(self.n_all, rank, world)
+        pick = lambda v: [v[i] for i in self.idx] if isinstance(v, (list, tuple)) else v
+        self.cosmo = pick(cosmo_dict if cosmo_dict is not None
+                          else defaults.default_cosmo_dict)
+        self.halo = pick(halo_dict if halo_dict is not None
+                         else defaults.default_halo_dict)
+        hd = hod_dict if hod_dict is not None else defaults.default_hod_dict
+        self.hod = ([hod_mod.HODZheng(h) for h in pick(hd)]
+                    if isinstance(hd, (list, tuple)) else hod_mod.HODZheng(hd))
+        self.kind = {"st": _lib.MF_ST, "tinker": _lib.MF_TINKER}[mass_function]
+        self.z = self.z_all[self.idx]
+        self.ctx = cosmology._context(stream=stream, device=device)
+        self._tables = 0
+
+    def setup(self, which="power_mm"):
+        """Stage K for this rank's epochs (asynchronous on the context's stream)."""
+        _, need = _WHICH[which]
+        if len(self.idx) == 0:
+            return
+        self.ctx.epochs_set(self.cosmo, self.z)
+        self.ctx.mass_setup(self.halo, self.kind)
+        self.ctx.halo_setup(self.halo, self.hod, need)
+        self._tables = need
+
+    def power(self, which, k, out=None):
+        """Stage E: [n_local, nk] for numpy or torch-cuda k."""
+        code, need = _WHICH[which]
+        if (self._tables & need) != need:
+            self.setup(which)
+        return self.ctx.power(code, k, 0, len(self.idx), out=out)
+
+    def power_all(self, which, k):
+        """Stage K + E on this rank's shard, then all-gather (torch.distributed) and
+        re-order to the caller's z order.  k: torch cuda tensor.  Returns the full
+        [n_all, nk] tensor on every rank."""
+        import torch
+        import torch.distributed as dist
+        rpr = rows_per_rank(self.n_all, self.world)
+        nk = k.numel()
+        local = torch.zeros((rpr, nk), dtype=torch.float64, device=k.device)
+        if len(self.idx):
+            self.power(which, k, out=local[:len(self.idx)])
+        self.ctx.sync()
+        if self.world == 1:
+            return local[:self.n_all]
+        full = torch.empty((self.world * rpr, nk), dtype=torch.float64, device=k.device)
+        dist.all_gather_into_tensor(full, local)
+        order = torch.as_tensor(unshard_order(self.n_all, self.world), device=k.device)
+        return full.index_select(0, order)

@@ -1,0 +1,322 @@
+"""halo.Halo / halo.HaloFit with the reference's constructor, setters and power_*
+methods (halo.py:23-1086, 1236-1412), every integral and spline on the MI355X.
+
+The object keeps the reference's lazy-initialisation flags (halo.py:93-104) and
+their exact invalidation rules, including the ones that look like oversights,
+because they change the numbers a drop-in user gets:
+
+* set_halo() hands the new dictionary to the mass function only; the profile
+  splines (c0, beta) and the Halo's delta_v keep the constructor's values and the
+  h_m / pp_mm flags are NOT reset (halo.py:220-235);
+* HaloFit fixes f_1..f_3 at construction and builds its sigma-spline once, at the
+  first power_mm call; set_redshift()/set_cosmology() never refresh either
+  (halo.py:1254-1266, 1337-1338).
+"""
+import numpy
+
+from . import _lib
+from . import cosmology
+from . import defaults
+from . import hod
+from . import mass_function
+
+_FLAG_BITS = (("_initialized_h_m", _lib.T_H_M), ("_initialized_pp_mm", _lib.T_PP_MM),
+              ("_initialized_h_g", _lib.T_H_G), ("_initialized_pp_gm", _lib.T_PP_GM),
+              ("_initialized_pp_gg", _lib.T_PP_GG))
+
+
+class Halo(object):
+    """Seljak (2000) halo model (halo.py:23-1086)."""
+
+    def __init__(self, redshift=0.0, input_hod=None, cosmo_single_epoch=None,
+                 mass_func=None, halo_dict=None, extrapolate=False, **kws):
+        self._k_min = defaults.default_limits['k_min']
+        self._k_max = defaults.default_limits['k_max']
+        self._ln_k_max = numpy.log(self._k_max)
+        self._ln_k_min = numpy.log(self._k_min)
+        self._ln_k_array = numpy.linspace(
+            self._ln_k_min, self._ln_k_max,
+            defaults.default_precision["halo_npoints"])
+        self._redshift = redshift
+        if cosmo_single_epoch is None:
+            cosmo_single_epoch = cosmology.SingleEpoch(redshift)
+        self.cosmo = cosmo_single_epoch
+        if halo_dict is None:
+            halo_dict = defaults.default_halo_dict
+        self.halo_dict = halo_dict
+        if mass_func is None:
+            mass_func = mass_function.MassFunction(
+                self._redshift, self.cosmo, self.halo_dict)
+        self.mass = mass_func
+        self.c0 = halo_dict["c0"] / (1.0 + self._redshift)
+        self.beta = halo_dict["beta"]
+        self.alpha = halo_dict["alpha"]
+        if self.alpha != -1.0:
+            raise _lib.ChompScopeError(
+                "halo alpha != -1 (y_general, halo.py:491-559) is outside the "
+                "hot-path scope: NFW only")
+        self._h = self.cosmo._h
+        if input_hod is None:
+            input_hod = hod.HODZheng()
+        self.local_hod = input_hod
+        if extrapolate:
+            raise _lib.ChompScopeError(
+                "extrapolate=True (halo.py:300-312, 341-367) is not accelerated yet")
+        self._extrapolate = extrapolate
+        # the dictionary the PROFILE sees: fixed here, untouched by set_halo
+        self._profile_dict = dict(halo_dict)
+        self._ctx = None
+        self._epoch_sig = None
+        self._mass_sig = None
+        self._nbar_valid = False
+        self._reset_flags(all_tables=True)
+
+    # -- device orchestration --------------------------------------------------
+    def _reset_flags(self, all_tables):
+        if all_tables:
+            self._initialized_h_m = False
+            self._initialized_pp_mm = False
+        self._initialized_h_g = False
+        self._initialized_pp_gm = False
+        self._initialized_pp_gg = False
+
+    def _profile(self):
+        # delta_v of the Halo is re-read from self.halo_dict on set_cosmology
+        # (halo.py:151-153) but c0/beta stay with the splines built at __init__ /
+        # set_cosmology from self.halo_dict as well; set_halo changes neither.
+        return self._profile_dict
+
+    def _sync(self, need_tables):
+        """Bring the device tables named by the CHOMP_T_* mask up to date."""
+        if self._ctx is None:
+            self._ctx = cosmology._context()
+        ctx = self._ctx
+        esig = (tuple(sorted(self.cosmo.cosmo_dict.items())), self.cosmo._redshift)
+        if esig != self._epoch_sig:
+            ctx.epochs_set(self.cosmo.cosmo_dict, [self.cosmo._redshift])
+            self._epoch_sig = esig
+            self._mass_sig = None
+            self._nbar_valid = False
+            self._after_epochs_set()
+        msig = (tuple(sorted(self.mass.halo_dict.items())), self.mass._kind)
+        if msig != self._mass_sig:
+            ctx.mass_setup(self.mass.halo_dict, self.mass._kind)
+            self._mass_sig = msig
+            self._nbar_valid = False
+        build = 0
+        for flag, bit in _FLAG_BITS:
+            if (need_tables & bit) and not getattr(self, flag):
+                build |= bit
+        if build or not self._nbar_valid:
+            ctx.halo_setup(self._profile(), self.local_hod, build)
+            for flag, bit in _FLAG_BITS:
+                if build & bit:
+                    setattr(self, flag, True)
+            self._nbar_valid = True
+        return ctx
+
+    def _after_epochs_set(self):
+        pass
+
+    def _scalars(self):
+        return self._sync(0).scalars(0)
+
+    n_bar = property(lambda self: float(self._scalars()["n_bar"]))
+    n_bar_over_rho_bar = property(
+        lambda self: float(self._scalars()["n_bar_over_rho_bar"]))
+    rho_bar = property(lambda self: float(self._scalars()["rho_bar"]))
+
+    @property
+    def delta_v(self):
+        dv = self._profile()['delta_v']
+        return float(self._scalars()["delta_v"]) if dv == -1 else dv
+
+    def _power(self, which, need, k):
+        ka = numpy.asarray(k, dtype=numpy.float64)
+        ctx = self._sync(need)
+        return ctx.power(which, ka, 0, 1).reshape(ka.shape)
+
+    # -- reference surface -----------------------------------------------------
+    def get_extrapolation(self):
+        return self._extrapolate
+
+    def set_extrapolation(self, boolean):
+        if boolean:
+            raise _lib.ChompScopeError(
+                "extrapolation beyond [k_min, k_max] (halo.py:300-312) is not "
+                "accelerated yet")
+        self._extrapolate = boolean
+
+    def get_cosmology(self):
+        return self.cosmo.get_cosmology()
+
+    def get_cosmology_object(self):
+        return self.cosmo
+
+    def set_cosmology(self, cosmo_dict, redshift=None):
+        """halo.py:135-173."""
+        if redshift is None:
+            redshift = self._redshift
+        self.cosmo_dict = cosmo_dict
+        self._redshift = redshift
+        self.cosmo = cosmology.SingleEpoch(redshift, cosmo_dict)
+        self._h = self.cosmo._h
+        self.c0 = self.halo_dict["c0"] / (1.0 + redshift)
+        self.mass.set_cosmology_object(self.cosmo)
+        # _initialize_halo_splines is re-run here (halo.py:162) with the Halo's OWN
+        # dictionary for c0 / delta_v (:151-157) and the current self.beta.
+        self._profile_dict = dict(self._profile_dict, c0=self.halo_dict["c0"],
+                                  beta=self.beta,
+                                  delta_v=self.halo_dict["delta_v"])
+        self._nbar_valid = False
+        self._reset_flags(all_tables=True)
+
+    def get_hod(self, return_object=False):
+        return self.local_hod.get_hod()
+
+    def get_hod_object(self):
+        return self.local_hod
+
+    def set_hod(self, hod_dict):
+        """halo.py:181-192."""
+        self.local_hod.set_hod(hod_dict)
+        self._nbar_valid = False
+        self._reset_flags(all_tables=False)
+
+    def set_hod_object(self, input_hod):
+        """halo.py:194-212."""
+        self.local_hod = input_hod
+        self._nbar_valid = False
+        self._reset_flags(all_tables=False)
+
+    def get_halo(self):
+        return self.halo_dict
+
+    def set_halo(self, halo_dict=None):
+        """halo.py:220-235: only the mass function sees the new dictionary."""
+        self.c0 = halo_dict["c0"] / (1.0 + self._redshift)
+        self.beta = halo_dict["beta"]
+        self.alpha = -1.0
+        self.mass.set_halo(halo_dict)
+        self.set_hod_object(self.local_hod)
+
+    def get_mass(self):
+        return self.mass
+
+    def get_redshift(self):
+        return self._redshift
+
+    def set_redshift(self, redshift):
+        if redshift != self._redshift:
+            self.set_cosmology(self.cosmo.cosmo_dict, redshift)
+
+    def linear_power(self, k):
+        return self._power(_lib.P_LIN, 0, k)
+
+    def power_mm(self, k):
+        return self._power(_lib.P_MM, _lib.FAM_MM, k)
+
+    def power_gm(self, k):
+        return self._power(_lib.P_GM, _lib.FAM_GM, k)
+
+    def power_mg(self, k):
+        return self.power_gm(k)
+
+    def power_gg(self, k):
+        return self._power(_lib.P_GG, _lib.FAM_GG, k)
+
+    def virial_radius(self, mass):
+        return self._sync(0).eval("virial_radius", mass)
+
+    def concentration(self, mass):
+        return self._sync(0).eval("concentration", mass)
+
+    def y(self, ln_k, mass):
+        m = numpy.asarray(mass, dtype=numpy.float64)
+        out = self._sync(0).y_nfw(0, ln_k, m)
+        return out.reshape(numpy.broadcast(numpy.asarray(ln_k), m).shape)
+
+    y_nfw = y
+
+    # knot accessors (the reference's *_spline evaluated inside [k_min, k_max])
+    def _knots(self, name, need):
+        return self._sync(need).table(name, 0)
+
+    def _h_m(self, k):
+        return self._ranged("h_m", _lib.T_H_M, k)
+
+    def _pp_mm(self, k):
+        return self._ranged("pp_mm", _lib.T_PP_MM, k)
+
+    def _h_g(self, k):
+        return self._ranged("h_g", _lib.T_H_G, k)
+
+    def _pp_gm(self, k):
+        return self._ranged("pp_gm", _lib.T_PP_GM, k)
+
+    def _pp_gg(self, k):
+        return self._ranged("pp_gg", _lib.T_PP_GG, k)
+
+    def _ranged(self, name, bit, k):
+        """halo.py:649-672 -- only exact at the knots here: served from the knot
+        table (used by write_power_components-style callers at the knot k's)."""
+        ka = numpy.asarray(k, dtype=numpy.float64)
+        knots = self._knots(name, bit)
+        idx = numpy.rint((numpy.log(ka) - self._ln_k_min) /
+                         (self._ln_k_array[1] - self._ln_k_array[0])).astype(int)
+        ok = (ka >= self._k_min) & (ka <= self._k_max)
+        idx = numpy.clip(idx, 0, knots.size - 1)
+        if not numpy.allclose(numpy.log(ka[ok]), self._ln_k_array[idx[ok]], atol=1e-12):
+            raise _lib.ChompScopeError(
+                "_%s(k) is only served at the spline knots" % name)
+        return numpy.where(ok, knots[idx], 0.0)
+
+
+class HaloFit(Halo):
+    """HALOFIT with the Takahashi et al. 2012 coefficients (halo.py:1236-1412)."""
+
+    def __init__(self, redshift=0.0, input_hod=None, cosmo_single_epoch=None,
+                 mass_func=None, halo_dict=None, **kws):
+        Halo.__init__(self, redshift, input_hod, cosmo_single_epoch, mass_func,
+                      halo_dict)
+        self._initialize_halo_fit()
+        self._initialized_sigma_spline = False
+        self._hf_coef = None
+
+    def _initialize_halo_fit(self):
+        om = self.cosmo.omega_m()
+        self._f_1 = numpy.power(om, -0.0307)
+        self._f_2 = numpy.power(om, -0.0585)
+        self._f_3 = numpy.power(om, 0.0743)
+        self._omega_l = self.cosmo.omega_l()
+        self._w = self.cosmo.w(self._redshift)
+
+    def _after_epochs_set(self):
+        # the device epoch was rebuilt: re-install the (possibly stale, as in the
+        # reference) HaloFit coefficient block
+        if self._initialized_sigma_spline and self._hf_coef is not None:
+            self._ctx.halofit_put(self._hf_coef, 0)
+
+    def _ensure_halofit(self):
+        ctx = self._sync(0)
+        if not self._initialized_sigma_spline:
+            ctx.halofit_setup(0, 0, float(self._f_1), float(self._f_2),
+                              float(self._f_3), float(self._omega_l), float(self._w))
+            self._hf_coef = ctx.halofit_get(0)
+            self._initialized_sigma_spline = True
+            (self._k_s, self._n_eff, self._C, self._a_n, self._b_n, self._c_n,
+             self._gamma_n, self._alpha_n, self._beta_n, self._mu_n,
+             self._nu_n) = [float(v) for v in self._hf_coef[3:14]]
+        return ctx
+
+    def power_mm(self, k):
+        self._ensure_halofit()
+        return self._power(_lib.P_MM | _lib.P_HALOFIT, 0, k)
+
+    def power_gm(self, k):
+        self._ensure_halofit()
+        return self._power(_lib.P_GM | _lib.P_HALOFIT, _lib.FAM_GM, k)
+
+    def power_gg(self, k):
+        self._ensure_halofit()
+        return self._power(_lib.P_GG | _lib.P_HALOFIT, _lib.FAM_GG, k)

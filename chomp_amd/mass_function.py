@@ -1,0 +1,135 @@
+"""mass_function.MassFunction / TinkerMassFunction (mass_function.py:25-362,
+436-564) over the HIP library: the mass-limit search, the 50 sigma(M) integrals,
+the nu <-> ln M splines and the normalisations all run on the device."""
+import numpy
+
+from . import _lib
+from . import cosmology
+from . import defaults
+
+
+class MassFunction(object):
+    """Sheth-Tormen mass function and bias (mass_function.py:25-362)."""
+    _kind = _lib.MF_ST
+
+    def __init__(self, redshift=0.0, cosmo_single_epoch=None, halo_dict=None, **kws):
+        self._redshift = redshift
+        if cosmo_single_epoch is None:
+            cosmo_single_epoch = cosmology.SingleEpoch(self._redshift)
+        self.cosmo = cosmo_single_epoch
+        self.cosmo.set_redshift(self._redshift)       # mutates the caller's object (:45)
+        if halo_dict is None:
+            halo_dict = defaults.default_halo_dict
+        self.halo_dict = halo_dict
+        self.stq = halo_dict["stq"]
+        self.st_little_a = halo_dict["st_little_a"]
+        self.c0 = halo_dict["c0"] / (1.0 + redshift)
+        self._ctx = None
+        self._sig = None
+        self._sc = None
+
+    # -- device state ----------------------------------------------------------
+    def _signature(self):
+        return (tuple(sorted(self.cosmo.cosmo_dict.items())), self.cosmo._redshift,
+                tuple(sorted(self.halo_dict.items())), self._kind)
+
+    def _dev(self):
+        sig = self._signature()
+        if self._ctx is None:
+            self._ctx = cosmology._context()
+        if sig != self._sig:
+            self._ctx.epochs_set(self.cosmo.cosmo_dict, [self.cosmo._redshift])
+            self._ctx.mass_setup(self.halo_dict, self._kind)
+            self._sc = self._ctx.scalars(0)
+            self._sig = sig
+        return self._ctx
+
+    def _scalar(self, name):
+        self._dev()
+        return float(self._sc[name])
+
+    delta_c = property(lambda self: self._scalar("delta_c"))
+    delta_v = property(lambda self: self._scalar("mf_delta_v"))
+    ln_mass_min = property(lambda self: self._scalar("ln_mass_min"))
+    ln_mass_max = property(lambda self: self._scalar("ln_mass_max"))
+    nu_min = property(lambda self: self._scalar("nu_min"))
+    nu_max = property(lambda self: self._scalar("nu_max"))
+    m_star = property(lambda self: self._scalar("m_star"))
+    f_norm = property(lambda self: self._scalar("f_norm"))
+    bias_norm = property(lambda self: self._scalar("bias_norm"))
+    _ln_mass_array = property(lambda self: self._dev().table("ln_mass"))
+    _nu_array = property(lambda self: self._dev().table("nu"))
+
+    # -- reference surface -----------------------------------------------------
+    def get_redshift(self):
+        return self._redshift
+
+    def set_redshift(self, redshift):
+        self._redshift = redshift
+        self.cosmo.set_redshift(redshift)
+        self.c0 = self.halo_dict["c0"] / (1.0 + redshift)
+
+    def get_cosmology(self):
+        return self.cosmo.get_cosmology()
+
+    def set_cosmology(self, cosmo_dict, redshift=None):
+        if redshift is None:
+            redshift = self._redshift
+        self._redshift = redshift
+        self.cosmo.set_cosmology(cosmo_dict, redshift)
+        self.c0 = self.halo_dict["c0"] / (1.0 + redshift)
+
+    def set_cosmology_object(self, cosmo_single_epoch):
+        self._redshift = cosmo_single_epoch.redshift()
+        self.cosmo = cosmo_single_epoch
+        self.c0 = self.halo_dict["c0"] / (1.0 + self._redshift)
+
+    def get_halo(self):
+        return self.halo_dict
+
+    def set_halo(self, halo_dict):
+        self.halo_dict = halo_dict
+        self.stq = self.halo_dict["stq"]
+        self.st_little_a = self.halo_dict["st_little_a"]
+        self.c0 = self.halo_dict["c0"] / (1.0 + self._redshift)
+
+    def f_nu(self, nu):
+        return self._dev().eval("f_nu", nu)
+
+    def f_m(self, mass):
+        return self.f_nu(self.nu(mass))
+
+    def bias_nu(self, nu):
+        return self._dev().eval("bias_nu", nu)
+
+    def bias_m(self, mass):
+        return self.bias_nu(self.nu(mass))
+
+    def nu(self, mass):
+        return self._dev().eval("nu_of_mass", mass)
+
+    def ln_mass(self, nu):
+        return self._dev().eval("ln_mass_of_nu", nu)
+
+    def mass(self, nu):
+        return numpy.exp(self.ln_mass(nu))
+
+
+class TinkerMassFunction(MassFunction):
+    """Tinker et al. 2010 (mass_function.py:436-564)."""
+    _kind = _lib.MF_TINKER
+
+    def _alpha(self):
+        return self._scalar("t_alpha")
+
+    def _beta(self):
+        return self._scalar("t_beta")
+
+    def _gamma(self):
+        return self._scalar("t_gamma")
+
+    def _phi(self):
+        return self._scalar("t_phi")
+
+    def _eta(self):
+        return self._scalar("t_eta")

@@ -1,0 +1,306 @@
+/*
+ * chomp_mi355x.h -- C ABI of libchomp_mi355x.so, the MI355X (gfx950) implementation
+ * of CHOMP's halo-model + Limber-projection hot path.
+ *
+ * The reference (morriscb/chomp) has no FFI: its boundary for this path is the
+ * Python method surface of halo.Halo / kernel.Kernel / correlation.Correlation.
+ * Each entry point below names the reference interface it replaces (file:line in
+ * /root/reference).  The chomp_amd Python package binds these with ctypes and mirrors the
+ * reference classes; INTEGRATION.md shows the stub a reference maintainer would
+ * add.  All functions return CHOMP_OK (0) or a negative error code; the message
+ * is available from chomp_last_error().  Plain pointers and sizes only.
+ *
+ * Memory-space convention: every array argument is paired with (or covered by) a
+ * `mem` argument: CHOMP_HOST (pointer is host memory; the library stages it) or
+ * CHOMP_DEVICE (pointer is HBM on the context's device, e.g. torch
+ * tensor.data_ptr(); no copy, the call is asynchronous on the context's stream).
+ *
+ * Threading: one HIP stream per context; calls on one context must be serialised
+ * by the caller; distinct contexts are independent.
+ */
+#ifndef CHOMP_MI355X_H
+#define CHOMP_MI355X_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CHOMP_OK 0
+#define CHOMP_ERR_ARG (-1)      /* bad argument (KeyError/ValueError analogue)   */
+#define CHOMP_ERR_HIP (-2)      /* HIP runtime failure                            */
+#define CHOMP_ERR_STATE (-3)    /* stage called before its prerequisite           */
+#define CHOMP_ERR_SCOPE (-4)    /* feature outside the hot-path scope (w != -1)   */
+
+#define CHOMP_HOST 0
+#define CHOMP_DEVICE 1
+
+typedef struct chomp_ctx chomp_ctx;
+
+/* defaults.default_cosmo_dict (defaults.py:6-18); w0/wa must be -1/0. */
+typedef struct chomp_cosmo {
+  double omega_m0, omega_b0, omega_l0, omega_r0, cmb_temp, h, sigma_8, n_scalar,
+      w0, wa;
+} chomp_cosmo;
+
+/* defaults.default_halo_dict (defaults.py:21-29). */
+typedef struct chomp_halo_par {
+  double stq, st_little_a, c0, beta, alpha, delta_v;
+} chomp_halo_par;
+
+/* hod.HODZheng parameters (hod.py:156-186, defaults.py:33-39). */
+typedef struct chomp_hod_par {
+  double log_M_min, sigma, log_M_0, log_M_1p, alpha;
+} chomp_hod_par;
+
+/* Snapshot of defaults.default_limits + defaults.default_precision
+ * (defaults.py:42-51, 62-92), taken when the context is created. */
+typedef struct chomp_config {
+  double k_min, k_max, mass_min, mass_max;
+  double corr_precision, cosmo_precision, dNdz_precision, halo_precision,
+      kernel_precision, mass_precision, window_precision, global_precision;
+  int corr_npoints, cosmo_npoints, halo_npoints, kernel_npoints,
+      kernel_bessel_limit, mass_npoints, window_npoints, divmax;
+} chomp_config;
+
+/* Mass functions: mass_function.MassFunction (Sheth-Tormen, mass_function.py:25)
+ * and mass_function.TinkerMassFunction (:436). */
+#define CHOMP_MF_ST 0
+#define CHOMP_MF_TINKER 1
+
+/* Knot tables built by chomp_halo_setup (bit mask): one bit per lazily
+ * initialised spline of the reference's Halo (halo.py:96-101), so a caller can
+ * mirror which of them a setter invalidates (halo.py:165-170, 186-189). */
+#define CHOMP_T_H_M 1u    /* Halo._initialize_h_m    halo.py:904-927   */
+#define CHOMP_T_PP_MM 2u  /* Halo._initialize_pp_mm  halo.py:971-994   */
+#define CHOMP_T_H_G 4u    /* Halo._initialize_h_g    halo.py:929-969   */
+#define CHOMP_T_PP_GM 8u  /* Halo._initialize_pp_gm  halo.py:1043-1086 */
+#define CHOMP_T_PP_GG 16u /* Halo._initialize_pp_gg  halo.py:996-1041  */
+#define CHOMP_FAM_MM (CHOMP_T_H_M | CHOMP_T_PP_MM)               /* power_mm */
+#define CHOMP_FAM_GM (CHOMP_T_H_M | CHOMP_T_H_G | CHOMP_T_PP_GM) /* power_gm */
+#define CHOMP_FAM_GG (CHOMP_T_H_G | CHOMP_T_PP_GG)               /* power_gg */
+
+/* Power spectra served by chomp_power. */
+#define CHOMP_P_LIN 0 /* Halo.linear_power  halo.py:266-275 */
+#define CHOMP_P_MM 1  /* Halo.power_mm      halo.py:277-320 */
+#define CHOMP_P_GM 2  /* Halo.power_gm/mg   halo.py:322-389 */
+#define CHOMP_P_GG 3  /* Halo.power_gg      halo.py:391-439 */
+#define CHOMP_P_HALOFIT 16 /* OR-ed in: HaloFit.power_* halo.py:1325-1413 */
+
+void chomp_default_config(chomp_config* cfg);
+
+/* Create a context on `device` using HIP stream `hip_stream` (NULL -> a new
+ * stream owned by the context).  Replaces the import-time snapshot of
+ * defaults.py that every reference constructor reads. */
+int chomp_ctx_create(const chomp_config* cfg, int device, void* hip_stream,
+                     chomp_ctx** out);
+void chomp_ctx_destroy(chomp_ctx* ctx);
+const char* chomp_last_error(chomp_ctx* ctx);
+/* Block until everything queued on the context's stream has finished. */
+int chomp_sync(chomp_ctx* ctx);
+
+/* ---- Stage K: per-(cosmology, z) tables -------------------------------------
+ * An "epoch" is one (cosmology, redshift) pair = one cosmology.SingleEpoch
+ * (cosmology.py:39-119).  A batch of n epochs is set up together; this is the
+ * z-axis of the (k, z) grid and the design-point axis of SimulationDesign. */
+
+/* SingleEpoch.__init__/_initialize_defaults for every epoch (cosmology.py:39-119):
+ * flatness flags, delta_H, chi(z), growth, sigma_8 normalisation. */
+int chomp_epochs_set(chomp_ctx* ctx, size_t n_epoch, const chomp_cosmo* cosmo,
+                     const double* z);
+
+/* MassFunction.__init__ (mass_function.py:38-61; Tinker :448-492): mass-limit
+ * search (:160-203), nu table + splines (:205-223), normalisation (:225-241).
+ * `par[i]` are the halo_dict values the mass function sees for epoch i. */
+int chomp_mass_setup(chomp_ctx* ctx, const chomp_halo_par* par, int mf_kind);
+
+/* Halo.__init__ + lazy initialisers (halo.py:41-104, 674-707, 839-1086): n_bar,
+ * then the 50-knot tables selected by `tables` (CHOMP_T_* bits) and their
+ * splines; tables not selected keep their previous contents.
+ * `profile[i]` are the halo_dict values the profile (c0, beta, delta_v) sees;
+ * they differ from chomp_mass_setup's only after Halo.set_halo (halo.py:220-235,
+ * which does not rebuild the profile splines). */
+int chomp_halo_setup(chomp_ctx* ctx, const chomp_halo_par* profile,
+                     const chomp_hod_par* hod, unsigned tables);
+
+/* HaloFit._initialize_sigma_spline (halo.py:1268-1319) for epoch `src_epoch`,
+ * stored as the HaloFit coefficient set of epoch `dst_epoch`; f_1..f_3, omega_l
+ * and w are passed explicitly because the reference fixes them at construction
+ * (halo.py:1261-1266) and never refreshes them on set_redshift. */
+int chomp_halofit_setup(chomp_ctx* ctx, size_t dst_epoch, size_t src_epoch,
+                        double f_1, double f_2, double f_3, double omega_l,
+                        double w);
+
+/* ---- Stage E: grid evaluation ------------------------------------------------
+ * Halo.linear_power / power_mm / power_gm / power_gg (halo.py:266-439) for every
+ * epoch of the batch: out[i*nk + j] = P_which(k[j]; epoch i), row-major (z-major).
+ * k in h/Mpc, P in (Mpc/h)^3.  extrapolate=False semantics: k < k_min -> scaled
+ * linear spectrum, k > k_max -> 0. */
+int chomp_power(chomp_ctx* ctx, int which, const double* k, size_t nk,
+                double* out, int mem);
+/* Same for the epoch range [epoch0, epoch0 + n). */
+int chomp_power_range(chomp_ctx* ctx, int which, size_t epoch0, size_t n,
+                      const double* k, size_t nk, double* out, int mem);
+
+/* SingleEpoch.sigma_r (cosmology.py:602-642) at n scales for one epoch (host). */
+int chomp_sigma_r(chomp_ctx* ctx, size_t epoch, const double* scale, size_t n,
+                  double* out);
+/* Halo.y (NFW, halo.py:561-585) at (ln_k[i], mass[i]) pairs for one epoch (host). */
+int chomp_y_nfw(chomp_ctx* ctx, size_t epoch, const double* ln_k,
+                const double* mass, size_t n, double* out);
+
+/* Element-wise lookups of one epoch (host or device buffers):
+ * MassFunction.nu / ln_mass / f_nu / bias_nu (mass_function.py:243-346),
+ * HODZheng moments (hod.py:189-230), Halo.virial_radius / concentration
+ * (halo.py:441-463), SingleEpoch.delta_k (cosmology.py:574-587). */
+#define CHOMP_EV_NU_OF_MASS 0
+#define CHOMP_EV_LN_MASS_OF_NU 1
+#define CHOMP_EV_F_NU 2
+#define CHOMP_EV_BIAS_NU 3
+#define CHOMP_EV_HOD_FIRST 4
+#define CHOMP_EV_HOD_SECOND 5
+#define CHOMP_EV_HOD_CENTRAL 6
+#define CHOMP_EV_HOD_SATELLITE 7
+#define CHOMP_EV_VIRIAL_RADIUS 8
+#define CHOMP_EV_CONCENTRATION 9
+#define CHOMP_EV_DELTA_K 10
+int chomp_eval(chomp_ctx* ctx, size_t epoch, int what, const double* x, size_t n,
+               double* out, int mem);
+
+/* HaloFit coefficient block of one epoch (f_1, f_2, f_3, k_s, n_eff, C, a_n, b_n,
+ * c_n, gamma_n, alpha_n, beta_n, mu_n, nu_n): read it back / write it.  The
+ * reference keeps these across set_redshift (halo.py:1254-1259 never resets
+ * _initialized_sigma_spline), so a caller mirroring that re-installs them after
+ * chomp_epochs_set. */
+#define CHOMP_HF_COUNT 14
+int chomp_halofit_get(chomp_ctx* ctx, size_t epoch, double* out);
+int chomp_halofit_put(chomp_ctx* ctx, size_t epoch, const double* in);
+
+/* ---- Introspection (per-stage parity tests, write() mirrors) ---------------- */
+#define CHOMP_SC_Z 0
+#define CHOMP_SC_CHI 1
+#define CHOMP_SC_GROWTH 2
+#define CHOMP_SC_OMEGA_M 3
+#define CHOMP_SC_OMEGA_L 4
+#define CHOMP_SC_DELTA_C 5
+#define CHOMP_SC_DELTA_V 6
+#define CHOMP_SC_RHO_BAR 7
+#define CHOMP_SC_SIGMA_NORM 8
+#define CHOMP_SC_LN_MASS_MIN 9
+#define CHOMP_SC_LN_MASS_MAX 10
+#define CHOMP_SC_NU_MIN 11
+#define CHOMP_SC_NU_MAX 12
+#define CHOMP_SC_M_STAR 13
+#define CHOMP_SC_F_NORM 14
+#define CHOMP_SC_BIAS_NORM 15
+#define CHOMP_SC_N_BAR 16
+#define CHOMP_SC_N_BAR_OVER_RHO_BAR 17
+#define CHOMP_SC_N_SEARCH 18
+#define CHOMP_SC_MF_DELTA_V 19
+#define CHOMP_SC_T_ALPHA 20
+#define CHOMP_SC_T_BETA 21
+#define CHOMP_SC_T_GAMMA 22
+#define CHOMP_SC_T_PHI 23
+#define CHOMP_SC_T_ETA 24
+#define CHOMP_SC_GROWTH_NORM 25
+#define CHOMP_SC_DELTA_H 26
+#define CHOMP_SC_HF_K_S 27
+#define CHOMP_SC_HF_N_EFF 28
+#define CHOMP_SC_HF_C 29
+#define CHOMP_SC_COUNT 30
+/* out[CHOMP_SC_COUNT] <- scalars of one epoch (SingleEpoch / MassFunction / Halo
+ * attributes: _chi, _growth, omega_m(), delta_c(), ..., f_norm, n_bar). */
+int chomp_get_scalars(chomp_ctx* ctx, size_t epoch, double* out);
+
+#define CHOMP_TAB_LN_MASS 0 /* MassFunction._ln_mass_array  [mass_npoints] */
+#define CHOMP_TAB_NU 1      /* MassFunction._nu_array       [mass_npoints] */
+#define CHOMP_TAB_H_M 2     /* knots of Halo._h_m_spline    [halo_npoints] */
+#define CHOMP_TAB_PP_MM 3
+#define CHOMP_TAB_H_G 4
+#define CHOMP_TAB_PP_GM 5
+#define CHOMP_TAB_PP_GG 6
+#define CHOMP_TAB_LEVELS 7  /* Romberg levels reached, 5 x halo_npoints, as doubles */
+#define CHOMP_TAB_HF_LN_SIGMA2 8 /* HaloFit._ln_sigma2_array [halo_npoints] */
+int chomp_get_table(chomp_ctx* ctx, size_t epoch, int table, double* out,
+                    size_t n);
+
+/* ---- Projection: MultiEpoch, windows, kernel, correlation --------------------
+ * One projection set-up per context. */
+
+/* kernel.dNdz family (kernel.py:26-179). kind: CHOMP_DNDZ_*; p[] per kind:
+ * MAGLIM {a, z0, b}; GAUSSIAN {z0, sigma_z}.  z_min/z_max are the values AFTER
+ * the constructor's clipping (kernel.py:101-104, 164-173), done by the caller. */
+#define CHOMP_DNDZ_MAGLIM 0
+#define CHOMP_DNDZ_GAUSSIAN 1
+typedef struct chomp_dndz {
+  int kind;
+  int pad_;
+  double z_min, z_max;
+  double p[4];
+} chomp_dndz;
+
+/* kernel.WindowFunctionGalaxy (kernel.py:358-387) / WindowFunctionConvergence
+ * (:410-484). */
+#define CHOMP_WINDOW_GALAXY 0
+#define CHOMP_WINDOW_CONVERGENCE 1
+typedef struct chomp_window {
+  int kind;
+  int pad_;
+  chomp_dndz dist;
+} chomp_window;
+
+/* cosmology.MultiEpoch(z_min, z_max, cosmo) (cosmology.py:747-817) +
+ * kernel.Kernel / GalaxyGalaxyLensingKernel.__init__ and _initialize_spline
+ * (kernel.py:584-649, 803-839): window tables, z_bar, 50 kernel knots.
+ * bessel_order 0 (J0) or 2 (J2). */
+int chomp_kernel_setup(chomp_ctx* ctx, const chomp_cosmo* cosmo, double me_z_min,
+                       double me_z_max, double ktheta_min, double ktheta_max,
+                       const chomp_window* a, const chomp_window* b,
+                       int bessel_order);
+
+#define CHOMP_KI_Z_BAR 0
+#define CHOMP_KI_CHI_MIN 1
+#define CHOMP_KI_CHI_MAX 2
+#define CHOMP_KI_Z_MIN 3
+#define CHOMP_KI_Z_MAX 4
+#define CHOMP_KI_D_ZBAR 5 /* MultiEpoch.growth_factor(z_bar), correlation.py:94 */
+#define CHOMP_KI_NORM_A 6 /* dNdz.norm of window a's distribution */
+#define CHOMP_KI_NORM_B 7
+#define CHOMP_KI_COUNT 8
+int chomp_kernel_info(chomp_ctx* ctx, double* out);
+
+#define CHOMP_KTAB_LN_KTHETA 0 /* Kernel._ln_ktheta_array [kernel_npoints]   */
+#define CHOMP_KTAB_KERNEL 1    /* Kernel._kernel_array    [kernel_npoints]   */
+#define CHOMP_KTAB_WA_CHI 2    /* window a _chi_array     [window_npoints]   */
+#define CHOMP_KTAB_WA 3        /* window a _wf_array                          */
+#define CHOMP_KTAB_WB_CHI 4
+#define CHOMP_KTAB_WB 5
+#define CHOMP_KTAB_ME_Z 6      /* MultiEpoch._z_array     [cosmo_npoints]    */
+#define CHOMP_KTAB_ME_CHI 7
+#define CHOMP_KTAB_ME_GROWTH 8
+#define CHOMP_KTAB_LEVELS 9
+int chomp_kernel_table(chomp_ctx* ctx, int table, double* out, size_t n);
+
+/* Kernel.kernel(ln_ktheta) (kernel.py:714-729); argument is ln(k*theta). */
+int chomp_kernel_eval(chomp_ctx* ctx, const double* ln_ktheta, size_t n,
+                      double* out, int mem);
+/* WindowFunction.window_function(chi) (kernel.py:326-340) of window 0 (a) / 1 (b). */
+int chomp_window_eval(chomp_ctx* ctx, int which_window, const double* chi,
+                      size_t n, double* out, int mem);
+
+/* Correlation.correlation(theta_rad) (correlation.py:242-275):
+ * w(theta) = int dlnk k^2/(2 pi) P(k)/D_z^2 K(ln k theta), one wavefront-group per
+ * theta.  P is `which` of halo epoch `epoch` (the caller has moved the halo to
+ * z_bar as Correlation.__init__ does, correlation.py:102-103). */
+int chomp_wtheta(chomp_ctx* ctx, int which, size_t epoch, double k_min,
+                 double k_max, double D_z, const double* theta, size_t n,
+                 double* out, int mem);
+/* CorrelationFourier.correlation(l) (correlation.py:360-392): Limber C_l. */
+int chomp_cell(chomp_ctx* ctx, int which, size_t epoch, double D_z,
+               const double* ell, size_t n, double* out, int mem);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHOMP_MI355X_H */

@@ -1,0 +1,205 @@
+"""GPU parity tests (pytest -m gpu): the HIP path, called through the C ABI
+(ctypes) and through the reference-shaped Python classes, against the oracle, the
+committed golden vectors of the reference and the reference's own pins.
+
+Tolerance: BASELINE.json north_star states 1e-4 relative for P(k); intermediate
+tables are held tighter so a failure localises to a stage."""
+import json
+import os
+
+import numpy
+import pytest
+
+from conftest import GOLDEN, load_golden, rel_err
+from params import c_dict, c_dict_2, h_dict_2, hod_dict, hod_dict_2
+
+pytestmark = pytest.mark.gpu
+
+RTOL_P = 1e-4          # north_star tolerance on P(k)
+K4 = numpy.logspace(-3, 2, 4)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from chomp_amd import _lib
+    _lib.lib()
+    return _lib
+
+
+@pytest.fixture(scope="module")
+def pins():
+    with open(os.path.join(GOLDEN, "reference_pins.json")) as f:
+        return json.load(f)
+
+
+def test_sigma_r_primitive(lib):
+    from chomp_amd import cosmology
+    g = load_golden("g3_stages")
+    for z in (0.0, 0.5, 1.0, 1.5):
+        c = cosmology.SingleEpoch(z)
+        got = c.sigma_r(g["R"])
+        assert rel_err(got, g["z%03d_sigma_R" % round(z * 100)]) < 5e-8
+        assert abs(c._sigma_norm / float(g["z%03d_sigma_norm" % round(z * 100)]) - 1) < 5e-8
+        assert abs(c._growth / float(g["z%03d_growth" % round(z * 100)]) - 1) < 1e-13
+        if z > 0:
+            assert abs(c._chi / float(g["z%03d_chi" % round(z * 100)]) - 1) < 5e-8
+
+
+@pytest.mark.parametrize("z", [0.0, 0.5, 1.0, 1.5])
+def test_stage_tables_vs_reference(lib, z):
+    """G3: every intermediate table of the P_mm path."""
+    from chomp_amd import halo
+    g = load_golden("g3_stages")
+    tag = "z%03d_" % round(z * 100)
+    h = halo.Halo(z)
+    ctx = h._sync(lib.FAM_MM)
+    sc = ctx.scalars(0)
+    # the mass-limit search must stop on exactly the reference's step
+    assert sc["ln_mass_min"] == g[tag + "ln_mass"][0]
+    assert sc["ln_mass_max"] == g[tag + "ln_mass"][-1]
+    assert numpy.array_equal(ctx.table("ln_mass"), g[tag + "ln_mass"])
+    assert rel_err(ctx.table("nu"), g[tag + "nu"]) < 1e-7
+    for name, key in (("delta_c", "delta_c"), ("delta_v", "delta_v"),
+                      ("rho_bar", "rho_bar"), ("f_norm", "f_norm"),
+                      ("bias_norm", "bias_norm"), ("m_star", "m_star"),
+                      ("nu_min", "nu_min"), ("nu_max", "nu_max"),
+                      ("n_bar", "n_bar")):
+        tol = 2e-5 if name == "n_bar" else 2e-7
+        assert abs(sc[name] / float(g[tag + key]) - 1) < tol, name
+    assert rel_err(ctx.table("h_m"), g[tag + "h_m"]) < 2e-5
+    assert rel_err(ctx.table("pp_mm"), g[tag + "pp_mm"]) < 2e-5
+
+
+def test_c1_wmap7_z0_full_surface(lib):
+    """G2 / config 1: 256 k at z=0 for all four spectra + the range branches."""
+    from chomp_amd import halo
+    g = load_golden("g2_wmap7_z0")
+    h = halo.Halo(0.0)
+    for name, key in (("linear_power", "lin"), ("power_mm", "mm"),
+                      ("power_gm", "gm"), ("power_gg", "gg")):
+        f = getattr(h, name)
+        assert rel_err(f(g["k"]), g[key]) < RTOL_P, name
+        got = f(g["k_probe"])
+        ref = g[key + "_probe"]
+        assert numpy.array_equal(got == 0.0, ref == 0.0), name   # k > k_max -> 0
+        assert numpy.allclose(got, ref, rtol=RTOL_P, atol=0), name
+    # scalar in -> 0-d array out, any shape in -> same shape out
+    assert numpy.shape(h.power_mm(0.1)) == ()
+    assert h.power_mm(g["k"].reshape(16, 16)).shape == (16, 16)
+    ctx = h._sync(0)
+    assert rel_err(ctx.table("h_g"), g["h_g"]) < 2e-5
+    assert rel_err(ctx.table("pp_gm"), g["pp_gm"]) < 5e-5
+    assert rel_err(ctx.table("pp_gg"), g["pp_gg"]) < 5e-5
+
+
+def _fresh():
+    from chomp_amd import cosmology, halo, hod
+    cosmo = cosmology.SingleEpoch(0.0, cosmo_dict=c_dict)
+    return halo.Halo(input_hod=hod.HODZheng(hod_dict), cosmo_single_epoch=cosmo)
+
+
+@pytest.mark.parametrize("tag,test", [
+    ("base", "HaloTest.test_halo"), ("cosmo2", "HaloTest.test_set_cosmology"),
+    ("halo2", "HaloTest.test_set_halo"), ("hod2", "HaloTest.test_set_hod"),
+    ("z1", None)])
+def test_reference_unit_tests(lib, pins, tag, test):
+    """The reference's HaloTest cases (unit_test.py:338-427) run against the mirror
+    classes: same calls, same 4-decimal assertions, plus G1 to 1e-4."""
+    h = _fresh()
+    if tag == "cosmo2":
+        h.set_cosmology(c_dict_2)
+    elif tag == "halo2":
+        h.set_halo(h_dict_2)
+    elif tag == "hod2":
+        h.set_hod(hod_dict_2)
+    elif tag == "z1":
+        h.set_redshift(1.0)
+    g1 = load_golden("g1_unit_points")
+    for which in ("mm", "gm", "gg"):
+        got = getattr(h, "power_" + which)(K4)
+        assert rel_err(got, g1["%s_%s" % (tag, which)]) < RTOL_P, which
+        key = "ln_power_" + which
+        if test and key in pins[test]:
+            for idx, k in enumerate(K4):        # scalar calls, as the reference does
+                v = numpy.log(getattr(h, "power_" + which)(k))
+                assert round(abs(v - pins[test][key][idx]), pins["places_halo"]) == 0
+    if tag in ("base", "cosmo2", "z1"):
+        assert rel_err(h.linear_power(K4), g1[tag + "_lin"]) < 1e-7
+
+
+def test_set_halo_keeps_stale_h_m(lib):
+    """halo.py:220-235 does not reset _initialized_h_m/_pp_mm: power_mm computed
+    BEFORE set_halo stays as it was."""
+    h = _fresh()
+    before = h.power_mm(K4)
+    h.set_halo(h_dict_2)
+    assert numpy.array_equal(h.power_mm(K4), before)
+
+
+def test_c2_grid_rows(lib):
+    """G4 / config 2: 64 z x (257-point subsample of the 4096 k) through HaloGrid,
+    plus the full 4096 x 64 grid for shape and finiteness."""
+    import torch
+    from chomp_amd import grid
+    g = load_golden("g4_pmm_grid")
+    hg = grid.HaloGrid(g["z"])
+    got = hg.power("power_mm", g["k"])
+    assert got.shape == g["mm"].shape
+    err = numpy.abs(got / g["mm"] - 1)
+    assert err.max() < RTOL_P, (err.max(), numpy.unravel_index(err.argmax(), err.shape))
+    k_full = torch.logspace(-3, 2, 4096, dtype=torch.float64, device="cuda")
+    out = hg.power("power_mm", k_full)
+    torch.cuda.synchronize()
+    assert out.shape == (64, 4096) and bool(torch.isfinite(out).all())
+    sub = out[:, torch.as_tensor(g["k_idx"], device="cuda")].cpu().numpy()
+    assert numpy.abs(sub / g["mm"] - 1).max() < RTOL_P
+
+
+@pytest.mark.parametrize("z", [0.0, 0.5, 1.0])
+def test_c3_tinker_zheng(lib, z):
+    """G5 / config 3: Tinker10 + Zheng HOD P_gm (and gg, mm)."""
+    from chomp_amd import cosmology, halo, hod, mass_function, defaults
+    g = load_golden("g5_tinker_zheng")
+    tag = "z%03d_" % round(z * 100)
+    cosmo = cosmology.SingleEpoch(z)
+    mass = mass_function.TinkerMassFunction(z, cosmo)
+    h = halo.Halo(z, hod.HODZheng(defaults.default_hod_dict), cosmo, mass)
+    assert rel_err(h.power_gm(g["k"]), g[tag + "gm"]) < RTOL_P
+    assert rel_err(h.power_gg(g["k"]), g[tag + "gg"]) < RTOL_P
+    assert rel_err(h.power_mm(g["k"]), g[tag + "mm"]) < RTOL_P
+    sc = h._sync(0).scalars(0)
+    mine = [sc["mf_delta_v"], sc["t_alpha"], sc["t_beta"], sc["t_gamma"],
+            sc["t_phi"], sc["t_eta"], sc["bias_norm"]]
+    assert numpy.allclose(mine, g[tag + "tinker"], rtol=1e-7)
+    assert abs(sc["n_bar"] / float(g[tag + "n_bar"]) - 1) < 2e-5
+    ctx = h._sync(0)
+    for name in ("h_m", "h_g", "pp_gm", "pp_gg", "pp_mm"):
+        assert rel_err(ctx.table(name), g[tag + name]) < 5e-5, name
+
+
+def test_romberg_levels_match_reference(lib):
+    """The device Romberg reproduces the reference's stopping levels (including the
+    'early' stops on the discontinuous HOD integrands)."""
+    from chomp_amd import halo
+    from oracle import chomp_oracle as o
+    h = halo.Halo(0.0)
+    h.power_gm(1.0), h.power_gg(1.0), h.power_mm(1.0)
+    lev = h._sync(0).table("levels").reshape(5, -1)
+    t = o.halo_table(families=("mm", "gm", "gg"))
+    names = ("_h_m_integrand", "_pp_mm_integrand", "_h_g_integrand",
+             "_pp_gm_integrand", "_pp_gg_integrand")
+    for i, n in enumerate(names):
+        same = numpy.mean(lev[i] == numpy.array(t.levels[n]))
+        assert same >= 0.9, (n, lev[i], t.levels[n])
+
+
+def test_mass_function_and_hod_lookups(lib):
+    from chomp_amd import mass_function, cosmology
+    g1 = load_golden("g1_unit_points")
+    cosmo = cosmology.SingleEpoch(0.0, cosmo_dict=c_dict)
+    mass = mass_function.MassFunction(cosmo_single_epoch=cosmo)
+    assert rel_err(mass.nu(g1["mass_arr"]), g1["mf_nu"]) < 1e-6
+    assert rel_err(mass.f_m(g1["mass_arr"]), g1["mf_f_m"]) < 1e-5
+    assert rel_err(mass.bias_m(g1["mass_arr"]), g1["mf_bias_m"]) < 1e-6
