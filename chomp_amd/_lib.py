@@ -120,6 +120,29 @@ _lib = None
 _lock = threading.Lock()
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process: PyTorch-ROCm wheels bundle their own
+    libamdhip64.so (same SONAME as /opt/rocm's).  If our library were loaded first it
+    would bind the system runtime and a later `import torch` would bring in a second
+    one, which then fails to open the GPU.  Loading torch's copy first (without
+    importing torch) makes both resolve to the same runtime, in either import order."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        cand = os.path.join(libdir, name)
+        if os.path.exists(cand):
+            try:
+                ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
 def lib():
     """Load (building if necessary) the HIP library.  Raises if impossible."""
     global _lib
@@ -134,6 +157,7 @@ def lib():
                     "chomp_amd: libchomp_mi355x.so is missing and could not be "
                     "built with hipcc (%s). This package has no CPU fallback."
                     % exc) from exc
+        _preload_hip_runtime()
         L = ctypes.CDLL(LIB_PATH)
         for name in EXPORTS:
             if not hasattr(L, name):

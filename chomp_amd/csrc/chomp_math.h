@@ -217,9 +217,20 @@ CHOMP_HD double spline_eval_uniform(double x0, double dx, const double* c, int n
 }
 
 // numpy.linspace(a, b, n)[i]
+// (numpy forms arange(n)*step + start with two roundings: no FMA contraction here,
+// so the knot grids are bit-identical to the reference's.)
 CHOMP_HD double linspace_at(double a, double b, int n, int i) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
   if (i == n - 1) return b;
-  return a + (double)i * ((b - a) / (double)(n - 1));
+  const double step = (b - a) / (double)(n - 1);
+#if defined(__clang__)
+  const double prod = (double)i * step;
+#else
+  volatile double prod = (double)i * step;
+#endif
+  return prod + a;
 }
 
 // ---------------------------------------------------------------------------
