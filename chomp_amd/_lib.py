@@ -38,8 +38,10 @@ EV = {"nu_of_mass": 0, "ln_mass_of_nu": 1, "f_nu": 2, "bias_nu": 3,
       "virial_radius": 8, "concentration": 9, "delta_k": 10}
 HF_COUNT = 14
 KI = {name: i for i, name in enumerate([
-    "z_bar", "chi_min", "chi_max", "z_min", "z_max", "D_zbar", "norm_a", "norm_b"])}
-KI_COUNT = 8
+    "z_bar", "chi_min", "chi_max", "z_min", "z_max", "D_zbar", "norm_a", "norm_b",
+    "wa_chi_min", "wa_chi_max", "wb_chi_min", "wb_chi_max", "j_limit"])}
+KI_COUNT = 13
+ME = {"chi_of_z": 0, "z_of_chi": 1, "growth_of_z": 2}
 KTAB = {"ln_ktheta": 0, "kernel": 1, "wa_chi": 2, "wa": 3, "wb_chi": 4, "wb": 5,
         "me_z": 6, "me_chi": 7, "me_growth": 8, "levels": 9}
 
@@ -89,6 +91,7 @@ EXPORTS = [
     "chomp_halo_setup", "chomp_halofit_setup", "chomp_power", "chomp_power_range",
     "chomp_sigma_r", "chomp_y_nfw", "chomp_get_scalars", "chomp_get_table",
     "chomp_eval", "chomp_halofit_get", "chomp_halofit_put",
+    "chomp_multi_epoch_setup", "chomp_me_eval",
     "chomp_kernel_setup", "chomp_kernel_info", "chomp_kernel_table",
     "chomp_kernel_eval", "chomp_window_eval", "chomp_wtheta", "chomp_cell",
 ]
@@ -189,6 +192,8 @@ def lib():
         L.chomp_kernel_setup.argtypes = [vp, ctypes.POINTER(Cosmo), d, d, d, d,
                                          ctypes.POINTER(Window),
                                          ctypes.POINTER(Window), i]
+        L.chomp_multi_epoch_setup.argtypes = [vp, ctypes.POINTER(Cosmo), d, d]
+        L.chomp_me_eval.argtypes = [vp, i, vp, sz, vp, i]
         L.chomp_kernel_info.argtypes = [vp, c_double_p]
         L.chomp_kernel_table.argtypes = [vp, i, c_double_p, sz]
         L.chomp_kernel_eval.argtypes = [vp, vp, sz, vp, i]
@@ -412,6 +417,19 @@ class Context(object):
         self._check(self._L.chomp_kernel_setup(
             self._h, ctypes.byref(c), me_z_min, me_z_max, ktheta_min, ktheta_max,
             ctypes.byref(wa), ctypes.byref(wb), int(bessel_order)))
+
+    def multi_epoch_setup(self, cosmo_dict, z_min, z_max):
+        c = cosmo_struct(cosmo_dict)
+        self._check(self._L.chomp_multi_epoch_setup(self._h, ctypes.byref(c),
+                                                    float(z_min), float(z_max)))
+
+    def me_eval(self, what, x):
+        if _is_torch(x):
+            return self._map1(self._L.chomp_me_eval, x, ME[what])
+        xa = numpy.asarray(x, dtype=numpy.float64)
+        out = self._map1(self._L.chomp_me_eval, numpy.ascontiguousarray(xa).ravel(),
+                         ME[what])
+        return out.reshape(xa.shape)
 
     def kernel_info(self):
         out = numpy.empty(KI_COUNT)

@@ -151,3 +151,97 @@ class SingleEpoch(object):
     def nu_m(self, mass):
         sqrt_nu = self.delta_c() / self.sigma_m(mass)
         return sqrt_nu * sqrt_nu
+
+
+class MultiEpoch(object):
+    """cosmology.MultiEpoch (cosmology.py:731-1164): chi(z), z(chi), D(z) on a
+    50-point grid over [z_min, z_max], tabulated and splined on the device."""
+
+    def __init__(self, z_min, z_max, cosmo_dict=None, with_bao=False, **kws):
+        self.z_min = z_min
+        self.z_max = z_max
+        if self.z_min < 0.0:
+            self.z_min = 0.0
+        if cosmo_dict is None:
+            cosmo_dict = defaults.default_cosmo_dict
+        self.epoch0 = SingleEpoch(0.0, cosmo_dict, with_bao, **kws)
+        self.cosmo_dict = cosmo_dict
+        e0 = self.epoch0
+        self._omega_m0, self._omega_b0, self._omega_l0 = e0._omega_m0, e0._omega_b0, e0._omega_l0
+        self._h, self.H0, self._omega_r0 = e0._h, e0.H0, e0._omega_r0
+        self._sigma_8, self._w0, self._wa, self._n = e0._sigma_8, e0._w0, e0._wa, e0._n
+        self._k_min, self._k_max = e0._k_min, e0._k_max
+        self._ctx = None
+        self._sig = None
+
+    def _dev(self):
+        if self._ctx is None:
+            self._ctx = _context()
+        sig = (tuple(sorted(self.cosmo_dict.items())), self.z_min, self.z_max)
+        if sig != self._sig:
+            self._ctx.multi_epoch_setup(self.cosmo_dict, self.z_min, self.z_max)
+            self._sig = sig
+        return self._ctx
+
+    _z_array = property(lambda self: self._dev().kernel_table("me_z"))
+    _chi_array = property(lambda self: self._dev().kernel_table("me_chi"))
+    _growth_array = property(lambda self: self._dev().kernel_table("me_growth"))
+    growth_norm = property(lambda self: self.epoch0.growth_norm)
+
+    def set_redshift(self, z_min, z_max):
+        self.z_max = z_max
+        self.z_min = z_min
+        if self.z_min < 0.0:
+            self.z_min = 0.0
+
+    def get_cosmology(self):
+        return self.epoch0.get_cosmology()
+
+    def set_cosmology(self, cosmo_dict, z_min=None, z_max=None):
+        if z_min is None:
+            z_min = self.z_min
+        if z_max is None:
+            z_max = self.z_max
+        ctx = self._ctx
+        self.__init__(z_min, z_max, cosmo_dict)
+        self._ctx = ctx
+
+    def E(self, redshift):
+        return self.epoch0.E(redshift)
+
+    def comoving_distance(self, redshift):
+        return self._dev().me_eval("chi_of_z", redshift)
+
+    def luminosity_distance(self, redshift):
+        return (1.0 + redshift) * self.comoving_distance(redshift)
+
+    def angular_diameter_distance(self, redshift):
+        return self.comoving_distance(redshift) / (1.0 + redshift)
+
+    def redshift(self, comoving_distance):
+        return self._dev().me_eval("z_of_chi", comoving_distance)
+
+    def growth_factor(self, redshift):
+        return self._dev().me_eval("growth_of_z", redshift)
+
+    def omega_m(self, redshift=None):
+        if redshift is None:
+            redshift = 0.0
+        return self._omega_m0 * (1.0 + redshift) ** 3 / self.epoch0.E0(redshift)
+
+    def omega_l(self, redshift=None):
+        if redshift is None:
+            redshift = 0.0
+        return self._omega_l0 / self.epoch0.E0(redshift)
+
+    def linear_power(self, k, redshift=None):
+        p = self.epoch0.linear_power(k)
+        if redshift is not None:
+            p = p * self.growth_factor(redshift) ** 2
+        return p
+
+    def sigma_r(self, scale, redshift=None):
+        sigma = self.epoch0.sigma_r(scale)
+        if redshift is not None:
+            sigma = sigma * self.growth_factor(redshift)
+        return sigma

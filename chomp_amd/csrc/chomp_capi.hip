@@ -53,7 +53,8 @@ struct chomp_ctx {
   double* d_stage_in = nullptr;
   double* d_stage_in2 = nullptr;
   double* d_stage_out = nullptr;
-  size_t cap_in = 0, cap_in2 = 0, cap_out = 0;
+  double* d_work = nullptr;
+  size_t cap_in = 0, cap_in2 = 0, cap_out = 0, cap_work = 0;
 
   // projection
   ProjState proj;
@@ -239,7 +240,7 @@ void chomp_ctx_destroy(chomp_ctx* ctx) {
   void* ptrs[] = {ctx->d_sici, ctx->d_j0, ctx->d_j2, ctx->d_tinker, ctx->d_gl16,
                   ctx->d_cand, ctx->d_cosmo, ctx->d_z, ctx->d_epochs, ctx->d_search,
                   ctx->d_tab, ctx->d_mass_par, ctx->d_profile, ctx->d_hod,
-                  ctx->d_stage_in, ctx->d_stage_in2, ctx->d_stage_out};
+                  ctx->d_stage_in, ctx->d_stage_in2, ctx->d_stage_out, ctx->d_work};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   proj_free(ctx->proj);

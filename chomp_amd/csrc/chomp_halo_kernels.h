@@ -574,6 +574,80 @@ __device__ __forceinline__ double halofit_mm(const Epoch& E, double k) {
   return 2.0 * kPi * kPi / (k * k * k) * (d2q + d2h);
 }
 
+// P(k) of one epoch from tables staged in LDS: shared by k_power and by the
+// projection integrands (correlation.py:270-275, 387-392 call halo.power_*).
+struct PowerEval {
+  const Epoch* E;
+  const double *ca, *cb, *cp;     // pp coefficients: h_a, h_b, 1-halo term
+  int NK, w;
+  bool halofit;
+  double x0, dx, k_min, k_max, c_lo;
+
+  // Stage the coefficient sets of spectrum `which` of epoch table `t` into `sm`
+  // (needs 12 (NK-1) doubles) and set the evaluator up.  All threads call it;
+  // __syncthreads() must follow before use.
+  __device__ __forceinline__ void stage(const chomp_config& cfg, const TabLayout& L,
+                                        const Epoch* Els, const double* t, int which,
+                                        double* sm) {
+    E = Els;
+    NK = L.NK;
+    halofit = (which & CHOMP_P_HALOFIT) != 0;
+    w = which & 15;
+    int fa = F_HM, fb = F_HM, fp = F_PPMM;
+    if (w == CHOMP_P_GM) { fa = F_HG; fb = F_HM; fp = F_PPGM; }
+    else if (w == CHOMP_P_GG) { fa = F_HG; fb = F_HG; fp = F_PPGG; }
+    double* a = sm;
+    double* b = a + 4 * (NK - 1);
+    double* p = b + 4 * (NK - 1);
+    if (needs_tables()) {
+      copy_doubles(a, t + L.off_kpp[fa], 4 * (NK - 1));
+      copy_doubles(b, t + L.off_kpp[fb], 4 * (NK - 1));
+      copy_doubles(p, t + L.off_kpp[fp], 4 * (NK - 1));
+    }
+    ca = a; cb = b; cp = p;
+    k_min = cfg.k_min;
+    k_max = cfg.k_max;
+    x0 = log(cfg.k_min);
+    dx = (log(cfg.k_max) - x0) / (double)(NK - 1);
+    c_lo = 0.0;
+  }
+  __device__ __forceinline__ bool needs_tables() const {
+    return w != CHOMP_P_LIN && !(halofit && w == CHOMP_P_MM);
+  }
+  // after the barrier: k < k_min constant (halo.py:314-317)
+  __device__ __forceinline__ void finish() {
+    if (w != CHOMP_P_LIN && !halofit) {
+      const double ha = pp_poly(ca, 0, 0.0), hb = pp_poly(cb, 0, 0.0), p0 = pp_poly(cp, 0, 0.0);
+      c_lo = ha * hb + p0 / linear_power(*E, k_min);
+    }
+  }
+  __device__ __forceinline__ double operator()(double kv) const {
+    if (w == CHOMP_P_LIN) return linear_power(*E, kv);
+    if (halofit) {
+      const double pmm = halofit_mm(*E, kv);
+      if (w == CHOMP_P_MM) return pmm;
+      double ha = 0.0, hb = 0.0, pp = 0.0;               // halo.py:649-672 range rule
+      if (kv >= k_min && kv <= k_max) {
+        const double lk = log(kv);
+        ha = spline_eval_uniform(x0, dx, ca, NK, lk);
+        hb = spline_eval_uniform(x0, dx, cb, NK, lk);
+        pp = spline_eval_uniform(x0, dx, cp, NK, lk);
+      }
+      return pmm * ha * hb + pp;
+    }
+    if (kv < k_min) return linear_power(*E, kv) * c_lo;
+    if (kv <= k_max) {
+      const double lk = log(kv);
+      const double ha = spline_eval_uniform(x0, dx, ca, NK, lk);
+      const double hb = spline_eval_uniform(x0, dx, cb, NK, lk);
+      const double pp = spline_eval_uniform(x0, dx, cp, NK, lk);
+      const double plin = 2.0 * kPi * kPi * delta_k_ln(*E, lk, kv) / (kv * kv * kv);
+      return plin * ha * hb + pp;
+    }
+    return 0.0;                                           // k > k_max (or NaN)
+  }
+};
+
 __global__ __launch_bounds__(256) void k_power(chomp_config cfg, TabLayout L,
                                                const Epoch* __restrict__ epochs,
                                                const double* __restrict__ tab, int which,
@@ -581,68 +655,17 @@ __global__ __launch_bounds__(256) void k_power(chomp_config cfg, TabLayout L,
                                                size_t nk, double* __restrict__ out) {
   extern __shared__ __align__(16) double sm[];
   __shared__ Epoch E;
-  const int NK = L.NK;
   const int e = epoch0 + blockIdx.y;
-  const bool halofit = (which & CHOMP_P_HALOFIT) != 0;
-  const int w = which & 15;
-  int fa = F_HM, fb = F_HM, fp = F_PPMM;
-  if (w == CHOMP_P_GM) { fa = F_HG; fb = F_HM; fp = F_PPGM; }
-  else if (w == CHOMP_P_GG) { fa = F_HG; fb = F_HG; fp = F_PPGG; }
-  double* ca = sm;
-  double* cb = ca + 4 * (NK - 1);
-  double* cp = cb + 4 * (NK - 1);
-  const double* t = tab + (size_t)e * L.stride;
   copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
                kEpochDoubles);
-  if (w != CHOMP_P_LIN && !(halofit && w == CHOMP_P_MM)) {
-    copy_doubles(ca, t + L.off_kpp[fa], 4 * (NK - 1));
-    copy_doubles(cb, t + L.off_kpp[fb], 4 * (NK - 1));
-    copy_doubles(cp, t + L.off_kpp[fp], 4 * (NK - 1));
-  }
+  PowerEval P;
+  P.stage(cfg, L, &E, tab + (size_t)e * L.stride, which, sm);
   __syncthreads();
-  const double x0 = log(cfg.k_min), x1 = log(cfg.k_max);
-  const double dx = (x1 - x0) / (double)(NK - 1);
-  double c_lo = 0.0;
-  if (w != CHOMP_P_LIN && !halofit) {
-    // k < k_min: P_lin(k) * (h_a h_b + pp / P_lin)|_{k_min}   (halo.py:314-317)
-    const double ha = pp_poly(ca, 0, 0.0), hb = pp_poly(cb, 0, 0.0), p0 = pp_poly(cp, 0, 0.0);
-    c_lo = ha * hb + p0 / linear_power(E, cfg.k_min);
-  }
+  P.finish();
   double* o = out + (size_t)blockIdx.y * nk;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nk;
-       i += (size_t)gridDim.x * blockDim.x) {
-    const double kv = k[i];
-    double r;
-    if (w == CHOMP_P_LIN) {
-      r = linear_power(E, kv);
-    } else if (halofit) {
-      const double pmm = halofit_mm(E, kv);
-      if (w == CHOMP_P_MM) {
-        r = pmm;
-      } else {
-        double ha = 0.0, hb = 0.0, pp = 0.0;            // halo.py:649-672 range rule
-        if (kv >= cfg.k_min && kv <= cfg.k_max) {
-          const double lk = log(kv);
-          ha = spline_eval_uniform(x0, dx, ca, NK, lk);
-          hb = spline_eval_uniform(x0, dx, cb, NK, lk);
-          pp = spline_eval_uniform(x0, dx, cp, NK, lk);
-        }
-        r = pmm * ha * hb + pp;
-      }
-    } else if (kv < cfg.k_min) {
-      r = linear_power(E, kv) * c_lo;
-    } else if (kv <= cfg.k_max) {
-      const double lk = log(kv);
-      const double ha = spline_eval_uniform(x0, dx, ca, NK, lk);
-      const double hb = spline_eval_uniform(x0, dx, cb, NK, lk);
-      const double pp = spline_eval_uniform(x0, dx, cp, NK, lk);
-      const double plin = 2.0 * kPi * kPi * delta_k_ln(E, lk, kv) / (kv * kv * kv);
-      r = plin * ha * hb + pp;
-    } else {
-      r = 0.0;
-    }
-    o[i] = r;
-  }
+       i += (size_t)gridDim.x * blockDim.x)
+    o[i] = P(k[i]);
 }
 
 // sigma_r at arbitrary scales (SingleEpoch.sigma_r): grid n, block 256.

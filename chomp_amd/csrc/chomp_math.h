@@ -216,6 +216,93 @@ CHOMP_HD double spline_eval_uniform(double x0, double dx, const double* c, int n
   return pp_poly(c, i, xv - (x0 + dx * (double)i));
 }
 
+// ---------------------------------------------------------------------------
+// Quintic interpolating spline (FITPACK InterpolatedUnivariateSpline(k=5)) and its
+// first two derivatives at one point: what HaloFit needs for n_eff and C
+// (halo.py:1289-1294).  Knots as FITPACK's fpcurf chooses them for s = 0, odd k:
+// 6-fold end knots and the data sites x[3] .. x[n-4] inside.
+// work: (n + 6) + 11 n + n doubles.  n >= 7.
+// ---------------------------------------------------------------------------
+// B-spline basis of degree p (<= 5) at x in knot span m: N[r] = B_{m-p+r,p}(x).
+CHOMP_HD void bspline_basis(const double* t, int m, int p, double x, double* N) {
+  double left[6], right[6];
+  N[0] = 1.0;
+  for (int j = 1; j <= p; ++j) {
+    left[j] = x - t[m + 1 - j];
+    right[j] = t[m + j] - x;
+    double saved = 0.0;
+    for (int r = 0; r < j; ++r) {
+      const double temp = N[r] / (right[r + 1] + left[j - r]);
+      N[r] = saved + right[r + 1] * temp;
+      saved = left[j - r] * temp;
+    }
+    N[j] = saved;
+  }
+}
+
+CHOMP_HD void quintic_derivs(const double* x, const double* y, int n, double xq,
+                             double* work, double* d1, double* d2) {
+  double* t = work;               // [n + 6]
+  double* ab = t + (n + 6);       // [n][11] band storage, column j at j - i + 5
+  double* c = ab + 11 * n;        // [n]
+  for (int i = 0; i < 6; ++i) { t[i] = x[0]; t[n + i] = x[n - 1]; }
+  for (int i = 0; i < n - 6; ++i) t[6 + i] = x[3 + i];
+  for (int i = 0; i < 11 * n; ++i) ab[i] = 0.0;
+  double N[6];
+  int m = 5;
+  for (int i = 0; i < n; ++i) {
+    while (m < n - 1 && x[i] >= t[m + 1]) ++m;
+    bspline_basis(t, m, 5, x[i], N);
+    for (int r = 0; r < 6; ++r) {
+      const int j = m - 5 + r;
+      ab[11 * i + (j - i + 5)] = N[r];
+    }
+    c[i] = y[i];
+  }
+  // banded elimination without pivoting (the collocation matrix is totally positive)
+  for (int col = 0; col < n; ++col) {
+    const double piv = ab[11 * col + 5];
+    const int rmax = col + 5 < n - 1 ? col + 5 : n - 1;
+    for (int r = col + 1; r <= rmax; ++r) {
+      const double a = ab[11 * r + (col - r + 5)];
+      if (a == 0.0) continue;
+      const double f = a / piv;
+      const int jmax = col + 5 < n - 1 ? col + 5 : n - 1;
+      for (int j = col; j <= jmax; ++j) {
+        const int kr = j - r + 5;
+        if (kr >= 0 && kr <= 10) ab[11 * r + kr] -= f * ab[11 * col + (j - col + 5)];
+      }
+      c[r] -= f * c[col];
+    }
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double sum = c[i];
+    const int jmax = i + 5 < n - 1 ? i + 5 : n - 1;
+    for (int j = i + 1; j <= jmax; ++j) sum -= ab[11 * i + (j - i + 5)] * c[j];
+    c[i] = sum / ab[11 * i + 5];
+  }
+  // derivatives at xq
+  m = 5;
+  while (m < n - 1 && xq >= t[m + 1]) ++m;
+  double c1[6], c2[5];
+  for (int r = 1; r <= 5; ++r) {          // j = m-5+r = m-4 .. m
+    const int j = m - 5 + r;
+    c1[r] = 5.0 * (c[j] - c[j - 1]) / (t[j + 5] - t[j]);
+  }
+  for (int r = 2; r <= 5; ++r) {          // j = m-3 .. m
+    const int j = m - 5 + r;
+    c2[r - 1] = 4.0 * (c1[r] - c1[r - 1]) / (t[j + 4] - t[j]);
+  }
+  bspline_basis(t, m, 4, xq, N);
+  double s1 = 0.0;
+  for (int r = 0; r < 5; ++r) s1 += c1[r + 1] * N[r];
+  bspline_basis(t, m, 3, xq, N);
+  double s2 = 0.0;
+  for (int r = 0; r < 4; ++r) s2 += c2[r + 1] * N[r];
+  *d1 = s1;
+  *d2 = s2;
+}
+
 // numpy.linspace(a, b, n)[i]
 // (numpy forms arange(n)*step + start with two roundings: no FMA contraction here,
 // so the knot grids are bit-identical to the reference's.)

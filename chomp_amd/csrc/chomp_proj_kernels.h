@@ -1,13 +1,563 @@
-// chomp_proj_kernels.h -- projection-side state and kernels (placeholder until the
-// MultiEpoch / window / kernel / correlation kernels land).
+// chomp_proj_kernels.h -- HIP kernels of the projection side (gfx950):
+//
+//   k_halofit_sigma / k_halofit_finalize   HaloFit._initialize_sigma_spline (halo.py:1268-1319)
+//   k_proj_chi          MultiEpoch chi(z) Romberg per grid point (cosmology.py:787-794),
+//                       growth table (:813-814), dNdz.normalize (kernel.py:43-54)
+//   k_proj_me_splines   chi(z), z(chi), D(z) splines (cosmology.py:795-817) and the
+//                       windows' chi grids (kernel.py:289-306)
+//   k_proj_window       raw_window_function per chi knot: galaxy (kernel.py:382-387),
+//                       convergence with its inner Romberg (:443-484)
+//   k_proj_window_splines  window splines (:308-313) + Kernel.__init__ scalars and
+//                       _find_z_bar (:595-639)
+//   k_proj_kernel_knots K(ln k theta) knots: Romberg over chi with J0 / J2 truncated at
+//                       the 8th Bessel zero (:678-712, 812-839)
+//   k_proj_kernel_spline  (:641-649)
+//   k_kernel_eval / k_window_eval   Kernel.kernel (:714-729), window_function (:326-340)
+//   k_wtheta            Correlation.correlation (correlation.py:242-275)
+//   k_cell              CorrelationFourier.correlation (correlation.py:360-392)
+//
+// One integral per workgroup (1 or 4 wavefronts), all splines / Bessel Chebyshev
+// tables / P(k) knot splines staged in LDS, __shfl_xor reductions.
 #pragma once
+
 #include <hip/hip_runtime.h>
-#include "chomp_math.h"
-#include "chomp_romberg.h"
+
+#include "chomp_halo_kernels.h"
 
 namespace chomp {
-struct ProjState {
-  bool ready = false;
+
+struct DndzDev {
+  int kind, pad;
+  double z_min, z_max, p[4], norm;
 };
-inline void proj_free(ProjState&) {}
+
+// Scalars of one projection set-up (host fills the inputs, kernels fill the rest).
+struct ProjDev {
+  // SingleEpoch(0) background of the MultiEpoch (cosmology.py:761-783)
+  double om0, ol0, or0, H0, growth_norm;
+  double me_z_min[3], me_z_max[3];   // 0: the kernel's MultiEpoch, 1/2: windows' copies
+  DndzDev dist[2];
+  int wkind[2];
+  double w_z_min[2], w_z_max[2], w_chi_min[2], w_chi_max[2], w_g_chi_min[2];
+  double z_min, z_max, chi_min, chi_max, ln_kt_min, ln_kt_max, j_limit, z_bar, D_zbar;
+  int order, pad;
+};
+static_assert(sizeof(ProjDev) % 8 == 0, "ProjDev granularity");
+constexpr int kProjDoubles = (int)(sizeof(ProjDev) / sizeof(double));
+
+struct ProjLayout {
+  int NC, NWp, NKT;
+  int me_z[3], me_chi[3], me_growth[3], me_pp_chi[3], me_pp_z[3], me_pp_g[3];
+  int w_chi[2], w_wf[2], w_pp[2];
+  int k_ln, k_arr, k_pp, k_lev;
+  int total;
+};
+
+inline ProjLayout make_proj_layout(int NC, int NWp, int NKT) {
+  ProjLayout L;
+  L.NC = NC; L.NWp = NWp; L.NKT = NKT;
+  int o = 0;
+  for (int m = 0; m < 3; ++m) {
+    L.me_z[m] = o; o += NC;
+    L.me_chi[m] = o; o += NC;
+    L.me_growth[m] = o; o += NC;
+    L.me_pp_chi[m] = o; o += 4 * (NC - 1);
+    L.me_pp_z[m] = o; o += 4 * (NC - 1);
+    L.me_pp_g[m] = o; o += 4 * (NC - 1);
+  }
+  for (int w = 0; w < 2; ++w) {
+    L.w_chi[w] = o; o += NWp;
+    L.w_wf[w] = o; o += NWp;
+    L.w_pp[w] = o; o += 4 * (NWp - 1);
+  }
+  L.k_ln = o; o += NKT;
+  L.k_arr = o; o += NKT;
+  L.k_pp = o; o += 4 * (NKT - 1);
+  L.k_lev = o; o += NKT;
+  L.total = (o + 7) & ~7;
+  return L;
+}
+
+struct ProjState {
+  bool ready = false;      // full kernel set-up done
+  bool me_ready = false;   // MultiEpoch 0 tables valid
+  ProjLayout L;
+  ProjDev host;            // host copy of the scalars (refreshed by kernel_info)
+  ProjDev* d_pd = nullptr;
+  double* d_tab = nullptr;
+};
+inline void proj_free(ProjState& p) {
+  if (p.d_pd) (void)hipFree(p.d_pd);
+  if (p.d_tab) (void)hipFree(p.d_tab);
+  p.d_pd = nullptr;
+  p.d_tab = nullptr;
+  p.ready = false;
+  p.me_ready = false;
+}
+
+// ---------------------------------------------------------------------------
+// HaloFit
+// ---------------------------------------------------------------------------
+// grid NK, block 256: ln sigma^2(R_i), R_i = exp(linspace(ln 0.1, ln 10, NK)).
+__global__ __launch_bounds__(256) void k_halofit_sigma(chomp_config cfg, TabLayout L,
+                                                       const Epoch* __restrict__ epochs,
+                                                       int e, double* __restrict__ tab) {
+  __shared__ Epoch E;
+  __shared__ double red[8];
+  copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
+               kEpochDoubles);
+  __syncthreads();
+  const int i = blockIdx.x;
+  const double R = exp(linspace_at(log(0.1), log(10.0), L.NK, i));
+  HalofitSigmaIntegrand f{&E, R};
+  const double s2 = romberg1<4>(f, log(cfg.k_min), log(cfg.k_max), cfg.global_precision,
+                                cfg.halo_precision, cfg.divmax, red);
+  if (threadIdx.x == 0) tab[(size_t)e * L.stride + L.off_hf_lns2 + i] = log(s2);
+}
+
+// grid 1, block 64 (one lane works): k_sigma, n_eff, C and the Takahashi et al.
+// coefficients (halo.py:1285-1317) of epoch `src` stored into epoch `dst`.
+__global__ void k_halofit_finalize(TabLayout L, Epoch* __restrict__ epochs, int dst, int src,
+                                   const double* __restrict__ tab, double f1, double f2,
+                                   double f3, double omega_l, double w,
+                                   double* __restrict__ work) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int n = L.NK;
+  const double* lns2 = tab + (size_t)src * L.stride + L.off_hf_lns2;
+  double* xr = work;             // reversed ln sigma^2 (increasing)
+  double* yr = xr + n;           // reversed ln R
+  double* lnR = yr + n;
+  double* c = lnR + n;           // [4(n-1)]
+  double* w2 = c + 4 * (n - 1);  // scratch: max(2n, (n+6) + 12 n)
+  for (int i = 0; i < n; ++i) {
+    lnR[i] = linspace_at(log(0.1), log(10.0), n, i);
+  }
+  for (int i = 0; i < n; ++i) {
+    xr[i] = lns2[n - 1 - i];
+    yr[i] = lnR[n - 1 - i];
+  }
+  spline_build(xr, yr, n, c, w2);
+  const double k_s = 1.0 / exp(spline_eval(xr, c, n, 0.0));            // halo.py:1285-1287
+  double d1, d2;
+  quintic_derivs(lnR, lns2, n, log(1.0 / k_s), w2, &d1, &d2);          // :1289-1292
+  const double ne = -d1 - 3.0, C = -d2;
+  Epoch& E = epochs[dst];
+  E.hf_f1 = f1; E.hf_f2 = f2; E.hf_f3 = f3;
+  E.hf_k_s = k_s; E.hf_n_eff = ne; E.hf_C = C;
+  E.hf_a_n = pow(10.0, 1.5222 + 2.8553 * ne + 2.3706 * ne * ne + 0.9903 * ne * ne * ne +
+                           0.2250 * ne * ne * ne * ne + -0.6038 * C +
+                           0.1749 * omega_l * (1.0 + w));
+  E.hf_b_n = pow(10.0, -0.5642 + 0.5864 * ne + 0.5716 * ne * ne + -1.5474 * C +
+                           0.2279 * omega_l * (1.0 + w));
+  E.hf_c_n = pow(10.0, 0.3698 + 2.0404 * ne + 0.8161 * ne * ne + 0.5869 * C);
+  E.hf_gamma_n = 0.1971 - 0.0843 * ne + 0.8460 * C;
+  E.hf_alpha_n = fabs(6.0835 + 1.3373 * ne - 0.1959 * ne * ne + -5.5274 * C);
+  E.hf_beta_n = 2.0379 - 0.7354 * ne + 0.3157 * ne * ne + 1.2490 * ne * ne * ne +
+                0.3980 * ne * ne * ne * ne + -0.1682 * C;
+  E.hf_mu_n = 0.0;
+  E.hf_nu_n = pow(10.0, 5.2105 + 3.6902 * ne);
+}
+
+// ---------------------------------------------------------------------------
+// Redshift distributions (kernel.py:26-179)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double dndz_raw(const DndzDev& d, double z) {
+  if (d.kind == CHOMP_DNDZ_MAGLIM)          // z^a exp(-(z/z0)^b), p = {a, z0, b}
+    return pow(z, d.p[0]) * exp(-1.0 * pow(z / d.p[1], d.p[2]));
+  const double t = z - d.p[0];              // Gaussian, p = {z0, sigma_z}
+  return exp(-1.0 * t * t / (2.0 * d.p[1] * d.p[1]));
+}
+__device__ __forceinline__ double dndz_eval(const DndzDev& d, double z) {
+  return (z <= d.z_max && z >= d.z_min) ? d.norm * dndz_raw(d, z) : 0.0;
+}
+struct DndzRaw {
+  const DndzDev* d;
+  __device__ __forceinline__ double operator()(double z) const { return dndz_raw(*d, z); }
+};
+
+// grid (NC, 4), block 64.  y < 3: chi and growth of MultiEpoch y at grid point x;
+// y == 3, x < 2: normalisation of distribution x.
+__global__ __launch_bounds__(64) void k_proj_chi(chomp_config cfg, ProjLayout L,
+                                                 ProjDev* __restrict__ pd,
+                                                 double* __restrict__ tab) {
+  const int i = blockIdx.x, m = blockIdx.y;
+  if (m == 3) {
+    if (i >= 2) return;
+    __shared__ DndzDev D;
+    if (threadIdx.x == 0) D = pd->dist[i];
+    __syncthreads();
+    DndzRaw f{&D};
+    const double norm = romberg1<1>(f, D.z_min, D.z_max, cfg.global_precision,
+                                    cfg.dNdz_precision, cfg.divmax, nullptr);
+    if (threadIdx.x == 0) pd->dist[i].norm = 1.0 / norm;
+    return;
+  }
+  const double z = linspace_at(pd->me_z_min[m], pd->me_z_max[m], L.NC, i);
+  EIntegrand f{pd->om0, pd->ol0, pd->or0, pd->H0};
+  const double chi = romberg1<1>(f, 0.0, z, cfg.global_precision, cfg.cosmo_precision,
+                                 cfg.divmax, nullptr);
+  if (threadIdx.x == 0) {
+    tab[L.me_z[m] + i] = z;
+    tab[L.me_chi[m] + i] = chi;
+    tab[L.me_growth[m] + i] = growth_approx(pd->om0, pd->ol0, 1.0 / (1.0 + z)) / pd->growth_norm;
+  }
+}
+
+// MultiEpoch lookups with the reference's range rules (cosmology.py:873-953).
+struct MEView {
+  const double *z, *chi, *pp_chi, *pp_z, *pp_g;   // z uniform, chi increasing
+  int NC;
+  double z_min, z_max;
+  __device__ __forceinline__ double dz() const { return (z_max - z_min) / (double)(NC - 1); }
+  __device__ __forceinline__ double comoving_distance(double zz) const {
+    return (zz <= z_max && zz >= z_min) ? spline_eval_uniform(z_min, dz(), pp_chi, NC, zz) : 0.0;
+  }
+  __device__ __forceinline__ double redshift(double c) const {
+    return spline_eval(chi, pp_z, NC, c);
+  }
+  __device__ __forceinline__ double growth_factor(double zz) const {
+    return (zz <= z_max && zz >= z_min) ? spline_eval_uniform(z_min, dz(), pp_g, NC, zz) : 1.0;
+  }
+};
+__device__ __forceinline__ MEView me_view(const ProjLayout& L, const ProjDev& pd,
+                                          const double* tab, int m) {
+  return MEView{tab + L.me_z[m], tab + L.me_chi[m], tab + L.me_pp_chi[m], tab + L.me_pp_z[m],
+                tab + L.me_pp_g[m], L.NC, pd.me_z_min[m], pd.me_z_max[m]};
+}
+
+// grid 3, block 192.  Splines of MultiEpoch m; blocks 1/2 then lay out window
+// (m-1)'s chi grid (kernel.py:298-304, 438-441).
+__global__ __launch_bounds__(192) void k_proj_me_splines(chomp_config cfg, ProjLayout L,
+                                                         ProjDev* __restrict__ pd,
+                                                         double* __restrict__ tab,
+                                                         double* __restrict__ work) {
+  const int m = blockIdx.x, NC = L.NC;
+  double* wk = work + (size_t)m * 6 * NC;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
+    if (wave == 0) spline_build(tab + L.me_z[m], tab + L.me_chi[m], NC, tab + L.me_pp_chi[m], wk);
+    if (wave == 1) spline_build(tab + L.me_chi[m], tab + L.me_z[m], NC, tab + L.me_pp_z[m], wk + 2 * NC);
+    if (wave == 2) spline_build(tab + L.me_z[m], tab + L.me_growth[m], NC, tab + L.me_pp_g[m], wk + 4 * NC);
+  }
+  __threadfence_block();
+  __syncthreads();
+  if (m == 0) return;
+  const int w = m - 1;
+  __shared__ double lim[2];
+  if (threadIdx.x == 0) {
+    const MEView me = me_view(L, *pd, tab, m);
+    const double wp = cfg.window_precision;
+    double cmin = me.comoving_distance(pd->w_z_min[w]);
+    if (cmin < wp) cmin = wp;
+    const double cmax = me.comoving_distance(pd->w_z_max[w]);
+    double g = me.comoving_distance(pd->dist[w].z_min);
+    if (g < wp) g = wp;
+    pd->w_chi_min[w] = cmin;
+    pd->w_chi_max[w] = cmax;
+    pd->w_g_chi_min[w] = g;
+    lim[0] = cmin;
+    lim[1] = cmax;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < L.NWp; i += blockDim.x)
+    tab[L.w_chi[w] + i] = linspace_at(lim[0], lim[1], L.NWp, i);
+}
+
+// Lensing-efficiency integrand, kernel.py:479-484.
+struct LensIntegrand {
+  const double *chi_knots, *pp_z;
+  int NC;
+  const DndzDev* d;
+  double om0, ol0, or0, H0, chi0;
+  __device__ __forceinline__ double operator()(double c) const {
+    const double z = spline_eval(chi_knots, pp_z, NC, c);
+    const double dzdchi = H0 * sqrt(E0_of(om0, ol0, or0, z));
+    return dzdchi * dndz_eval(*d, z) * (c - chi0) / c;
+  }
+};
+
+// grid (NWp, 2), block 64: raw window function of window y at its x-th chi knot.
+__global__ __launch_bounds__(64) void k_proj_window(chomp_config cfg, ProjLayout L,
+                                                    const ProjDev* __restrict__ pd,
+                                                    double* __restrict__ tab) {
+  extern __shared__ __align__(16) double sm[];
+  __shared__ DndzDev D;
+  const int i = blockIdx.x, w = blockIdx.y, m = w + 1, NC = L.NC;
+  double* chi_knots = sm;
+  double* pp_z = sm + NC;
+  copy_doubles(chi_knots, tab + L.me_chi[m], NC);
+  copy_doubles(pp_z, tab + L.me_pp_z[m], 4 * (NC - 1));
+  if (threadIdx.x == 0) D = pd->dist[w];
+  __syncthreads();
+  const double chi = tab[L.w_chi[w] + i];
+  const double z = spline_eval(chi_knots, pp_z, NC, chi);
+  double val;
+  if (pd->wkind[w] == CHOMP_WINDOW_GALAXY) {                       // kernel.py:382-387
+    val = pd->H0 * sqrt(E0_of(pd->om0, pd->ol0, pd->or0, z)) * dndz_eval(D, z);
+  } else {                                                         // kernel.py:443-477
+    const double a = 1.0 / (1.0 + z);
+    double bound = chi;
+    if (bound < pd->w_g_chi_min[w]) bound = pd->w_g_chi_min[w];
+    double g = 0.0;
+    if (!(bound <= cfg.window_precision)) {
+      LensIntegrand f{chi_knots, pp_z, NC, &D, pd->om0, pd->ol0, pd->or0, pd->H0, chi};
+      g = romberg1<1>(f, bound, pd->w_chi_max[w], cfg.global_precision,
+                      cfg.window_precision, cfg.divmax, nullptr);
+    }
+    g *= pd->H0 * pd->H0 * chi;
+    val = 3.0 / 2.0 * pd->om0 * g / a;
+  }
+  if (threadIdx.x == 0) tab[L.w_wf[w] + i] = val;
+}
+
+// Window lookup with the range rule of kernel.py:326-340 (uniform chi knots).
+struct WindowView {
+  const double* pp;
+  int N;
+  double chi_min, chi_max;
+  __device__ __forceinline__ double operator()(double c) const {
+    if (!(c >= chi_min && c <= chi_max)) return 0.0;
+    return spline_eval_uniform(chi_min, (chi_max - chi_min) / (double)(N - 1), pp, N, c);
+  }
+};
+
+// grid 1, block 128: window splines, then Kernel.__init__ scalars + _find_z_bar.
+__global__ __launch_bounds__(128) void k_proj_window_splines(chomp_config cfg, ProjLayout L,
+                                                             ProjDev* __restrict__ pd,
+                                                             double* __restrict__ tab,
+                                                             double* __restrict__ work) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0)
+    spline_build(tab + L.w_chi[wave], tab + L.w_wf[wave], L.NWp, tab + L.w_pp[wave],
+                 work + (size_t)wave * 2 * L.NWp);
+  __threadfence_block();
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const MEView me = me_view(L, *pd, tab, 0);
+  const WindowView wa{tab + L.w_pp[0], L.NWp, pd->w_chi_min[0], pd->w_chi_max[0]};
+  const WindowView wb{tab + L.w_pp[1], L.NWp, pd->w_chi_min[1], pd->w_chi_max[1]};
+  const double z_min = pd->w_z_min[0] > pd->w_z_min[1] ? pd->w_z_min[0] : pd->w_z_min[1];
+  const double z_max = pd->w_z_max[0] < pd->w_z_max[1] ? pd->w_z_max[0] : pd->w_z_max[1];
+  pd->z_min = z_min;                                               // kernel.py:595-598
+  pd->z_max = z_max;
+  const double c0 = me.comoving_distance(z_min);
+  pd->chi_min = cfg.window_precision > c0 ? cfg.window_precision : c0;   // :610-612
+  pd->chi_max = me.comoving_distance(z_max);
+  for (int i = 0; i < L.NKT; ++i)
+    tab[L.k_ln + i] = linspace_at(pd->ln_kt_min, pd->ln_kt_max, L.NKT, i);
+  // _find_z_bar (:635-639): argmax over linspace(z_min, z_max, NKT) of W_a W_b D^2
+  double best = -INFINITY, zb = z_min;
+  for (int i = 0; i < L.NKT; ++i) {
+    const double z = linspace_at(z_min, z_max, L.NKT, i);
+    const double chi = me.comoving_distance(z);
+    const double D = me.growth_factor(me.redshift(chi));
+    const double v = wa(chi) * wb(chi) * D * D;
+    if (v > best) { best = v; zb = z; }
+  }
+  pd->z_bar = zb;
+  pd->D_zbar = me.growth_factor(zb);                               // correlation.py:94
+}
+
+// LDS-resident view of everything a projection integrand needs.
+struct ProjLds {
+  MEView me;
+  WindowView wa, wb;
+  const BesselTab* bess;
+  // Carve `sm` and copy the tables in (all threads; barrier afterwards).
+  __device__ __forceinline__ double* stage(const ProjLayout& L, const ProjDev& pd,
+                                           const double* tab, double* sm) {
+    const int NC = L.NC, NW = L.NWp;
+    double* chi = sm;                 // [NC]
+    double* pp_z = chi + NC;          // [4(NC-1)]
+    double* pp_g = pp_z + 4 * (NC - 1);
+    double* pa = pp_g + 4 * (NC - 1); // [4(NW-1)]
+    double* pb = pa + 4 * (NW - 1);
+    copy_doubles(chi, tab + L.me_chi[0], NC);
+    copy_doubles(pp_z, tab + L.me_pp_z[0], 4 * (NC - 1));
+    copy_doubles(pp_g, tab + L.me_pp_g[0], 4 * (NC - 1));
+    copy_doubles(pa, tab + L.w_pp[0], 4 * (NW - 1));
+    copy_doubles(pb, tab + L.w_pp[1], 4 * (NW - 1));
+    me = MEView{nullptr, chi, nullptr, pp_z, pp_g, NC, pd.me_z_min[0], pd.me_z_max[0]};
+    wa = WindowView{pa, NW, pd.w_chi_min[0], pd.w_chi_max[0]};
+    wb = WindowView{pb, NW, pd.w_chi_min[1], pd.w_chi_max[1]};
+    return pb + 4 * (NW - 1);
+  }
+  static __host__ __device__ int doubles(const ProjLayout& L) {
+    return L.NC + 8 * (L.NC - 1) + 8 * (L.NWp - 1);
+  }
+};
+
+// kernel.py:707-712 (J0) / 833-839 (J2)
+template <int ORDER>
+struct KernelIntegrand {
+  const ProjLds* P;
+  double ktheta;
+  __device__ __forceinline__ double operator()(double chi) const {
+    const double D = P->me.growth_factor(P->me.redshift(chi));
+    return P->wa(chi) * P->wb(chi) * D * D * bessel_j<ORDER>(ktheta * chi, *P->bess);
+  }
+};
+
+// grid NKT, block 256: one kernel knot per block.
+__global__ __launch_bounds__(256) void k_proj_kernel_knots(chomp_config cfg, ProjLayout L,
+                                                           const ProjDev* __restrict__ pdg,
+                                                           double* __restrict__ tab,
+                                                           const BesselTab* __restrict__ bess_g) {
+  extern __shared__ __align__(16) double sm[];
+  __shared__ ProjDev pd;
+  __shared__ BesselTab B;
+  __shared__ double red[8];
+  copy_doubles(reinterpret_cast<double*>(&pd), reinterpret_cast<const double*>(pdg), kProjDoubles);
+  copy_doubles(reinterpret_cast<double*>(&B), reinterpret_cast<const double*>(bess_g),
+               (int)(sizeof(BesselTab) / sizeof(double)));
+  __syncthreads();
+  ProjLds P;
+  P.stage(L, pd, tab, sm);
+  P.bess = &B;
+  __syncthreads();
+  const int i = blockIdx.x;
+  const double ktheta = exp(tab[L.k_ln + i]);
+  double chi_max = pd.j_limit / ktheta;                            // kernel.py:689-691
+  if (chi_max >= pd.chi_max) chi_max = pd.chi_max;
+  int level = 0;
+  double v;
+  if (pd.order == 0) {
+    KernelIntegrand<0> f{&P, ktheta};
+    v = romberg1<4>(f, pd.chi_min, chi_max, cfg.global_precision, cfg.kernel_precision,
+                    cfg.divmax, red, &level);
+  } else {
+    KernelIntegrand<2> f{&P, ktheta};
+    v = romberg1<4>(f, pd.chi_min, chi_max, cfg.global_precision, cfg.kernel_precision,
+                    cfg.divmax, red, &level);
+  }
+  if (threadIdx.x == 0) {
+    tab[L.k_arr + i] = v;
+    tab[L.k_lev + i] = (double)level;
+  }
+}
+
+__global__ void k_proj_kernel_spline(ProjLayout L, double* __restrict__ tab,
+                                     double* __restrict__ work) {
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    spline_build(tab + L.k_ln, tab + L.k_arr, L.NKT, tab + L.k_pp, work);
+}
+
+// Kernel.kernel(ln_ktheta), kernel.py:714-729 (uniform ln(k theta) knots).
+struct KernelView {
+  const double* pp;
+  int N;
+  double lo, hi;
+  __device__ __forceinline__ double operator()(double x) const {
+    const double dx = (hi - lo) / (double)(N - 1);
+    if (x < lo) return pp_poly(pp, 0, 0.0);
+    if (x <= hi) return spline_eval_uniform(lo, dx, pp, N, x);
+    return 0.0;
+  }
+};
+
+__global__ void k_kernel_eval(ProjLayout L, const ProjDev* __restrict__ pd,
+                              const double* __restrict__ tab, const double* __restrict__ x,
+                              int n, double* __restrict__ out) {
+  const KernelView K{tab + L.k_pp, L.NKT, pd->ln_kt_min, pd->ln_kt_max};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    out[i] = K(x[i]);
+}
+
+__global__ void k_me_eval(ProjLayout L, const ProjDev* __restrict__ pd,
+                          const double* __restrict__ tab, int what,
+                          const double* __restrict__ x, int n, double* __restrict__ out) {
+  const MEView me = me_view(L, *pd, tab, 0);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const double v = x[i];
+    out[i] = what == CHOMP_ME_CHI_OF_Z ? me.comoving_distance(v)
+             : what == CHOMP_ME_Z_OF_CHI ? me.redshift(v) : me.growth_factor(v);
+  }
+}
+
+__global__ void k_window_eval(ProjLayout L, const ProjDev* __restrict__ pd,
+                              const double* __restrict__ tab, int w,
+                              const double* __restrict__ x, int n, double* __restrict__ out) {
+  const WindowView W{tab + L.w_pp[w], L.NWp, pd->w_chi_min[w], pd->w_chi_max[w]};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    out[i] = W(x[i]);
+}
+
+// correlation.py:270-275
+struct WthetaIntegrand {
+  const PowerEval* P;
+  const KernelView* K;
+  double theta, inv_D2;
+  __device__ __forceinline__ double operator()(double ln_k) const {
+    const double k = exp(ln_k);
+    return k * k / (2.0 * kPi) * (*P)(k) * inv_D2 * (*K)(log(k * theta));
+  }
+};
+
+// grid n_theta, block 256: one theta per workgroup.
+__global__ __launch_bounds__(256) void k_wtheta(chomp_config cfg, TabLayout HL, ProjLayout L,
+                                                const Epoch* __restrict__ epochs, int e,
+                                                const double* __restrict__ htab, int which,
+                                                const ProjDev* __restrict__ pd,
+                                                const double* __restrict__ ptab, double k_min,
+                                                double k_max, double D_z,
+                                                const double* __restrict__ theta,
+                                                double* __restrict__ out) {
+  extern __shared__ __align__(16) double sm[];
+  __shared__ Epoch E;
+  __shared__ double red[8];
+  copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
+               kEpochDoubles);
+  PowerEval P;
+  P.stage(cfg, HL, &E, htab + (size_t)e * HL.stride, which, sm);
+  double* kpp = sm + 12 * (HL.NK - 1);
+  copy_doubles(kpp, ptab + L.k_pp, 4 * (L.NKT - 1));
+  __syncthreads();
+  P.finish();
+  const KernelView K{kpp, L.NKT, pd->ln_kt_min, pd->ln_kt_max};
+  WthetaIntegrand f{&P, &K, theta[blockIdx.x], 1.0 / (D_z * D_z)};
+  const double v = romberg1<4>(f, log(k_min), log(k_max), cfg.global_precision,
+                               cfg.corr_precision, cfg.divmax, red);
+  if (threadIdx.x == 0) out[blockIdx.x] = v;
+}
+
+// correlation.py:387-392
+struct CellIntegrand {
+  const PowerEval* P;
+  const ProjLds* G;
+  double ell, inv_D2;
+  __device__ __forceinline__ double operator()(double chi) const {
+    const double D = G->me.growth_factor(G->me.redshift(chi));
+    return (*P)(ell / chi) * inv_D2 * G->wa(chi) * G->wb(chi) * D * D / (chi * chi);
+  }
+};
+
+// grid n_ell, block 256: one multipole per workgroup.
+__global__ __launch_bounds__(256) void k_cell(chomp_config cfg, TabLayout HL, ProjLayout L,
+                                              const Epoch* __restrict__ epochs, int e,
+                                              const double* __restrict__ htab, int which,
+                                              const ProjDev* __restrict__ pdg,
+                                              const double* __restrict__ ptab, double D_z,
+                                              const double* __restrict__ ell,
+                                              double* __restrict__ out) {
+  extern __shared__ __align__(16) double sm[];
+  __shared__ Epoch E;
+  __shared__ ProjDev pd;
+  __shared__ double red[8];
+  copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
+               kEpochDoubles);
+  copy_doubles(reinterpret_cast<double*>(&pd), reinterpret_cast<const double*>(pdg), kProjDoubles);
+  __syncthreads();
+  PowerEval P;
+  P.stage(cfg, HL, &E, htab + (size_t)e * HL.stride, which, sm);
+  ProjLds G;
+  G.stage(L, pd, ptab, sm + 12 * (HL.NK - 1));
+  G.bess = nullptr;
+  __syncthreads();
+  P.finish();
+  CellIntegrand f{&P, &G, ell[blockIdx.x], 1.0 / (D_z * D_z)};
+  const double v = romberg1<4>(f, pd.chi_min, pd.chi_max, cfg.global_precision,
+                               cfg.corr_precision, cfg.divmax, red);
+  if (threadIdx.x == 0) out[blockIdx.x] = v;
+}
+
 }  // namespace chomp

@@ -259,6 +259,18 @@ int chomp_kernel_setup(chomp_ctx* ctx, const chomp_cosmo* cosmo, double me_z_min
                        const chomp_window* a, const chomp_window* b,
                        int bessel_order);
 
+/* cosmology.MultiEpoch alone (cosmology.py:747-817): the 50-point chi(z), z(chi),
+ * D(z) tables and splines, without windows or kernel. */
+int chomp_multi_epoch_setup(chomp_ctx* ctx, const chomp_cosmo* cosmo, double z_min,
+                            double z_max);
+/* MultiEpoch.comoving_distance / redshift / growth_factor (cosmology.py:873-953)
+ * of the context's MultiEpoch (after chomp_multi_epoch_setup or chomp_kernel_setup). */
+#define CHOMP_ME_CHI_OF_Z 0
+#define CHOMP_ME_Z_OF_CHI 1
+#define CHOMP_ME_GROWTH_OF_Z 2
+int chomp_me_eval(chomp_ctx* ctx, int what, const double* x, size_t n, double* out,
+                  int mem);
+
 #define CHOMP_KI_Z_BAR 0
 #define CHOMP_KI_CHI_MIN 1
 #define CHOMP_KI_CHI_MAX 2
@@ -267,7 +279,12 @@ int chomp_kernel_setup(chomp_ctx* ctx, const chomp_cosmo* cosmo, double me_z_min
 #define CHOMP_KI_D_ZBAR 5 /* MultiEpoch.growth_factor(z_bar), correlation.py:94 */
 #define CHOMP_KI_NORM_A 6 /* dNdz.norm of window a's distribution */
 #define CHOMP_KI_NORM_B 7
-#define CHOMP_KI_COUNT 8
+#define CHOMP_KI_WA_CHI_MIN 8 /* WindowFunction.chi_min / chi_max of window a, b */
+#define CHOMP_KI_WA_CHI_MAX 9
+#define CHOMP_KI_WB_CHI_MIN 10
+#define CHOMP_KI_WB_CHI_MAX 11
+#define CHOMP_KI_J_LIMIT 12   /* Kernel._j0_limit / _j2_limit */
+#define CHOMP_KI_COUNT 13
 int chomp_kernel_info(chomp_ctx* ctx, double* out);
 
 #define CHOMP_KTAB_LN_KTHETA 0 /* Kernel._ln_ktheta_array [kernel_npoints]   */

@@ -33,6 +33,11 @@ void hc_spline(const double* x, const double* y, int n, const double* xe, int ne
                      : spline_eval(x, c, n, xe[i]);
   delete[] c; delete[] w;
 }
+void hc_quintic(const double* x, const double* y, int n, double xq, double* d) {
+  double* w = new double[(n + 6) + 11 * n + n];
+  quintic_derivs(x, y, n, xq, w, &d[0], &d[1]);
+  delete[] w;
+}
 // epoch background + linear power + sigma integrand + y_nfw + mass function + HOD
 void hc_epoch(const double* cosmo, double z, double sigma_norm, Epoch* e) {
   std::memset(e, 0, sizeof(Epoch));

@@ -75,6 +75,18 @@ def test_notaknot_spline(hc):
         assert numpy.max(numpy.abs(out - ref(xe)) / (1 + numpy.abs(ref(xe)))) < 2e-13
 
 
+def test_quintic_derivatives(hc):
+    """HaloFit's k=5 spline derivatives (halo.py:1289-1292)."""
+    x = numpy.linspace(numpy.log(0.1), numpy.log(10.0), 50)
+    y = -1.3 * x - 0.21 * x ** 2 + 0.01 * numpy.sin(2 * x) + 0.4
+    sp = InterpolatedUnivariateSpline(x, y, k=5)
+    d = numpy.empty(2)
+    for xq in (-2.0, -0.9957, 0.0, 0.3337, 1.9, x[7], x[0], x[-1]):
+        hc.hc_quintic(_p(x), _p(y), x.size, ctypes.c_double(xq), _p(d))
+        ref = sp.derivatives(xq)[1:3]
+        assert numpy.allclose(d, ref, rtol=1e-9, atol=1e-11), (xq, d, ref)
+
+
 def _epoch(hc, cd, z, sigma_norm=1.0):
     n = hc.hc_sizeof_epoch()
     buf = (ctypes.c_char * n)()
