@@ -45,9 +45,14 @@ struct chomp_ctx {
   chomp_halo_par* d_mass_par = nullptr;
   chomp_halo_par* d_profile = nullptr;
   HodDev* d_hod = nullptr;
+  double* d_nodes = nullptr;       // node tables of the halo integrals
+  double* d_snodes = nullptr;      // node tables of the sigma(R) integrals
   bool have_epochs = false, have_mass = false, have_halo = false;
   unsigned fam_mask = 0;          // families (F_* bits) with valid splines
   std::vector<char> have_halofit;
+  // host shadows of the uploaded parameter blocks: an unchanged block is not
+  // re-uploaded (MCMC-style loops re-run the set-up with mostly identical inputs)
+  std::vector<char> sh_cosmo, sh_z, sh_mass, sh_profile, sh_hod;
 
   // staging for host-pointer calls
   double* d_stage_in = nullptr;
@@ -74,6 +79,18 @@ int fail(chomp_ctx* c, int code, const std::string& msg) {
       return fail(ctx, CHOMP_ERR_HIP,                                             \
                   std::string(#call) + ": " + hipGetErrorString(e_));             \
   } while (0)
+
+// Upload `bytes` from `src` to `dst` unless the shadow says the device already holds
+// exactly these bytes.  A changed block is copied from the shadow (which outlives
+// the call) and the stream is drained so the shadow can be rewritten next time.
+int upload(chomp_ctx* ctx, void* dst, const void* src, size_t bytes, std::vector<char>& shadow) {
+  if (shadow.size() == bytes && std::memcmp(shadow.data(), src, bytes) == 0) return CHOMP_OK;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(ctx, CHOMP_ERR_HIP, "upload: sync");
+  shadow.assign(static_cast<const char*>(src), static_cast<const char*>(src) + bytes);
+  hipError_t e = hipMemcpyAsync(dst, shadow.data(), bytes, hipMemcpyHostToDevice, ctx->stream);
+  if (e != hipSuccess) return fail(ctx, CHOMP_ERR_HIP, std::string("upload: ") + hipGetErrorString(e));
+  return CHOMP_OK;
+}
 
 template <class T>
 int ensure(chomp_ctx* ctx, T** p, size_t* cap, size_t n) {
@@ -157,7 +174,7 @@ int setup_constants(chomp_ctx* ctx) {
 int alloc_epochs(chomp_ctx* ctx, size_t n) {
   if (n <= ctx->cap_epoch) return CHOMP_OK;
   void* old[] = {ctx->d_cosmo, ctx->d_z, ctx->d_epochs, ctx->d_search, ctx->d_tab,
-                 ctx->d_mass_par, ctx->d_profile, ctx->d_hod};
+                 ctx->d_mass_par, ctx->d_profile, ctx->d_hod, ctx->d_nodes, ctx->d_snodes};
   for (void* p : old)
     if (p) HIPCHK(hipFree(p));
   HIPCHK(hipMalloc(&ctx->d_cosmo, n * sizeof(chomp_cosmo)));
@@ -168,7 +185,11 @@ int alloc_epochs(chomp_ctx* ctx, size_t n) {
   HIPCHK(hipMalloc(&ctx->d_mass_par, n * sizeof(chomp_halo_par)));
   HIPCHK(hipMalloc(&ctx->d_profile, n * sizeof(chomp_halo_par)));
   HIPCHK(hipMalloc(&ctx->d_hod, n * sizeof(HodDev)));
+  HIPCHK(hipMalloc(&ctx->d_nodes, n * 3 * (size_t)kNodeStride * sizeof(double)));
+  HIPCHK(hipMalloc(&ctx->d_snodes, n * (size_t)kSigmaStride * sizeof(double)));
   ctx->cap_epoch = n;
+  ctx->sh_cosmo.clear(); ctx->sh_z.clear(); ctx->sh_mass.clear();
+  ctx->sh_profile.clear(); ctx->sh_hod.clear();
   return CHOMP_OK;
 }
 
@@ -239,7 +260,7 @@ void chomp_ctx_destroy(chomp_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   void* ptrs[] = {ctx->d_sici, ctx->d_j0, ctx->d_j2, ctx->d_tinker, ctx->d_gl16,
                   ctx->d_cand, ctx->d_cosmo, ctx->d_z, ctx->d_epochs, ctx->d_search,
-                  ctx->d_tab, ctx->d_mass_par, ctx->d_profile, ctx->d_hod,
+                  ctx->d_tab, ctx->d_mass_par, ctx->d_profile, ctx->d_hod, ctx->d_nodes, ctx->d_snodes,
                   ctx->d_stage_in, ctx->d_stage_in2, ctx->d_stage_out, ctx->d_work};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -275,14 +296,15 @@ int chomp_epochs_set(chomp_ctx* ctx, size_t n_epoch, const chomp_cosmo* cosmo,
   ctx->have_mass = ctx->have_halo = false;
   ctx->fam_mask = 0;
   ctx->have_halofit.assign(n_epoch, 0);
-  HIPCHK(hipMemcpyAsync(ctx->d_cosmo, cosmo, n_epoch * sizeof(chomp_cosmo),
-                        hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->d_z, z, n_epoch * sizeof(double), hipMemcpyHostToDevice,
-                        ctx->stream));
-  // pageable host memory: the async copies above have completed staging on return
-  hipLaunchKernelGGL(k_epoch_init, dim3((unsigned)n_epoch, 2), dim3(1024), 0, ctx->stream,
+  rc = upload(ctx, ctx->d_cosmo, cosmo, n_epoch * sizeof(chomp_cosmo), ctx->sh_cosmo);
+  if (rc) return rc;
+  rc = upload(ctx, ctx->d_z, z, n_epoch * sizeof(double), ctx->sh_z);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_sigma_nodes, dim3((kSigmaCount + 255) / 256, (unsigned)n_epoch), dim3(256),
+                     0, ctx->stream, ctx->cfg, ctx->d_cosmo, ctx->d_z, ctx->d_snodes);
+  hipLaunchKernelGGL(k_epoch_init, dim3((unsigned)n_epoch, 2), dim3(64 * kInitNW), 0, ctx->stream,
                      ctx->cfg, ctx->d_cosmo, ctx->d_z, ctx->d_epochs, ctx->d_search,
-                     ctx->d_cand);
+                     ctx->d_cand, ctx->d_snodes);
   HIPCHK(hipGetLastError());
   ctx->have_epochs = true;
   return CHOMP_OK;
@@ -296,10 +318,10 @@ int chomp_mass_setup(chomp_ctx* ctx, const chomp_halo_par* par, int mf_kind) {
   HIPCHK(hipSetDevice(ctx->device));
   const size_t n = ctx->n_epoch;
   const TabLayout& L = ctx->L;
-  HIPCHK(hipMemcpyAsync(ctx->d_mass_par, par, n * sizeof(chomp_halo_par),
-                        hipMemcpyHostToDevice, ctx->stream));
+  int rcu = upload(ctx, ctx->d_mass_par, par, n * sizeof(chomp_halo_par), ctx->sh_mass);
+  if (rcu) return rcu;
   hipLaunchKernelGGL(k_nu_table, dim3(L.NM, (unsigned)n), dim3(256), 0, ctx->stream, ctx->cfg,
-                     L, ctx->d_epochs, ctx->d_search, ctx->d_tab);
+                     L, ctx->d_epochs, ctx->d_search, ctx->d_snodes, ctx->d_tab);
   const size_t sh = (size_t)(2 * L.NM + 8 * (L.NM - 1) + 4 * L.NM + 32 + 8) * sizeof(double);
   hipLaunchKernelGGL(k_mass_setup, dim3((unsigned)n), dim3(256), sh, ctx->stream, ctx->cfg, L,
                      ctx->d_epochs, ctx->d_search, ctx->d_tab, ctx->d_mass_par, mf_kind,
@@ -336,11 +358,10 @@ int chomp_halo_setup(chomp_ctx* ctx, const chomp_halo_par* profile,
     d.second_zero = std::pow(10.0, h.log_M_0);
     d.safe_norm = std::pow(10.0, h.log_M_min + 1.0 * h.sigma);
   }
-  HIPCHK(hipMemcpyAsync(ctx->d_profile, profile, n * sizeof(chomp_halo_par),
-                        hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->d_hod, hd.data(), n * sizeof(HodDev), hipMemcpyHostToDevice,
-                        ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));    // hd is a local buffer
+  int rcu = upload(ctx, ctx->d_profile, profile, n * sizeof(chomp_halo_par), ctx->sh_profile);
+  if (rcu) return rcu;
+  rcu = upload(ctx, ctx->d_hod, hd.data(), n * sizeof(HodDev), ctx->sh_hod);
+  if (rcu) return rcu;
   // header bits CHOMP_T_* are (1 << F_*) by construction
   const unsigned fam = tables & 31u;
   int groups[3] = {-1, -1, -1};
@@ -349,10 +370,19 @@ int chomp_halo_setup(chomp_ctx* ctx, const chomp_halo_par* profile,
   if (fam & ((1u << F_HG) | (1u << F_PPGM))) groups[ng++] = 1;
   if (fam & (1u << F_PPGG)) groups[ng++] = 2;
   if (ng == 0) groups[ng++] = 3;     // n_bar only
-  const size_t sh = (size_t)(L.NM + 8 * (L.NM - 1) + 8) * sizeof(double);
-  hipLaunchKernelGGL(k_halo_knots, dim3(L.NK + 1, (unsigned)n, ng), dim3(256), sh, ctx->stream,
+  const size_t sh = (size_t)(L.NM + 8 * (L.NM - 1) + kKnotScratch) * sizeof(double);
+  hipLaunchKernelGGL(k_halo_nodes, dim3((kNodeCount + 255) / 256 + 1, (unsigned)n, ng), dim3(256),
+                     sh, ctx->stream, ctx->cfg, L, ctx->d_epochs, ctx->d_tab, ctx->d_profile,
+                     ctx->d_hod, ctx->d_sici, ctx->d_nodes, ctx->d_tab, groups[0], groups[1],
+                     groups[2]);
+  if (groups[0] != 3)
+  hipLaunchKernelGGL(k_halo_knots, dim3(L.NK, (unsigned)n, ng), dim3(256), sh, ctx->stream,
                      ctx->cfg, L, ctx->d_epochs, ctx->d_tab, ctx->d_profile, ctx->d_hod,
-                     ctx->d_sici, groups[0], groups[1], groups[2], fam);
+                     ctx->d_sici, ctx->d_nodes, groups[0], groups[1], groups[2], fam);
+  if (ctx->cfg.divmax > kNodeLevel && groups[0] != 3)
+    hipLaunchKernelGGL(k_halo_knots_deep, dim3(L.NK, (unsigned)n, ng), dim3(256), sh, ctx->stream,
+                       ctx->cfg, L, ctx->d_epochs, ctx->d_tab, ctx->d_profile, ctx->d_hod,
+                       ctx->d_sici, groups[0], groups[1], groups[2], fam);
   const size_t sh2 = (size_t)(16 * L.NK) * sizeof(double);
   hipLaunchKernelGGL(k_halo_finalize, dim3((unsigned)n), dim3(384), sh2, ctx->stream, ctx->cfg,
                      L, ctx->d_epochs, ctx->d_tab, ctx->d_profile, ctx->d_hod, fam);
@@ -433,7 +463,7 @@ int chomp_sigma_r(chomp_ctx* ctx, size_t epoch, const double* scale, size_t n, d
   HIPCHK(hipMemcpyAsync(ctx->d_stage_in, scale, n * sizeof(double), hipMemcpyHostToDevice,
                         ctx->stream));
   hipLaunchKernelGGL(k_sigma_r, dim3((unsigned)n), dim3(256), 0, ctx->stream, ctx->cfg,
-                     ctx->d_epochs, (int)epoch, ctx->d_stage_in, ctx->d_stage_out);
+                     ctx->d_epochs, (int)epoch, ctx->d_stage_in, ctx->d_snodes, ctx->d_stage_out);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out, ctx->d_stage_out, n * sizeof(double), hipMemcpyDeviceToHost,
                         ctx->stream));

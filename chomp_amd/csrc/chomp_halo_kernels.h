@@ -58,6 +58,20 @@ inline TabLayout make_layout(int NM, int NK) {
 // Families: index into off_knot / off_kpp.
 enum { F_HM = 0, F_PPMM = 1, F_HG = 2, F_PPGM = 3, F_PPGG = 4 };
 
+// Node tables of the halo integrals: every knot k of an epoch integrates over the
+// SAME ln(nu) nodes, so everything that does not depend on k (nu f(nu), b(nu), M(nu),
+// concentration, r_s, HOD moments) is tabulated once per (epoch, integration range)
+// on the level-kNodeLevel Romberg grid, stored level by level so a level's nodes are
+// contiguous.  Deeper levels fall back to direct evaluation.
+constexpr int kNodeLevel = 10;
+constexpr int kNodeCount = (1 << kNodeLevel) + 1;
+constexpr int kNodeFields = 7;   // wA, wB, ln_rs, con, ln_cp, inv_mass_k, flag
+constexpr int kNodeStride = kNodeFields * kNodeCount;   // doubles per (epoch, group)
+__host__ __device__ inline int node_index(int lev, long j) {
+  return lev == 0 ? (int)j : 1 + (1 << (lev - 1)) + (int)j;
+}
+
+constexpr int kKnotScratch = romberg_scratch<4, 2>();   // LDS doubles of a knot block
 constexpr int kSearchJ = 2048;        // candidates per walking direction
 constexpr int kEpochDoubles = (int)(sizeof(Epoch) / sizeof(double));
 static_assert(sizeof(Epoch) % sizeof(double) == 0, "Epoch must be 8-byte granular");
@@ -67,23 +81,105 @@ __device__ __forceinline__ void copy_doubles(double* dst, const double* src, int
   for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
 }
 
-// nu(M) = (delta_c / sigma(R(M)))^2, cosmology.py:662-699, with the whole block on
-// one Romberg integral.
+// sigma(R) node table.  For 14.0662/k_max < R < 0.1/k_min (0.14 < R < 100 Mpc/h at
+// the default limits) SingleEpoch.sigma_r integrates over the fixed range
+// [ln k_min, ln k_max] (cosmology.py:611-632), so every such integral of an epoch
+// visits the same ln k nodes: k_j and the R-independent factor
+// (k_j/H0)^(3+n) T(k_j)^2 of Delta^2 are tabulated once per epoch on the
+// level-kSigmaLevel Romberg grid (level-major order) by k_sigma_nodes.
+constexpr int kSigmaLevel = 13;
+constexpr int kSigmaCount = (1 << kSigmaLevel) + 1;
+constexpr int kSigmaStride = 2 * kSigmaCount;      // doubles per epoch: k[], d2[]
+
+// grid (ceil(kSigmaCount / 256), n_epoch), block 256.
+__global__ __launch_bounds__(256) void k_sigma_nodes(chomp_config cfg,
+                                                     const chomp_cosmo* __restrict__ cosmo,
+                                                     const double* __restrict__ zin,
+                                                     double* __restrict__ snodes) {
+  __shared__ Epoch E;
+  const int e = blockIdx.y;
+  if (threadIdx.x == 0) {
+    const chomp_cosmo c = cosmo[e];
+    E.om0 = c.omega_m0; E.ob0 = c.omega_b0; E.ol0 = c.omega_l0; E.or0 = c.omega_r0;
+    E.tcmb = c.cmb_temp; E.h = c.h; E.sigma8 = c.sigma_8; E.ns = c.n_scalar;
+    E.z = zin[e];
+    epoch_background(E, cfg.cosmo_precision, cfg.k_min, cfg.k_max);
+  }
+  __syncthreads();
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= kSigmaCount) return;
+  const double a = log(cfg.k_min), b = log(cfg.k_max);
+  double x;
+  if (idx < 2) {
+    x = idx == 0 ? a : b;
+  } else {
+    const int m = idx - 1;
+    const int lev = 32 - __builtin_clz((unsigned)m);
+    const long j = m - (1 << (lev - 1));
+    const double h = (b - a) / (double)(1L << (lev - 1));
+    x = (a + 0.5 * h) + h * (double)j;
+  }
+  const double k = exp(x);
+  const double T = eh_transfer(E, k);
+  double* n = snodes + (size_t)e * kSigmaStride;
+  n[idx] = k;
+  n[kSigmaCount + idx] = exp((3.0 + E.ns) * (x - E.ln_H0)) * T * T;
+}
+
+// Delta^2(k) W(kR)^2 / (amp sigma_norm^2) from the table (levels <= kSigmaLevel),
+// direct evaluation beyond.
+struct SigmaTabIntegrand {
+  const Epoch* e;
+  const double* node;      // this epoch's table
+  double scale, inv_amp;
+  __device__ __forceinline__ void operator()(double ln_k, double (&out)[1], int lev,
+                                             long j) const {
+    if (lev <= kSigmaLevel) {
+      const int idx = node_index(lev, j);
+      const double kR = scale * node[idx];
+      double s, c;
+      sincos(kR, &s, &c);
+      const double W = 3.0 * (s - kR * c) / (kR * kR * kR);
+      out[0] = node[kSigmaCount + idx] * W * W;
+    } else {
+      SigmaIntegrand f{e, scale};
+      out[0] = f(ln_k) * inv_amp;
+    }
+  }
+};
+
+// sigma^2(R) = int dlnk Delta^2 W^2 (cosmology.py:602-642) with the whole group on
+// one Romberg integral; `rtol` is cosmo_precision for reference-exact values.
 template <int NW>
-__device__ __forceinline__ double nu_of_mass_block(const Epoch& E, double mass,
-                                                   const chomp_config& cfg, double* red) {
-  const double R = scale_of_mass(E, mass);
+__device__ __forceinline__ double sigma2_block(const Epoch& E, const double* snode, double R,
+                                               const chomp_config& cfg, double rtol,
+                                               double* red) {
   double lo, hi;
   sigma_limits(E, R, &lo, &hi);
+  const double need_min = 1.0 / R / 10.0, need_max = 1.0 / R * 14.0662;
+  const double amp2 = E.amp * E.sigma_norm * E.sigma_norm;
+  if (need_min > E.k_min && need_max < E.k_max) {          // fixed range: table path
+    SigmaTabIntegrand f{&E, snode, R, 1.0 / amp2};
+    const RombergOut<1> r = romberg_group<NW, 1>(f, lo, hi, cfg.global_precision, rtol,
+                                                 cfg.divmax, red);
+    return amp2 * r.value[0];
+  }
   SigmaIntegrand f{&E, R};
-  const double s2 = romberg1<NW>(f, lo, hi, cfg.global_precision, cfg.cosmo_precision,
-                                 cfg.divmax, red);
+  return romberg1<NW>(f, lo, hi, cfg.global_precision, rtol, cfg.divmax, red);
+}
+
+// nu(M) = (delta_c / sigma(R(M)))^2, cosmology.py:662-699.
+template <int NW>
+__device__ __forceinline__ double nu_of_mass_block(const Epoch& E, const double* snode,
+                                                   double mass, const chomp_config& cfg,
+                                                   double rtol, double* red) {
+  const double s2 = sigma2_block<NW>(E, snode, scale_of_mass(E, mass), cfg, rtol, red);
   const double sq = E.delta_c / sqrt(s2);
   return sq * sq;
 }
 
 // ---------------------------------------------------------------------------
-// k_epoch_init: grid (n_epoch, 2), block 1024.  blockIdx.y = side of the mass
+// k_epoch_init: grid (n_epoch, 2), block 64 * kInitNW.  blockIdx.y = side of the mass
 // range being searched (0: mass_min, 1: mass_max).
 //
 // The reference walks mass_min (from 1e9) and mass_max (from 1e16) in 5 % steps
@@ -94,11 +190,13 @@ __device__ __forceinline__ double nu_of_mass_block(const Epoch& E, double mass,
 // bracketing secant search on ln nu (4-6 sigma integrals), every integral spread
 // over the block's 16 wavefronts.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_epoch_init(
+constexpr int kInitNW = 8;       // wavefronts per k_epoch_init block
+__global__ __launch_bounds__(64 * kInitNW) void k_epoch_init(
     chomp_config cfg, const chomp_cosmo* __restrict__ cosmo, const double* __restrict__ zin,
-    Epoch* __restrict__ epochs, double* __restrict__ search, const double* __restrict__ cand) {
+    Epoch* __restrict__ epochs, double* __restrict__ search, const double* __restrict__ cand,
+    const double* __restrict__ snodes) {
   __shared__ Epoch E;
-  __shared__ double red[32];
+  __shared__ double red[romberg_scratch<kInitNW, 1>()];
   const int e = blockIdx.x, side = blockIdx.y;
   if (threadIdx.x == 0) {
     double* p = reinterpret_cast<double*>(&E);
@@ -110,19 +208,16 @@ __global__ __launch_bounds__(1024) void k_epoch_init(
     epoch_background(E, cfg.cosmo_precision, cfg.k_min, cfg.k_max);
   }
   __syncthreads();
+  const double* snode = snodes + (size_t)e * kSigmaStride;
   {   // sigma_8 normalisation, cosmology.py:118-119
-    double lo, hi;
-    sigma_limits(E, 8.0, &lo, &hi);
-    SigmaIntegrand f{&E, 8.0};
-    const double s2 = romberg1<16>(f, lo, hi, cfg.global_precision, cfg.cosmo_precision,
-                                   cfg.divmax, red);
+    const double s2 = sigma2_block<kInitNW>(E, snode, 8.0, cfg, cfg.cosmo_precision, red);
     __syncthreads();
     if (threadIdx.x == 0) E.sigma_norm = E.sigma8 * E.growth / sqrt(s2);
     __syncthreads();
   }
   if (side == 0) {   // comoving distance, cosmology.py:106-110
     EIntegrand f{E.om0, E.ol0, E.or0, E.H0};
-    const double chi = romberg1<16>(f, 0.0, E.z, cfg.global_precision,
+    const double chi = romberg1<kInitNW>(f, 0.0, E.z, cfg.global_precision,
                                     cfg.cosmo_precision, cfg.divmax, red);
     __syncthreads();
     if (threadIdx.x == 0) E.chi = chi;
@@ -139,7 +234,18 @@ __global__ __launch_bounds__(1024) void k_epoch_init(
     //       [3] max-side divide; index 0 of each is the starting mass.
     const double* down = cand + (side == 0 ? 0 : 3) * kSearchJ;
     const double* up = cand + (side == 0 ? 1 : 2) * kSearchJ;
-    const double nu0 = nu_of_mass_block<16>(E, down[0], cfg, red);
+    // Probes use a looser Romberg tolerance; any probe that lands within kAmbiguous
+    // (in ln nu) of the band edge is redone at the reference's tolerance, so every
+    // comparison that decides the stopping step is either far from the edge or exact.
+    const double rtol_probe = 1e-6, kAmbiguous = 1e-3;
+    auto nu_at = [&](double m) {
+      double nu = nu_of_mass_block<kInitNW>(E, snode, m, cfg, rtol_probe, red);
+      const double edge = fmin(fabs(log(nu / thr_lo)), fabs(log(nu / thr_hi)));
+      if (edge < kAmbiguous && cfg.cosmo_precision < rtol_probe)
+        nu = nu_of_mass_block<kInitNW>(E, snode, m, cfg, cfg.cosmo_precision, red);
+      return nu;
+    };
+    const double nu0 = nu_at(down[0]);
     n_eval = 1;
     double mass = down[0];
     int dir = 0;
@@ -167,7 +273,7 @@ __global__ __launch_bounds__(1024) void k_epoch_init(
           if (want > (double)(jh - jl - 1)) want = (double)(jh - jl - 1);
           jp = jl + (int)want;
         }
-        const double nu = nu_of_mass_block<16>(E, tab[jp], cfg, red);
+        const double nu = nu_at(tab[jp]);
         ++n_eval;
         const bool pred = dir < 0 ? !(thr < nu) : !(thr > nu);
         const double tp = dir < 0 ? log(nu / thr) : log(thr / nu);
@@ -206,16 +312,18 @@ __global__ __launch_bounds__(1024) void k_epoch_init(
 __global__ __launch_bounds__(256) void k_nu_table(chomp_config cfg, TabLayout L,
                                                   const Epoch* __restrict__ epochs,
                                                   const double* __restrict__ search,
+                                                  const double* __restrict__ snodes,
                                                   double* __restrict__ tab) {
   __shared__ Epoch E;
-  __shared__ double red[8];
+  __shared__ double red[romberg_scratch<4, 2>()];
   const int i = blockIdx.x, e = blockIdx.y;
   copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
                kEpochDoubles);
   __syncthreads();
   const double ln_lo = search[(e * 2 + 0) * 2], ln_hi = search[(e * 2 + 1) * 2];
   const double lnm = linspace_at(ln_lo, ln_hi, L.NM, i);
-  const double nu = nu_of_mass_block<4>(E, exp(lnm), cfg, red);
+  const double nu = nu_of_mass_block<4>(E, snodes + (size_t)e * kSigmaStride, exp(lnm), cfg,
+                                        cfg.cosmo_precision, red);
   if (threadIdx.x == 0) {
     double* t = tab + (size_t)e * L.stride;
     t[L.off_ln_mass + i] = lnm;
@@ -421,14 +529,188 @@ __device__ __forceinline__ void apply_halo_hod(Epoch& E, const chomp_halo_par& h
   E.ln_nu_lo_second = log(nu2);
 }
 
+// Lower limit of group g's integrals: 0: nu_min; 1: nu(first_moment_zero); 2:
+// nu(second_moment_zero) (halo.py:909-911, 935-939, 1002-1006).
+__device__ __forceinline__ double group_lower(const Epoch& E, int group) {
+  return group == 0 ? log(E.nu_min) : (group == 1 ? E.ln_nu_lo_first : E.ln_nu_lo_second);
+}
+
+// Stage what every halo-integral block needs into LDS and derive the epoch's
+// halo/HOD constants there (all threads call; ends with a barrier).
+struct HaloLds {
+  double *nu_knots, *lnm_pp, *nu_pp, *rest;
+  __device__ __forceinline__ void stage(const TabLayout& L, Epoch& E, SiCiTab& S,
+                                        const Epoch* epochs, int e, const double* t,
+                                        const chomp_halo_par* profile, const HodDev* hod,
+                                        const SiCiTab* sici_g, double* sm) {
+    const int NM = L.NM;
+    nu_knots = sm;
+    lnm_pp = nu_knots + NM;
+    nu_pp = lnm_pp + 4 * (NM - 1);
+    rest = nu_pp + 4 * (NM - 1);
+    copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
+                 kEpochDoubles);
+    copy_doubles(reinterpret_cast<double*>(&S), reinterpret_cast<const double*>(sici_g),
+                 (int)(sizeof(SiCiTab) / sizeof(double)));
+    copy_doubles(nu_knots, t + L.off_nu, NM);
+    copy_doubles(lnm_pp, t + L.off_lnm_pp, 4 * (NM - 1));
+    copy_doubles(nu_pp, t + L.off_nu_pp, 4 * (NM - 1));
+    __syncthreads();
+    if (threadIdx.x == 0) apply_halo_hod(E, profile[e], hod[e], nu_pp, t[L.off_ln_mass], NM);
+    __syncthreads();
+  }
+};
+
 // ---------------------------------------------------------------------------
-// k_halo_knots: grid (NK + 1, n_epoch, n_groups), block 256 (4 wavefronts per
-// integral pair).  blockIdx.x < NK: knot ln k_i of group groups[blockIdx.z]
-// (0: h_m + pp_mm, 1: h_g + pp_gm, 2: pp_gg).  blockIdx.x == NK, blockIdx.z == 0:
-// the n_bar integral of the epoch.  The epoch array is read-only here; the halo/
-// HOD constants each block derives in LDS are written back by k_halo_finalize.
+// k_halo_nodes: grid (ceil(kNodeCount / 256) + 1, n_epoch, n_groups), block 256: one
+// node of the (epoch, group) table per thread; the extra x-block of z == 0 does the
+// epoch's n_bar integral (halo.py:674-700).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_halo_nodes(
+    chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs,
+    const double* __restrict__ tab, const chomp_halo_par* __restrict__ profile,
+    const HodDev* __restrict__ hod, const SiCiTab* __restrict__ sici_g,
+    double* __restrict__ nodes, double* __restrict__ tab_out, int g0, int g1, int g2) {
+  extern __shared__ __align__(16) double sm[];
+  __shared__ Epoch E;
+  __shared__ SiCiTab S;
+  const int e = blockIdx.y;
+  const int group = blockIdx.z == 0 ? g0 : (blockIdx.z == 1 ? g1 : g2);
+  const bool nbar_block = blockIdx.x == gridDim.x - 1;
+  if (nbar_block && blockIdx.z != 0) return;
+  if (!nbar_block && (group < 0 || group > 2)) return;
+  HaloLds H;
+  H.stage(L, E, S, epochs, e, tab + (size_t)e * L.stride, profile, hod, sici_g, sm);
+  if (nbar_block) {
+    HaloCtx c{&E, &S, H.nu_knots, H.lnm_pp, L.NM, 0.0};
+    IntegrandNbar f{c};
+    const double v = romberg1<4>(f, E.ln_nu_lo_first, log(E.nu_max), cfg.global_precision,
+                                 cfg.halo_precision, cfg.divmax, H.rest);
+    if (threadIdx.x == 0) tab_out[(size_t)e * L.stride + L.off_misc] = v;
+    return;
+  }
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= kNodeCount) return;
+  const double a = group_lower(E, group), b = log(E.nu_max);
+  double x;
+  if (idx < 2) {
+    x = idx == 0 ? a : b;
+  } else {
+    const int m = idx - 1;
+    const int lev = 32 - __builtin_clz((unsigned)m);      // floor(log2 m) + 1
+    const long j = m - (1 << (lev - 1));
+    const double h = (b - a) / (double)(1L << (lev - 1));
+    x = (a + 0.5 * h) + h * (double)j;
+  }
+  const double nu = exp(x);
+  const double lnm = spline_eval(H.nu_knots, H.lnm_pp, L.NM, nu);
+  const double mass = exp(lnm);
+  const double nf = nu * f_nu(E, nu);
+  const double ln_c = E.ln_c_const + E.beta * lnm;
+  const double ln_rv = (E.ln_rv_const + lnm) * (1.0 / 3.0);
+  const double con = exp(ln_c);
+  const double cp = 1.0 + con;
+  const double ln_cp = log(cp);
+  double wA, wB, flag = 0.0;
+  if (group == 0) {
+    wA = nf * bias_nu(E, nu);
+    wB = nf * mass;
+  } else if (group == 1) {
+    const double n1 = zheng_first(E, mass);
+    wA = nf * bias_nu(E, nu) * n1 / mass;
+    wB = nf * n1;
+    flag = n1 < 1.0 ? 1.0 : 0.0;
+  } else {
+    const double n2 = zheng_second(E, mass);
+    wA = 0.0;
+    wB = nf * n2 / mass;
+    flag = n2 < 1.0 ? 1.0 : 0.0;
+  }
+  double* n = nodes + ((size_t)e * 3 + group) * kNodeStride + idx;
+  n[0 * kNodeCount] = wA;
+  n[1 * kNodeCount] = wB;
+  n[2 * kNodeCount] = ln_rv - ln_c;
+  n[3 * kNodeCount] = con;
+  n[4 * kNodeCount] = ln_cp;
+  n[5 * kNodeCount] = 1.0 / (ln_cp - con / cp);
+  n[6 * kNodeCount] = flag;
+}
+
+// out[0] = wA y, out[1] = wB (flag ? y : y^2) from the node table; group 2 uses
+// only out[1].  Valid for levels <= kNodeLevel.
+struct NodeIntegrand {
+  const SiCiTab* sici;
+  const double* node;     // this (epoch, group)'s table
+  double ln_k;
+  __device__ __forceinline__ void operator()(double, double (&out)[2], int lev, long j) const {
+    const double* n = node + node_index(lev, j);
+    const double y = y_nfw_core(*sici, ln_k, n[2 * kNodeCount], n[3 * kNodeCount],
+                                n[4 * kNodeCount], n[5 * kNodeCount]);
+    out[0] = n[0] * y;
+    out[1] = n[kNodeCount] * (n[6 * kNodeCount] != 0.0 ? y : y * y);
+  }
+};
+
+__device__ __forceinline__ int group_fa(int group) { return group == 0 ? F_HM : F_HG; }
+__device__ __forceinline__ int group_fb(int group) {
+  return group == 0 ? F_PPMM : (group == 1 ? F_PPGM : F_PPGG);
+}
+constexpr double kPendingLevel = -1.0;   // levels-table marker: needs the deep pass
+
+// ---------------------------------------------------------------------------
+// k_halo_knots: grid (NK, n_epoch, n_groups), block 256 (4 wavefronts per integral
+// pair): knot ln k_i of group groups[blockIdx.z] (0: h_m + pp_mm, 1: h_g + pp_gm,
+// 2: pp_gg), Romberg levels <= kNodeLevel from the node table; integrals not
+// converged by then are marked for k_halo_knots_deep.  The epoch array is read-only
+// here; the halo/HOD constants each block derives in LDS are written back by
+// k_halo_finalize.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_halo_knots(
+    chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs,
+    double* __restrict__ tab, const chomp_halo_par* __restrict__ profile,
+    const HodDev* __restrict__ hod, const SiCiTab* __restrict__ sici_g,
+    const double* __restrict__ nodes, int g0, int g1, int g2, unsigned mask) {
+  extern __shared__ __align__(16) double sm[];
+  __shared__ Epoch E;
+  __shared__ SiCiTab S;
+  const int NK = L.NK;
+  const int ik = blockIdx.x, e = blockIdx.y;
+  const int group = blockIdx.z == 0 ? g0 : (blockIdx.z == 1 ? g1 : g2);
+  if (group < 0 || group > 2) return;
+  double* t = tab + (size_t)e * L.stride;
+  HaloLds H;
+  H.stage(L, E, S, epochs, e, t, profile, hod, sici_g, sm);
+  double* red = H.rest;                     // [kKnotScratch]
+  const double ln_nu_max = log(E.nu_max);
+  const double ln_k = linspace_at(log(cfg.k_min), log(cfg.k_max), NK, ik);   // halo.py:52-54
+  NodeIntegrand f{&S, nodes + ((size_t)e * 3 + group) * kNodeStride, ln_k};
+  const int dmax = cfg.divmax < kNodeLevel ? cfg.divmax : kNodeLevel;
+  const RombergOut<2> r = romberg_group<4, 2>(f, group_lower(E, group), ln_nu_max,
+                                              cfg.global_precision, cfg.halo_precision,
+                                              dmax, red);
+  if (threadIdx.x == 0) {
+    double* lev = t + L.off_levels;
+    const int fa = group_fa(group), fb = group_fb(group);
+    const bool more = cfg.divmax > kNodeLevel;
+    if (group != 2 && (mask & (1u << fa))) {
+      t[L.off_knot[fa] + ik] = r.value[0];
+      lev[fa * NK + ik] = (!r.converged[0] && more) ? kPendingLevel : (double)r.level[0];
+    }
+    if (mask & (1u << fb)) {
+      t[L.off_knot[fb] + ik] = r.value[1];
+      lev[fb * NK + ik] = (!r.converged[1] && more) ? kPendingLevel : (double)r.level[1];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_halo_knots_deep: same grid as k_halo_knots (without the n_bar column).  A block
+// whose knot is not marked pending exits at once; otherwise it redoes the Romberg
+// integral by direct evaluation up to divmax (the discontinuous HOD integrands run
+// to 2^18..2^20 nodes, halo.py:1038-1041, 1084-1086) and stores the pending
+// families.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_halo_knots_deep(
     chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs,
     double* __restrict__ tab, const chomp_halo_par* __restrict__ profile,
     const HodDev* __restrict__ hod, const SiCiTab* __restrict__ sici_g, int g0, int g1,
@@ -436,76 +718,46 @@ __global__ __launch_bounds__(256) void k_halo_knots(
   extern __shared__ __align__(16) double sm[];
   __shared__ Epoch E;
   __shared__ SiCiTab S;
-  const int NM = L.NM, NK = L.NK;
-  double* nu_knots = sm;                    // [NM]
-  double* lnm_pp = nu_knots + NM;           // [4(NM-1)]
-  double* nu_pp = lnm_pp + 4 * (NM - 1);    // [4(NM-1)]
-  double* red = nu_pp + 4 * (NM - 1);       // [8]
+  const int NK = L.NK;
   const int ik = blockIdx.x, e = blockIdx.y;
   const int group = blockIdx.z == 0 ? g0 : (blockIdx.z == 1 ? g1 : g2);
-  if (ik == NK && blockIdx.z != 0) return;
-  if (ik < NK && (group < 0 || group > 2)) return;
+  if (group < 0 || group > 2) return;
   double* t = tab + (size_t)e * L.stride;
-  copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
-               kEpochDoubles);
-  copy_doubles(reinterpret_cast<double*>(&S), reinterpret_cast<const double*>(sici_g),
-               (int)(sizeof(SiCiTab) / sizeof(double)));
-  copy_doubles(nu_knots, t + L.off_nu, NM);
-  copy_doubles(lnm_pp, t + L.off_lnm_pp, 4 * (NM - 1));
-  copy_doubles(nu_pp, t + L.off_nu_pp, 4 * (NM - 1));
-  __syncthreads();
-  if (threadIdx.x == 0) apply_halo_hod(E, profile[e], hod[e], nu_pp, t[L.off_ln_mass], NM);
-  __syncthreads();
-  const double ln_nu_max = log(E.nu_max);
-  HaloCtx c{&E, &S, nu_knots, lnm_pp, NM, 0.0};
-  if (ik == NK) {
-    IntegrandNbar f{c};
-    const double v = romberg1<4>(f, E.ln_nu_lo_first, ln_nu_max, cfg.global_precision,
-                                 cfg.halo_precision, cfg.divmax, red);
-    if (threadIdx.x == 0) t[L.off_misc] = v;
-    return;
-  }
-  c.ln_k = linspace_at(log(cfg.k_min), log(cfg.k_max), NK, ik);     // halo.py:52-54
   double* lev = t + L.off_levels;
+  const int fa = group_fa(group), fb = group_fb(group);
+  const bool pa = group != 2 && (mask & (1u << fa)) && lev[fa * NK + ik] == kPendingLevel;
+  const bool pb = (mask & (1u << fb)) && lev[fb * NK + ik] == kPendingLevel;
+  if (!pa && !pb) return;
+  HaloLds H;
+  H.stage(L, E, S, epochs, e, t, profile, hod, sici_g, sm);
+  double* red = H.rest;
+  const double ln_nu_max = log(E.nu_max);
+  HaloCtx c{&E, &S, H.nu_knots, H.lnm_pp, L.NM,
+            linspace_at(log(cfg.k_min), log(cfg.k_max), NK, ik)};
+  double va = 0.0, vb = 0.0;
+  int la = 0, lb = 0;
   if (group == 0) {
     IntegrandMM f{c};
-    const RombergOut<2> r = romberg_group<4, 2>(f, log(E.nu_min), ln_nu_max,
+    const RombergOut<2> r = romberg_group<4, 2>(f, group_lower(E, 0), ln_nu_max,
                                                 cfg.global_precision, cfg.halo_precision,
                                                 cfg.divmax, red);
-    if (threadIdx.x == 0) {
-      if (mask & (1u << F_HM)) {
-        t[L.off_knot[F_HM] + ik] = r.value[0];
-        lev[F_HM * NK + ik] = (double)r.level[0];
-      }
-      if (mask & (1u << F_PPMM)) {
-        t[L.off_knot[F_PPMM] + ik] = r.value[1];
-        lev[F_PPMM * NK + ik] = (double)r.level[1];
-      }
-    }
+    va = r.value[0]; vb = r.value[1]; la = r.level[0]; lb = r.level[1];
   } else if (group == 1) {
     IntegrandGM f{c};
-    const RombergOut<2> r = romberg_group<4, 2>(f, E.ln_nu_lo_first, ln_nu_max,
+    const RombergOut<2> r = romberg_group<4, 2>(f, group_lower(E, 1), ln_nu_max,
                                                 cfg.global_precision, cfg.halo_precision,
                                                 cfg.divmax, red);
-    if (threadIdx.x == 0) {
-      if (mask & (1u << F_HG)) {
-        t[L.off_knot[F_HG] + ik] = r.value[0];
-        lev[F_HG * NK + ik] = (double)r.level[0];
-      }
-      if (mask & (1u << F_PPGM)) {
-        t[L.off_knot[F_PPGM] + ik] = r.value[1];
-        lev[F_PPGM * NK + ik] = (double)r.level[1];
-      }
-    }
+    va = r.value[0]; vb = r.value[1]; la = r.level[0]; lb = r.level[1];
   } else {
     IntegrandGG f{c};
-    const RombergOut<1> r = romberg_group<4, 1>(f, E.ln_nu_lo_second, ln_nu_max,
+    const RombergOut<1> r = romberg_group<4, 1>(f, group_lower(E, 2), ln_nu_max,
                                                 cfg.global_precision, cfg.halo_precision,
                                                 cfg.divmax, red);
-    if (threadIdx.x == 0) {
-      t[L.off_knot[F_PPGG] + ik] = r.value[0];
-      lev[F_PPGG * NK + ik] = (double)r.level[0];
-    }
+    vb = r.value[0]; lb = r.level[0];
+  }
+  if (threadIdx.x == 0) {
+    if (pa) { t[L.off_knot[fa] + ik] = va; lev[fa * NK + ik] = (double)la; }
+    if (pb) { t[L.off_knot[fb] + ik] = vb; lev[fb * NK + ik] = (double)lb; }
   }
 }
 
@@ -672,18 +924,15 @@ __global__ __launch_bounds__(256) void k_power(chomp_config cfg, TabLayout L,
 __global__ __launch_bounds__(256) void k_sigma_r(chomp_config cfg,
                                                  const Epoch* __restrict__ epochs, int e,
                                                  const double* __restrict__ scale,
+                                                 const double* __restrict__ snodes,
                                                  double* __restrict__ out) {
   __shared__ Epoch E;
-  __shared__ double red[8];
+  __shared__ double red[romberg_scratch<4, 2>()];
   copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
                kEpochDoubles);
   __syncthreads();
-  const double R = scale[blockIdx.x];
-  double lo, hi;
-  sigma_limits(E, R, &lo, &hi);
-  SigmaIntegrand f{&E, R};
-  const double s2 = romberg1<4>(f, lo, hi, cfg.global_precision, cfg.cosmo_precision,
-                                cfg.divmax, red);
+  const double s2 = sigma2_block<4>(E, snodes + (size_t)e * kSigmaStride, scale[blockIdx.x], cfg,
+                                    cfg.cosmo_precision, red);
   if (threadIdx.x == 0) out[blockIdx.x] = sqrt(s2);
 }
 

@@ -15,6 +15,9 @@
 #define CHOMP_HD inline
 #endif
 
+#if defined(__HIPCC__)
+#define CHOMP_DEVICE_CONST __device__ const
+#endif
 #include "special_tables.h"
 
 namespace chomp {
@@ -92,6 +95,32 @@ CHOMP_HD void sici_sc(double x, double s, double c, const SiCiTab& T, double* si
     }
     *si = x * ps;
     *ci = CHOMP_EULER_GAMMA + log(x) + x2 * pc;
+  } else {
+    const double u = 4.0 / x;
+    int j = (int)(8.0 * u);
+    j = j > 7 ? 7 : j;
+    const double t = 16.0 * u - (double)(2 * j + 1);
+    const double F = cheb_eval<CHOMP_FG_NCOEF>(T.f[j], t);
+    const double G = cheb_eval<CHOMP_FG_NCOEF>(T.g[j], t);
+    const double f = F / x, g = G / (x * x);
+    *si = kHalfPi - f * c - g * s;
+    *ci = f * s - g * c;
+  }
+}
+
+// Same with ln x supplied by the caller (saves the log in the series branch).
+CHOMP_HD void sici_sc_ln(double x, double ln_x, double s, double c, const SiCiTab& T,
+                         double* si, double* ci) {
+  if (x < 4.0) {
+    const double x2 = x * x;
+    double ps = T.si_ser[CHOMP_SICI_NSER - 1], pc = T.ci_ser[CHOMP_SICI_NSER - 1];
+#pragma unroll
+    for (int k = CHOMP_SICI_NSER - 2; k >= 0; --k) {
+      ps = fma(ps, x2, T.si_ser[k]);
+      pc = fma(pc, x2, T.ci_ser[k]);
+    }
+    *si = x * ps;
+    *ci = CHOMP_EULER_GAMMA + ln_x + x2 * pc;
   } else {
     const double u = 4.0 / x;
     int j = (int)(8.0 * u);
@@ -584,6 +613,30 @@ CHOMP_HD double y_nfw(const Epoch& e, const SiCiTab& T, double ln_k, double ln_m
   const double rho_km = cz_c * (ci_cz - ci_z) + sz * (si_cz - si_z) - scz / (cp * z);
   const double mass_k = log(cp) - con / cp;
   return rho_km / mass_k;
+}
+
+// The k-dependent core of y_nfw for a halo whose concentration con, ln(1+con),
+// ln r_s and 1/(ln(1+c) - c/(1+c)) are already known (per-node tables).
+CHOMP_HD double y_nfw_core(const SiCiTab& T, double ln_k, double ln_rs, double con,
+                           double ln_cp, double inv_mass_k) {
+  const double ln_z = ln_k + ln_rs;
+  const double z = exp(ln_z);
+  const double cp = 1.0 + con;
+  const double cz = con * z;
+  double sz, cz_c, scz, ccz;
+#if defined(__HIP_DEVICE_COMPILE__)
+  sincos(z, &sz, &cz_c);
+  sincos(cz, &scz, &ccz);
+#else
+  sz = sin(z); cz_c = cos(z); scz = sin(cz); ccz = cos(cz);
+#endif
+  const double s_cp = sz * ccz + cz_c * scz;
+  const double c_cp = cz_c * ccz - sz * scz;
+  double si_z, ci_z, si_cz, ci_cz;
+  sici_sc_ln(z, ln_z, sz, cz_c, T, &si_z, &ci_z);
+  sici_sc_ln(cp * z, ln_z + ln_cp, s_cp, c_cp, T, &si_cz, &ci_cz);
+  const double rho_km = cz_c * (ci_cz - ci_z) + sz * (si_cz - si_z) - scz / (cp * z);
+  return rho_km * inv_mass_k;
 }
 
 // Halo constants from the profile halo_dict (halo.py:71-83, 873-902).

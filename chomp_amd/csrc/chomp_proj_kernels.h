@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void k_halofit_sigma(chomp_config cfg, TabLayo
                                                        const Epoch* __restrict__ epochs,
                                                        int e, double* __restrict__ tab) {
   __shared__ Epoch E;
-  __shared__ double red[8];
+  __shared__ double red[romberg_scratch<4, 2>()];
   copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
                kEpochDoubles);
   __syncthreads();
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void k_proj_kernel_knots(chomp_config cfg, Pro
   extern __shared__ __align__(16) double sm[];
   __shared__ ProjDev pd;
   __shared__ BesselTab B;
-  __shared__ double red[8];
+  __shared__ double red[romberg_scratch<4, 2>()];
   copy_doubles(reinterpret_cast<double*>(&pd), reinterpret_cast<const double*>(pdg), kProjDoubles);
   copy_doubles(reinterpret_cast<double*>(&B), reinterpret_cast<const double*>(bess_g),
                (int)(sizeof(BesselTab) / sizeof(double)));
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256) void k_wtheta(chomp_config cfg, TabLayout HL, 
                                                 double* __restrict__ out) {
   extern __shared__ __align__(16) double sm[];
   __shared__ Epoch E;
-  __shared__ double red[8];
+  __shared__ double red[romberg_scratch<4, 2>()];
   copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
                kEpochDoubles);
   PowerEval P;
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) void k_cell(chomp_config cfg, TabLayout HL, Pr
   extern __shared__ __align__(16) double sm[];
   __shared__ Epoch E;
   __shared__ ProjDev pd;
-  __shared__ double red[8];
+  __shared__ double red[romberg_scratch<4, 2>()];
   copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
                kEpochDoubles);
   copy_doubles(reinterpret_cast<double*>(&pd), reinterpret_cast<const double*>(pdg), kProjDoubles);

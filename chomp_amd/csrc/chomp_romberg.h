@@ -11,10 +11,14 @@
 //     wavefronts; the 2^(i-1) new mid-points of level i are strided over the
 //     64*NW lanes, partial sums reduced with __shfl_xor butterflies (+ one LDS
 //     exchange when NW > 1);
-//   * the Richardson row lives one entry per lane (lane k holds R[i][k]), so the
-//     extrapolation is 2 register values per lane instead of a 21-entry array;
+//   * lane m holds the trapezoid estimate T_m and the extrapolated value of row i is
+//     the weighted sum R[i][i] = sum_m C[i][m] T_m (weights = the Richardson
+//     recurrence unrolled once, exactly, in tools/gen_special_tables.py): one
+//     multiply and one butterfly per row instead of an i-step dependent chain;
 //   * every lane of the group ends up with the same sums, so the stopping test
-//     is wave-uniform and needs no broadcast.
+//     is wave-uniform and needs no broadcast;
+//   * for multi-wavefront groups the first round evaluates the whole level-L0 grid
+//     (one node per thread) instead of walking levels 0..L0 with mostly idle lanes.
 //
 // Nodes follow SciPy's formula lox + h*j with h = (b-a)/2^(i-1), lox = a + h/2.
 #pragma once
@@ -50,13 +54,44 @@ __device__ __forceinline__ double group_sum(double v, double* red, int& flip) {
   }
 }
 
+constexpr int kMaxDivmax = 30;   // chomp_ctx_create enforces divmax <= 30
+
 template <int NF>
 struct RombergOut {
   double value[NF];
   int level[NF];
+  bool converged[NF];   // false: divmax exhausted (SciPy would warn and return value)
 };
 
+// LDS doubles a group needs: 2*NW for the sum exchange + NF*(32 NW + 1) for the
+// values of the fused first round (NW > 1 only).
+template <int NW, int NF>
+constexpr int romberg_scratch() {
+  return NW == 1 ? 1 : 2 * NW + NF * (32 * NW + 1);
+}
+
+namespace detail {
+// Integrands may take the node's (level, index-within-level) besides x, so that
+// table-driven integrands can look their node up; plain ones take (x, out).
+template <class F, int NF>
+__device__ __forceinline__ auto call_f(const F& f, double x, double (&o)[NF], int lev, long j,
+                                       int) -> decltype(f(x, o, lev, j), void()) {
+  f(x, o, lev, j);
+}
+template <class F, int NF>
+__device__ __forceinline__ void call_f(const F& f, double x, double (&o)[NF], int, long, long) {
+  f(x, o);
+}
+}  // namespace detail
+
 // F: void operator()(double x, double (&out)[NF]) const
+//    or void operator()(double x, double (&out)[NF], int level, long j) const
+// where the node is the j-th new point of `level` (level 0: j = 0 -> a, 1 -> b).
+//
+// NW > 1: the first round evaluates the whole level-L0 grid (2^L0 + 1 = 32 NW + 1
+// points, one per thread) at once; the Romberg rows 0..L0 and their stopping tests
+// are then replayed from the per-level sums, so an integral that the reference
+// stops at level <= L0 still returns exactly that level's value.
 template <int NW, int NF, class F>
 __device__ __forceinline__ RombergOut<NF> romberg_group(const F& f, double a, double b,
                                                         double tol, double rtol,
@@ -64,34 +99,122 @@ __device__ __forceinline__ RombergOut<NF> romberg_group(const F& f, double a, do
   constexpr int NT = 64 * NW;
   const int lane = threadIdx.x & 63;
   const int gt = (NW == 1) ? lane : (int)threadIdx.x;
+  const int cl = lane & 31;                      // column of the weight table
   int flip = 0;
   const double intrange = b - a;
 
-  double ordsum[NF], last[NF], result[NF];
+  // Lane m (< 32) holds the trapezoid estimate T_m; the Romberg value of row i is
+  // R[i][i] = sum_m C[i][m] T_m (CHOMP_ROMBERG_C: the Richardson recurrence unrolled
+  // on coefficient vectors), one multiply and one wavefront butterfly per row instead
+  // of an i-step dependent chain.
+  double ordsum[NF], Tl[NF], prev[NF];
   bool done[NF];
   RombergOut<NF> out;
+  bool all_done = false;
 
-  // T_0: the two end points (lanes 0 and 1 of the group)
-  {
+  auto advance = [&](int q, int i, double S, double n, double c_il) {
+    ordsum[q] += S;
+    const double Ti = intrange * ordsum[q] / n;          // R[i][0]
+    if (lane == i) Tl[q] = Ti;
+    const double cur = wave_sum(lane < 32 ? c_il * Tl[q] : 0.0);
+    const double err = fabs(cur - prev[q]);
+    prev[q] = cur;
+    out.value[q] = cur;
+    out.level[q] = i;
+    if (err < tol || err < rtol * fabs(cur)) done[q] = true;
+  };
+
+  int i0;   // first level handled by the generic loop
+  if constexpr (NW == 1) {
+    // T_0: the two end points (lanes 0 and 1)
     double v[NF];
 #pragma unroll
     for (int q = 0; q < NF; ++q) v[q] = 0.0;
-    if (gt < 2) f(gt == 0 ? a : b, v);
+    if (gt < 2) detail::call_f<F, NF>(f, gt == 0 ? a : b, v, 0, (long)gt, 0);
 #pragma unroll
     for (int q = 0; q < NF; ++q) {
       ordsum[q] = 0.5 * group_sum<NW>(v[q], red, flip);
-      result[q] = intrange * ordsum[q];
-      last[q] = (lane == 0) ? result[q] : 0.0;   // lane k holds R[i-1][k]
-      done[q] = false;
-      out.value[q] = result[q];
+      out.value[q] = intrange * ordsum[q];
       out.level[q] = 0;
+      prev[q] = out.value[q];
+      Tl[q] = (lane == 0) ? out.value[q] : 0.0;
+      done[q] = false;
     }
+    i0 = 1;
+  } else {
+    constexpr int L0max = (NW == 2) ? 6 : (NW == 4) ? 7 : (NW == 8) ? 8 : 9;
+    static_assert(NW == 2 || NW == 4 || NW == 8 || NW == 16, "NW must be 1,2,4,8,16");
+    const int L0 = divmax < L0max ? divmax : L0max;
+    const int N0 = 1 << L0;                              // intervals of the fused grid
+    double* fv = red + 2 * NW;                           // [NF][32 NW + 1]
+    constexpr int FS = 32 * NW + 1;
+    // weight rows 1..L0, fetched before the node evaluations hide their latency
+    double crow[L0max + 1];
+#pragma unroll
+    for (int i = 1; i <= L0max; ++i) crow[i] = CHOMP_ROMBERG_C[i][cl];
+    if (gt <= N0) {
+      double v[NF];
+      int lev;
+      long j;
+      double x;
+      if (gt == 0) { lev = 0; j = 0; x = a; }
+      else if (gt == N0) { lev = 0; j = 1; x = b; }
+      else {
+        const int tz = __builtin_ctz((unsigned)gt);
+        lev = L0 - tz;
+        j = (long)(((gt >> tz) - 1) >> 1);
+        const double h = intrange / (double)(1L << (lev - 1));
+        x = (a + 0.5 * h) + h * (double)j;
+      }
+      detail::call_f<F, NF>(f, x, v, lev, j, 0);
+#pragma unroll
+      for (int q = 0; q < NF; ++q) fv[q * FS + gt] = v[q];
+    }
+    __syncthreads();
+    // lane l of every wavefront sums level l (lane 0: the end points)
+    double Sl[NF];
+#pragma unroll
+    for (int q = 0; q < NF; ++q) {
+      Sl[q] = 0.0;
+      if (lane == 0) {
+        Sl[q] = 0.5 * (fv[q * FS] + fv[q * FS + N0]);
+      } else if (lane <= L0) {
+        const int stride = N0 >> (lane - 1);
+        for (int p = stride >> 1; p < N0; p += stride) Sl[q] += fv[q * FS + p];
+      }
+    }
+    __syncthreads();          // fv may be reused by a later call
+#pragma unroll
+    for (int q = 0; q < NF; ++q) {
+      ordsum[q] = __shfl(Sl[q], 0, 64);
+      out.value[q] = intrange * ordsum[q];
+      out.level[q] = 0;
+      prev[q] = out.value[q];
+      Tl[q] = (lane == 0) ? out.value[q] : 0.0;
+      done[q] = false;
+    }
+    double n = 1.0;
+#pragma unroll
+    for (int i = 1; i <= L0max; ++i) {
+      if (i <= L0 && !all_done) {
+        n *= 2.0;
+        all_done = true;
+#pragma unroll
+        for (int q = 0; q < NF; ++q) {
+          const double S = __shfl(Sl[q], i, 64);
+          if (!done[q]) advance(q, i, S, n, crow[i]);
+          all_done = all_done && done[q];
+        }
+      }
+    }
+    i0 = L0 + 1;
   }
 
-  long n = 1;
-  for (int i = 1; i <= divmax; ++i) {
-    n *= 2;
-    const long numtosum = n / 2;
+  double n = (double)(1L << (i0 - 1));
+  for (int i = i0; i <= divmax && !all_done; ++i) {
+    const double c_il = CHOMP_ROMBERG_C[i][cl];          // latency hidden by the nodes
+    n *= 2.0;
+    const long numtosum = 1L << (i - 1);
     const double h = intrange / (double)numtosum;
     const double lox = a + 0.5 * h;
     double part[NF];
@@ -99,36 +222,20 @@ __device__ __forceinline__ RombergOut<NF> romberg_group(const F& f, double a, do
     for (int q = 0; q < NF; ++q) part[q] = 0.0;
     for (long j = gt; j < numtosum; j += NT) {
       double v[NF];
-      f(lox + h * (double)j, v);
+      detail::call_f<F, NF>(f, lox + h * (double)j, v, i, j, 0);
 #pragma unroll
       for (int q = 0; q < NF; ++q) part[q] += v[q];
     }
-    bool all_done = true;
+    all_done = true;
 #pragma unroll
     for (int q = 0; q < NF; ++q) {
-      const double s = group_sum<NW>(part[q], red, flip);
-      if (done[q]) continue;
-      ordsum[q] += s;
-      double cur = intrange * ordsum[q] / (double)n;     // R[i][0]
-      double mine = (lane == 0) ? cur : 0.0;
-      double p4 = 1.0;
-      for (int k = 0; k < i; ++k) {                      // Richardson
-        p4 *= 4.0;
-        const double lastk = __shfl(last[q], k, 64);
-        cur = (p4 * cur - lastk) / (p4 - 1.0);
-        if (lane == k + 1) mine = cur;
-      }
-      const double lastresult = __shfl(last[q], i - 1, 64);
-      const double err = fabs(cur - lastresult);
-      result[q] = cur;
-      out.value[q] = cur;
-      out.level[q] = i;
-      if (err < tol || err < rtol * fabs(cur)) done[q] = true;
-      last[q] = mine;
+      const double S = group_sum<NW>(part[q], red, flip);
+      if (!done[q]) advance(q, i, S, n, c_il);
       all_done = all_done && done[q];
     }
-    if (all_done) break;
   }
+#pragma unroll
+  for (int q = 0; q < NF; ++q) out.converged[q] = done[q];
   return out;
 }
 

@@ -88,16 +88,26 @@ class HaloGrid(object):
         re-order to the caller's z order.  k: torch cuda tensor.  Returns the full
         [n_all, nk] tensor on every rank."""
         import torch
-        import torch.distributed as dist
         rpr = rows_per_rank(self.n_all, self.world)
-        nk = k.numel()
-        local = torch.zeros((rpr, nk), dtype=torch.float64, device=k.device)
+        local = torch.zeros((rpr, k.numel()), dtype=torch.float64, device=k.device)
         if len(self.idx):
             self.power(which, k, out=local[:len(self.idx)])
         self.ctx.sync()
-        if self.world == 1:
-            return local[:self.n_all]
-        full = torch.empty((self.world * rpr, nk), dtype=torch.float64, device=k.device)
-        dist.all_gather_into_tensor(full, local)
-        order = torch.as_tensor(unshard_order(self.n_all, self.world), device=k.device)
-        return full.index_select(0, order)
+        return gather_rows(local, self.n_all, self.world)
+
+
+def gather_rows(local, n_all, world):
+    """All-gather the per-rank row blocks ([rows_per_rank, nk], zero padded) and
+    put the rows back into epoch order.  RCCL on GPUs ("nccl" backend), gloo on CPU
+    tensors (used by the multi-process CPU tests)."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return local[:n_all]
+    rpr = rows_per_rank(n_all, world)
+    assert local.shape[0] == rpr
+    full = torch.empty((world * rpr, local.shape[1]), dtype=local.dtype,
+                       device=local.device)
+    dist.all_gather_into_tensor(full, local.contiguous())
+    order = torch.as_tensor(unshard_order(n_all, world), device=local.device)
+    return full.index_select(0, order)

@@ -1,7 +1,13 @@
-import sys; sys.path.insert(0,'.')
-import numpy as np
-from chomp_amd import halo, _lib
-g=np.load('tests/golden/g3_stages.npz')
-h=halo.Halo(0.0); ctx=h._sync(_lib.FAM_MM)
-x=ctx.table("ln_mass"); r=g['z000_ln_mass']
-d=x-r; print(np.nonzero(d)[0], d[np.nonzero(d)[0]][:5])
+import sys, time; sys.path.insert(0,'.')
+import numpy as np, torch
+from chomp_amd import grid, defaults
+def run(z, tag):
+    hg = grid.HaloGrid(np.array([z]))
+    hg.ctx.epochs_set(hg.cosmo, hg.z); hg.ctx.sync()
+    t0=time.perf_counter()
+    for _ in range(50): hg.ctx.epochs_set(hg.cosmo, hg.z)
+    hg.ctx.sync(); t1=time.perf_counter()
+    print(tag, z, "epochs_set %.1f us" % ((t1-t0)/50*1e6), int(hg.ctx.scalars(0)['n_search']))
+for z in (0.0, 1.5): run(z, "search ")
+defaults.default_limits["mass_min"]=1e9; defaults.default_limits["mass_max"]=1e16
+for z in (0.0, 1.5): run(z, "fixed  ")
