@@ -299,31 +299,46 @@ class Context(object):
         raise ChompError("%s (code %d)" % (msg, rc))
 
     # -- Stage K -------------------------------------------------------------
-    def epochs_set(self, cosmo_dicts, z):
-        z = numpy.ascontiguousarray(numpy.atleast_1d(z), dtype=numpy.float64)
-        n = z.size
+    # Each call takes either Python dictionaries / objects (converted here) or the
+    # ctypes arrays built once by pack_* (the batched path does that: converting 64
+    # dictionaries per step costs more host time than the kernels take).
+    @staticmethod
+    def pack_cosmo(cosmo_dicts, n):
         if isinstance(cosmo_dicts, dict):
             cosmo_dicts = [cosmo_dicts] * n
-        arr = (Cosmo * n)(*[cosmo_struct(c) for c in cosmo_dicts])
+        return (Cosmo * n)(*[cosmo_struct(c) for c in cosmo_dicts])
+
+    @staticmethod
+    def pack_halo(halo_dicts, n):
+        if isinstance(halo_dicts, dict):
+            halo_dicts = [halo_dicts] * n
+        return (HaloPar * n)(*[halo_struct(h) for h in halo_dicts])
+
+    @staticmethod
+    def pack_hod(hods, n):
+        if not isinstance(hods, (list, tuple)):
+            hods = [hods] * n
+        return (HodPar * n)(*[hod_struct(h) for h in hods])
+
+    def epochs_set(self, cosmo, z):
+        z = numpy.ascontiguousarray(numpy.atleast_1d(z), dtype=numpy.float64)
+        n = z.size
+        arr = cosmo if isinstance(cosmo, ctypes.Array) else self.pack_cosmo(cosmo, n)
+        assert len(arr) == n
         self._check(self._L.chomp_epochs_set(self._h, n, arr,
                                              z.ctypes.data_as(c_double_p)))
         self.n_epoch = n
 
-    def mass_setup(self, halo_dicts, mf_kind):
-        n = self.n_epoch
-        if isinstance(halo_dicts, dict):
-            halo_dicts = [halo_dicts] * n
-        arr = (HaloPar * n)(*[halo_struct(h) for h in halo_dicts])
+    def mass_setup(self, halo, mf_kind):
+        arr = halo if isinstance(halo, ctypes.Array) else self.pack_halo(halo, self.n_epoch)
+        assert len(arr) == self.n_epoch
         self._check(self._L.chomp_mass_setup(self._h, arr, int(mf_kind)))
 
-    def halo_setup(self, profile_dicts, hods, tables):
+    def halo_setup(self, profile, hods, tables):
         n = self.n_epoch
-        if isinstance(profile_dicts, dict):
-            profile_dicts = [profile_dicts] * n
-        if not isinstance(hods, (list, tuple)):
-            hods = [hods] * n
-        pa = (HaloPar * n)(*[halo_struct(h) for h in profile_dicts])
-        ha = (HodPar * n)(*[hod_struct(h) for h in hods])
+        pa = profile if isinstance(profile, ctypes.Array) else self.pack_halo(profile, n)
+        ha = hods if isinstance(hods, ctypes.Array) else self.pack_hod(hods, n)
+        assert len(pa) == n and len(ha) == n
         self._check(self._L.chomp_halo_setup(self._h, pa, ha, int(tables)))
 
     def halofit_setup(self, dst, src, f1, f2, f3, omega_l, w):

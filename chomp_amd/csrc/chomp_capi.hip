@@ -322,7 +322,7 @@ int chomp_mass_setup(chomp_ctx* ctx, const chomp_halo_par* par, int mf_kind) {
   if (rcu) return rcu;
   hipLaunchKernelGGL(k_nu_table, dim3(L.NM, (unsigned)n), dim3(256), 0, ctx->stream, ctx->cfg,
                      L, ctx->d_epochs, ctx->d_search, ctx->d_snodes, ctx->d_tab);
-  const size_t sh = (size_t)(2 * L.NM + 8 * (L.NM - 1) + 4 * L.NM + 32 + 8) * sizeof(double);
+  const size_t sh = (size_t)(2 * L.NM + 8 * (L.NM - 1) + 18 * L.NM + 32 + 8) * sizeof(double);
   hipLaunchKernelGGL(k_mass_setup, dim3((unsigned)n), dim3(256), sh, ctx->stream, ctx->cfg, L,
                      ctx->d_epochs, ctx->d_search, ctx->d_tab, ctx->d_mass_par, mf_kind,
                      ctx->d_tinker, ctx->d_gl16);
@@ -376,14 +376,14 @@ int chomp_halo_setup(chomp_ctx* ctx, const chomp_halo_par* profile,
                      ctx->d_hod, ctx->d_sici, ctx->d_nodes, ctx->d_tab, groups[0], groups[1],
                      groups[2]);
   if (groups[0] != 3)
-  hipLaunchKernelGGL(k_halo_knots, dim3(L.NK, (unsigned)n, ng), dim3(256), sh, ctx->stream,
-                     ctx->cfg, L, ctx->d_epochs, ctx->d_tab, ctx->d_profile, ctx->d_hod,
-                     ctx->d_sici, ctx->d_nodes, groups[0], groups[1], groups[2], fam);
+  hipLaunchKernelGGL(k_halo_knots, dim3(L.NK, (unsigned)n, ng), dim3(256), 0, ctx->stream,
+                     ctx->cfg, L, ctx->d_tab, ctx->d_sici, ctx->d_nodes, groups[0], groups[1],
+                     groups[2], fam);
   if (ctx->cfg.divmax > kNodeLevel && groups[0] != 3)
     hipLaunchKernelGGL(k_halo_knots_deep, dim3(L.NK, (unsigned)n, ng), dim3(256), sh, ctx->stream,
                        ctx->cfg, L, ctx->d_epochs, ctx->d_tab, ctx->d_profile, ctx->d_hod,
                        ctx->d_sici, groups[0], groups[1], groups[2], fam);
-  const size_t sh2 = (size_t)(16 * L.NK) * sizeof(double);
+  const size_t sh2 = (size_t)(51 * L.NK) * sizeof(double);
   hipLaunchKernelGGL(k_halo_finalize, dim3((unsigned)n), dim3(384), sh2, ctx->stream, ctx->cfg,
                      L, ctx->d_epochs, ctx->d_tab, ctx->d_profile, ctx->d_hod, fam);
   HIPCHK(hipGetLastError());

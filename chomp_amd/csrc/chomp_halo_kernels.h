@@ -66,7 +66,8 @@ enum { F_HM = 0, F_PPMM = 1, F_HG = 2, F_PPGM = 3, F_PPGG = 4 };
 constexpr int kNodeLevel = 10;
 constexpr int kNodeCount = (1 << kNodeLevel) + 1;
 constexpr int kNodeFields = 7;   // wA, wB, ln_rs, con, ln_cp, inv_mass_k, flag
-constexpr int kNodeStride = kNodeFields * kNodeCount;   // doubles per (epoch, group)
+constexpr int kNodeStride = kNodeFields * kNodeCount + 8;   // doubles per (epoch, group);
+                                                            // tail: integration limits a, b
 __host__ __device__ inline int node_index(int lev, long j) {
   return lev == 0 ? (int)j : 1 + (1 << (lev - 1)) + (int)j;
 }
@@ -166,6 +167,37 @@ __device__ __forceinline__ double sigma2_block(const Epoch& E, const double* sno
   }
   SigmaIntegrand f{&E, R};
   return romberg1<NW>(f, lo, hi, cfg.global_precision, rtol, cfg.divmax, red);
+}
+
+// Not-a-knot spline build by parallel cyclic reduction.  Every thread of the block
+// must call it (it contains barriers); the threads with 0 <= tid < tps of an
+// `active` caller work on one system, rows strided by tps, so several systems can
+// be built in lockstep by disjoint thread ranges.  w: 9 n doubles of LDS per system.
+__device__ __forceinline__ void spline_build_pcr(const double* x, const double* y, int n,
+                                                 double* c, double* w, int tid, int tps,
+                                                 bool active) {
+  double *a0 = w, *b0 = w + n, *c0 = w + 2 * n, *d0 = w + 3 * n;
+  double *a1 = w + 4 * n, *b1 = w + 5 * n, *c1 = w + 6 * n, *d1 = w + 7 * n;
+  double* sl = w + 8 * n;
+  if (active)
+    for (int i = tid; i < n; i += tps) spline_row(x, y, n, i, &a0[i], &b0[i], &c0[i], &d0[i]);
+  __syncthreads();
+  for (int s = 1; s < n; s *= 2) {
+    if (active)
+      for (int i = tid; i < n; i += tps) pcr_step(n, i, s, a0, b0, c0, d0, a1, b1, c1, d1);
+    __syncthreads();
+    double* t;
+    t = a0; a0 = a1; a1 = t;
+    t = b0; b0 = b1; b1 = t;
+    t = c0; c0 = c1; c1 = t;
+    t = d0; d0 = d1; d1 = t;
+  }
+  if (active)
+    for (int i = tid; i < n; i += tps) sl[i] = d0[i] / b0[i];
+  __syncthreads();
+  if (active)
+    for (int i = tid; i < n - 1; i += tps) spline_coef(x, y, sl, i, c);
+  __syncthreads();
 }
 
 // nu(M) = (delta_c / sigma(R(M)))^2, cosmology.py:662-699.
@@ -369,8 +401,8 @@ __global__ __launch_bounds__(256) void k_mass_setup(
   double* y_nu = x_lnm + NM;             // [NM]
   double* c_nu = y_nu + NM;              // [4(NM-1)]
   double* c_lnm = c_nu + 4 * (NM - 1);   // [4(NM-1)]
-  double* work = c_lnm + 4 * (NM - 1);   // [4NM]
-  double* gl = work + 4 * NM;            // [32]
+  double* work = c_lnm + 4 * (NM - 1);   // [18 NM]
+  double* gl = work + 18 * NM;           // [32]
   double* red = gl + 32;                 // [8]
   const int e = blockIdx.x;
   double* t = tab + (size_t)e * L.stride;
@@ -380,9 +412,11 @@ __global__ __launch_bounds__(256) void k_mass_setup(
   copy_doubles(y_nu, t + L.off_nu, NM);
   copy_doubles(gl, gl16, 32);
   __syncthreads();
-  if (threadIdx.x == 0) spline_build(x_lnm, y_nu, NM, c_nu, work);             // nu(ln M)
-  if (threadIdx.x == 64) spline_build(y_nu, x_lnm, NM, c_lnm, work + 2 * NM);  // ln M(nu)
-  __syncthreads();
+  {   // nu(ln M) on threads 0..127, ln M(nu) on threads 128..255, in lockstep
+    const int sys = threadIdx.x >> 7, tid = threadIdx.x & 127;
+    spline_build_pcr(sys == 0 ? x_lnm : y_nu, sys == 0 ? y_nu : x_lnm, NM,
+                     sys == 0 ? c_nu : c_lnm, work + sys * 9 * NM, tid, 128, true);
+  }
   if (threadIdx.x == 0) {
     const chomp_halo_par hp = par[e];
     E.ln_mass_min = search[(e * 2 + 0) * 2];
@@ -592,6 +626,11 @@ __global__ __launch_bounds__(256) void k_halo_nodes(
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= kNodeCount) return;
   const double a = group_lower(E, group), b = log(E.nu_max);
+  if (idx == 0) {
+    double* hdr = nodes + ((size_t)e * 3 + group) * kNodeStride + kNodeFields * kNodeCount;
+    hdr[0] = a;
+    hdr[1] = b;
+  }
   double x;
   if (idx < 2) {
     x = idx == 0 ? a : b;
@@ -661,33 +700,30 @@ constexpr double kPendingLevel = -1.0;   // levels-table marker: needs the deep 
 // k_halo_knots: grid (NK, n_epoch, n_groups), block 256 (4 wavefronts per integral
 // pair): knot ln k_i of group groups[blockIdx.z] (0: h_m + pp_mm, 1: h_g + pp_gm,
 // 2: pp_gg), Romberg levels <= kNodeLevel from the node table; integrals not
-// converged by then are marked for k_halo_knots_deep.  The epoch array is read-only
-// here; the halo/HOD constants each block derives in LDS are written back by
-// k_halo_finalize.
+// converged by then are marked for k_halo_knots_deep.  A block only stages the Si/Ci
+// tables: everything else it needs is in the (epoch, group) node table.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_halo_knots(
-    chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs,
-    double* __restrict__ tab, const chomp_halo_par* __restrict__ profile,
-    const HodDev* __restrict__ hod, const SiCiTab* __restrict__ sici_g,
-    const double* __restrict__ nodes, int g0, int g1, int g2, unsigned mask) {
-  extern __shared__ __align__(16) double sm[];
-  __shared__ Epoch E;
+    chomp_config cfg, TabLayout L, double* __restrict__ tab,
+    const SiCiTab* __restrict__ sici_g, const double* __restrict__ nodes, int g0, int g1,
+    int g2, unsigned mask) {
   __shared__ SiCiTab S;
+  __shared__ double red[kKnotScratch];
   const int NK = L.NK;
   const int ik = blockIdx.x, e = blockIdx.y;
   const int group = blockIdx.z == 0 ? g0 : (blockIdx.z == 1 ? g1 : g2);
   if (group < 0 || group > 2) return;
+  copy_doubles(reinterpret_cast<double*>(&S), reinterpret_cast<const double*>(sici_g),
+               (int)(sizeof(SiCiTab) / sizeof(double)));
+  const double* node = nodes + ((size_t)e * 3 + group) * kNodeStride;
+  const double a = node[kNodeFields * kNodeCount], b = node[kNodeFields * kNodeCount + 1];
+  __syncthreads();
   double* t = tab + (size_t)e * L.stride;
-  HaloLds H;
-  H.stage(L, E, S, epochs, e, t, profile, hod, sici_g, sm);
-  double* red = H.rest;                     // [kKnotScratch]
-  const double ln_nu_max = log(E.nu_max);
   const double ln_k = linspace_at(log(cfg.k_min), log(cfg.k_max), NK, ik);   // halo.py:52-54
-  NodeIntegrand f{&S, nodes + ((size_t)e * 3 + group) * kNodeStride, ln_k};
+  NodeIntegrand f{&S, node, ln_k};
   const int dmax = cfg.divmax < kNodeLevel ? cfg.divmax : kNodeLevel;
-  const RombergOut<2> r = romberg_group<4, 2>(f, group_lower(E, group), ln_nu_max,
-                                              cfg.global_precision, cfg.halo_precision,
-                                              dmax, red);
+  const RombergOut<2> r = romberg_group<4, 2>(f, a, b, cfg.global_precision,
+                                              cfg.halo_precision, dmax, red);
   if (threadIdx.x == 0) {
     double* lev = t + L.off_levels;
     const int fa = group_fa(group), fb = group_fb(group);
@@ -762,9 +798,10 @@ __global__ __launch_bounds__(256) void k_halo_knots_deep(
 }
 
 // ---------------------------------------------------------------------------
-// k_halo_finalize: grid n_epoch, block 384 (6 wavefronts).  Lane 0 of wavefront
-// f < 5 normalises family f and builds its not-a-knot spline over ln k; lane 0 of
-// wavefront 5 writes the epoch's halo/HOD constants and n_bar back.
+// k_halo_finalize: grid n_epoch, block 384 (6 wavefronts).  Wavefront f < 5
+// normalises family f and builds its not-a-knot spline over ln k (the five builds
+// run in lockstep, parallel cyclic reduction); lane 0 of wavefront 5 writes the
+// epoch's halo/HOD constants and n_bar back.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(384) void k_halo_finalize(
     chomp_config cfg, TabLayout L, Epoch* __restrict__ epochs, double* __restrict__ tab,
@@ -773,38 +810,40 @@ __global__ __launch_bounds__(384) void k_halo_finalize(
   extern __shared__ __align__(16) double sm[];
   const int NK = L.NK;
   double* xk = sm;                      // [NK]
-  double* work = xk + NK;               // [5][3NK]
+  double* yk = xk + NK;                 // [5][NK]
+  double* work = yk + 5 * NK;           // [5][9 NK]
   const int e = blockIdx.x;
   double* t = tab + (size_t)e * L.stride;
+  const int f = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const double nbr = t[L.off_misc];                    // n_bar / rho_bar
+  const double rho_bar = epochs[e].rho_bar;            // unchanged by the write-back below
   for (int i = threadIdx.x; i < NK; i += blockDim.x)
     xk[i] = linspace_at(log(cfg.k_min), log(cfg.k_max), NK, i);
-  __syncthreads();
-  const int f = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) != 0) return;
-  const double nbr = t[L.off_misc];                    // n_bar / rho_bar
-  if (f == 5) {
+  const bool active = f < 5 && ((fam_mask >> f) & 1u);
+  if (active) {
+    const double n_bar = nbr * rho_bar;
+    double scale = 1.0;
+    if (f == F_PPMM) scale = 1.0 / rho_bar;                       // halo.py:983
+    else if (f == F_HG) scale = 1.0 / nbr;                        // :959
+    else if (f == F_PPGM) scale = 1.0 / n_bar;                    // :1072
+    else if (f == F_PPGG) scale = rho_bar / (n_bar * n_bar);      // :1026
+    for (int i = lane; i < NK; i += 64) {
+      const double v = t[L.off_knot[f] + i] * scale;
+      yk[f * NK + i] = v;
+      t[L.off_knot[f] + i] = v;
+    }
+  }
+  if (f == 5 && lane == 0) {
     Epoch E = epochs[e];
     apply_halo_hod(E, profile[e], hod[e], t + L.off_nu_pp, t[L.off_ln_mass], L.NM);
     E.n_bar_over_rho_bar = nbr;                        // halo.py:692-700
     E.n_bar = nbr * E.rho_bar;
     epochs[e] = E;
-    return;
   }
-  if (!((fam_mask >> f) & 1u)) return;
-  const double rho_bar = epochs[e].rho_bar;            // not modified by wavefront 5
-  const double n_bar = nbr * rho_bar;
-  double scale = 1.0;
-  if (f == F_PPMM) scale = 1.0 / rho_bar;                       // halo.py:983
-  else if (f == F_HG) scale = 1.0 / nbr;                        // :959
-  else if (f == F_PPGM) scale = 1.0 / n_bar;                    // :1072
-  else if (f == F_PPGG) scale = rho_bar / (n_bar * n_bar);      // :1026
-  double* y = work + f * 3 * NK;
-  double* w = y + NK;
-  for (int i = 0; i < NK; ++i) {
-    y[i] = t[L.off_knot[f] + i] * scale;
-    t[L.off_knot[f] + i] = y[i];
-  }
-  spline_build(xk, y, NK, t + L.off_kpp[f], w);
+  __syncthreads();
+  const int fs = f < 5 ? f : 0;
+  spline_build_pcr(xk, yk + fs * NK, NK, t + L.off_kpp[fs], work + fs * 9 * NK, lane, 64,
+                   active);
 }
 
 // ---------------------------------------------------------------------------

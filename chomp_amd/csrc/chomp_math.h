@@ -222,6 +222,54 @@ CHOMP_HD void spline_build(const double* x, const double* y, int n, double* c,
   }
 }
 
+// --- The same spline, built in parallel -------------------------------------
+// Row i of the not-a-knot slope system  A s = r  (see spline_build): sub-, main and
+// super-diagonal and right-hand side.
+CHOMP_HD void spline_row(const double* x, const double* y, int n, int i, double* a,
+                         double* b, double* c, double* r) {
+  if (i == 0) {
+    const double h0 = x[1] - x[0], h1 = x[2] - x[1];
+    const double d0 = (y[1] - y[0]) / h0, d1 = (y[2] - y[1]) / h1;
+    *a = 0.0; *b = h1; *c = h0 + h1;
+    *r = ((3.0 * h0 + 2.0 * h1) * h1 * d0 + h0 * h0 * d1) / (h0 + h1);
+  } else if (i == n - 1) {
+    const double hl = x[n - 1] - x[n - 2], hll = x[n - 2] - x[n - 3];
+    const double dl = (y[n - 1] - y[n - 2]) / hl, dll = (y[n - 2] - y[n - 3]) / hll;
+    *a = hl + hll; *b = hll; *c = 0.0;
+    *r = (hl * hl * dll + (2.0 * hll + 3.0 * hl) * hll * dl) / (hll + hl);
+  } else {
+    const double hl = x[i] - x[i - 1], hr = x[i + 1] - x[i];
+    const double dl = (y[i] - y[i - 1]) / hl, dr = (y[i + 1] - y[i]) / hr;
+    *a = hr; *b = 2.0 * (hl + hr); *c = hl;
+    *r = 3.0 * (hr * dl + hl * dr);
+  }
+}
+
+// One parallel-cyclic-reduction step of stride s for row i: reads (a,b,c,d)[in],
+// writes [out].  After ceil(log2 n) steps x_i = d_i / b_i.
+CHOMP_HD void pcr_step(int n, int i, int s, const double* ai, const double* bi,
+                       const double* ci, const double* di, double* ao, double* bo,
+                       double* co, double* dout) {
+  const int lo = i - s, hi = i + s;
+  const double al = lo >= 0 ? -ai[i] / bi[lo] : 0.0;
+  const double ga = hi < n ? -ci[i] / bi[hi] : 0.0;
+  double b = bi[i], d = di[i], a = 0.0, c = 0.0;
+  if (lo >= 0) { b += al * ci[lo]; d += al * di[lo]; a = al * ai[lo]; }
+  if (hi < n) { b += ga * ai[hi]; d += ga * di[hi]; c = ga * ci[hi]; }
+  ao[i] = a; bo[i] = b; co[i] = c; dout[i] = d;
+}
+
+// pp coefficients of interval i from the slopes s.
+CHOMP_HD void spline_coef(const double* x, const double* y, const double* s, int i,
+                          double* c) {
+  const double h = x[i + 1] - x[i];
+  const double d = (y[i + 1] - y[i]) / h;
+  c[4 * i + 0] = y[i];
+  c[4 * i + 1] = s[i];
+  c[4 * i + 2] = (3.0 * d - 2.0 * s[i] - s[i + 1]) / h;
+  c[4 * i + 3] = (s[i] + s[i + 1] - 2.0 * d) / (h * h);
+}
+
 CHOMP_HD double pp_poly(const double* c, int i, double d) {
   const double* q = c + 4 * i;
   return fma(fma(fma(q[3], d, q[2]), d, q[1]), d, q[0]);

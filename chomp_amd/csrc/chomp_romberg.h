@@ -63,11 +63,11 @@ struct RombergOut {
   bool converged[NF];   // false: divmax exhausted (SciPy would warn and return value)
 };
 
-// LDS doubles a group needs: 2*NW for the sum exchange + NF*(32 NW + 1) for the
-// values of the fused first round (NW > 1 only).
+// LDS doubles a group needs: 2*NW for the sum exchange + NF*(7 NW + 2) for the
+// per-wavefront stride sums of the fused first round (NW > 1 only).
 template <int NW, int NF>
 constexpr int romberg_scratch() {
-  return NW == 1 ? 1 : 2 * NW + NF * (32 * NW + 1);
+  return NW == 1 ? 1 : 2 * NW + NF * (7 * NW + 2);
 }
 
 namespace detail {
@@ -146,14 +146,16 @@ __device__ __forceinline__ RombergOut<NF> romberg_group(const F& f, double a, do
     static_assert(NW == 2 || NW == 4 || NW == 8 || NW == 16, "NW must be 1,2,4,8,16");
     const int L0 = divmax < L0max ? divmax : L0max;
     const int N0 = 1 << L0;                              // intervals of the fused grid
-    double* fv = red + 2 * NW;                           // [NF][32 NW + 1]
-    constexpr int FS = 32 * NW + 1;
+    double* cw = red + 2 * NW;                           // [NF][7 NW + 2]
+    constexpr int FS = 7 * NW + 2;
     // weight rows 1..L0, fetched before the node evaluations hide their latency
     double crow[L0max + 1];
 #pragma unroll
     for (int i = 1; i <= L0max; ++i) crow[i] = CHOMP_ROMBERG_C[i][cl];
+    double v[NF];
+#pragma unroll
+    for (int q = 0; q < NF; ++q) v[q] = 0.0;
     if (gt <= N0) {
-      double v[NF];
       int lev;
       long j;
       double x;
@@ -167,23 +169,53 @@ __device__ __forceinline__ RombergOut<NF> romberg_group(const F& f, double a, do
         x = (a + 0.5 * h) + h * (double)j;
       }
       detail::call_f<F, NF>(f, x, v, lev, j, 0);
-#pragma unroll
-      for (int q = 0; q < NF; ++q) fv[q * FS + gt] = v[q];
     }
-    __syncthreads();
-    // lane l of every wavefront sums level l (lane 0: the end points)
-    double Sl[NF];
+    // Per-level sums of the fused grid.  Thread p holds node p; nodes of level l are
+    // the multiples of s = N0 >> l that are not multiples of 2s, so with
+    // C_s = sum of the interior nodes at multiples of s, S_l = C_s - C_2s.  One xor
+    // butterfly per wavefront yields its C_32 .. C_1 in lane 0 on the way (after the
+    // steps with offsets >= s, lane 0 holds the lanes that are multiples of s); the
+    // strides >= 64 only involve lane 0 of each wavefront.
+    const int wv = (int)(threadIdx.x >> 6);
 #pragma unroll
     for (int q = 0; q < NF; ++q) {
-      Sl[q] = 0.0;
-      if (lane == 0) {
-        Sl[q] = 0.5 * (fv[q * FS] + fv[q * FS + N0]);
-      } else if (lane <= L0) {
-        const int stride = N0 >> (lane - 1);
-        for (int p = stride >> 1; p < N0; p += stride) Sl[q] += fv[q * FS + p];
+      double* c = cw + q * FS;
+      if (gt == 0) c[7 * NW] = v[q];                      // f(a)
+      if (gt == N0) c[7 * NW + 1] = v[q];                 // f(b)
+      double x = (gt > 0 && gt < N0) ? v[q] : 0.0;        // interior nodes only
+      if (lane == 0) c[wv * 7 + 6] = x;
+#pragma unroll
+      for (int st = 0; st < 6; ++st) {
+        x += __shfl_xor(x, 32 >> st, 64);
+        if (lane == 0) c[wv * 7 + st] = x;                // C_(32 >> st) of this wavefront
       }
     }
-    __syncthreads();          // fv may be reused by a later call
+    __syncthreads();
+    double Sl[NF];     // lane l: sum of level l (lane 0: the end points)
+#pragma unroll
+    for (int q = 0; q < NF; ++q) {
+      const double* c = cw + q * FS;
+      double Cs = 0.0, C2s = 0.0;                         // for this lane's level
+      if (lane >= 1 && lane <= L0) {
+        const int s = N0 >> lane;                         // stride of level `lane`
+        auto C_of = [&](int stride) {
+          double t = 0.0;
+          if (stride >= N0) return t;                     // no interior multiples
+          if (stride < 64) {
+            const int st = 5 - (31 - __builtin_clz((unsigned)stride));   // 32>>st == stride
+            for (int w = 0; w < NW; ++w) t += c[w * 7 + st];
+          } else {
+            const int ws = stride >> 6;
+            for (int w = ws; w * 64 < N0; w += ws) t += c[w * 7 + 6];
+          }
+          return t;
+        };
+        Cs = C_of(s);
+        C2s = C_of(2 * s);
+      }
+      Sl[q] = (lane == 0) ? 0.5 * (c[7 * NW] + c[7 * NW + 1]) : (Cs - C2s);
+    }
+    __syncthreads();          // cw may be reused by a later call
 #pragma unroll
     for (int q = 0; q < NF; ++q) {
       ordsum[q] = __shfl(Sl[q], 0, 64);

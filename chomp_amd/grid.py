@@ -65,15 +65,21 @@ class HaloGrid(object):
         self.z = self.z_all[self.idx]
         self.ctx = cosmology._context(stream=stream, device=device)
         self._tables = 0
+        n = len(self.idx)
+        # parameter blocks packed once (ctypes), not per set-up call
+        self._c_cosmo = self.ctx.pack_cosmo(self.cosmo, n) if n else None
+        self._c_halo = self.ctx.pack_halo(self.halo, n) if n else None
+        self._c_hod = self.ctx.pack_hod(self.hod, n) if n else None
+        self._z = numpy.ascontiguousarray(self.z, dtype=numpy.float64)
 
     def setup(self, which="power_mm"):
         """Stage K for this rank's epochs (asynchronous on the context's stream)."""
         _, need = _WHICH[which]
         if len(self.idx) == 0:
             return
-        self.ctx.epochs_set(self.cosmo, self.z)
-        self.ctx.mass_setup(self.halo, self.kind)
-        self.ctx.halo_setup(self.halo, self.hod, need)
+        self.ctx.epochs_set(self._c_cosmo, self._z)
+        self.ctx.mass_setup(self._c_halo, self.kind)
+        self.ctx.halo_setup(self._c_halo, self._c_hod, need)
         self._tables = need
 
     def power(self, which, k, out=None):

@@ -33,6 +33,26 @@ void hc_spline(const double* x, const double* y, int n, const double* xe, int ne
                      : spline_eval(x, c, n, xe[i]);
   delete[] c; delete[] w;
 }
+// serial emulation of the parallel (PCR) spline build used by the kernels
+void hc_spline_pcr(const double* x, const double* y, int n, const double* xe, int ne,
+                   double* out) {
+  double* w = new double[9 * n + 4 * n];
+  double *a[2] = {w, w + 4 * n}, *b[2] = {w + n, w + 5 * n}, *c[2] = {w + 2 * n, w + 6 * n},
+         *d[2] = {w + 3 * n, w + 7 * n};
+  double* sl = w + 8 * n;
+  double* cf = w + 9 * n;
+  for (int i = 0; i < n; ++i) spline_row(x, y, n, i, &a[0][i], &b[0][i], &c[0][i], &d[0][i]);
+  int cur = 0;
+  for (int s = 1; s < n; s *= 2) {
+    for (int i = 0; i < n; ++i)
+      pcr_step(n, i, s, a[cur], b[cur], c[cur], d[cur], a[cur ^ 1], b[cur ^ 1], c[cur ^ 1], d[cur ^ 1]);
+    cur ^= 1;
+  }
+  for (int i = 0; i < n; ++i) sl[i] = d[cur][i] / b[cur][i];
+  for (int i = 0; i < n - 1; ++i) spline_coef(x, y, sl, i, cf);
+  for (int i = 0; i < ne; ++i) out[i] = spline_eval(x, cf, n, xe[i]);
+  delete[] w;
+}
 void hc_quintic(const double* x, const double* y, int n, double xq, double* d) {
   double* w = new double[(n + 6) + 11 * n + n];
   quintic_derivs(x, y, n, xq, w, &d[0], &d[1]);

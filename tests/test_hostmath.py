@@ -75,6 +75,22 @@ def test_notaknot_spline(hc):
         assert numpy.max(numpy.abs(out - ref(xe)) / (1 + numpy.abs(ref(xe)))) < 2e-13
 
 
+def test_parallel_spline_build(hc):
+    """The PCR (parallel cyclic reduction) build used inside the kernels gives the
+    same not-a-knot spline, on uniform, non-uniform and steeply graded knots."""
+    rng = numpy.random.default_rng(11)
+    cases = [numpy.linspace(-6.9, 4.6, 50), numpy.cumsum(rng.uniform(0.05, 2.0, 50)),
+             numpy.geomspace(0.1, 47.0, 50), numpy.linspace(0.0, 1.0, 100),
+             numpy.cumsum(rng.uniform(0.01, 5.0, 9))]
+    for x in cases:
+        y = numpy.cos(0.7 * x) * numpy.exp(0.05 * x) + 0.1 * x
+        ref = InterpolatedUnivariateSpline(x, y)
+        xe = numpy.concatenate([numpy.linspace(x[0], x[-1], 777), x])
+        out = numpy.empty_like(xe)
+        hc.hc_spline_pcr(_p(x), _p(y), x.size, _p(xe), xe.size, _p(out))
+        assert numpy.max(numpy.abs(out - ref(xe)) / (1 + numpy.abs(ref(xe)))) < 5e-13
+
+
 def test_quintic_derivatives(hc):
     """HaloFit's k=5 spline derivatives (halo.py:1289-1292)."""
     x = numpy.linspace(numpy.log(0.1), numpy.log(10.0), 50)
