@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstddef>
+#include <cstdint>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -59,6 +60,8 @@ struct chomp_ctx {
   double* d_stage_in2 = nullptr;
   double* d_stage_out = nullptr;
   double* d_work = nullptr;
+  int* d_flags = nullptr;          // per-wavefront slow-path flags of k_power_grid
+  size_t cap_flags = 0;
   size_t cap_in = 0, cap_in2 = 0, cap_out = 0, cap_work = 0;
 
   // projection
@@ -261,7 +264,7 @@ void chomp_ctx_destroy(chomp_ctx* ctx) {
   void* ptrs[] = {ctx->d_sici, ctx->d_j0, ctx->d_j2, ctx->d_tinker, ctx->d_gl16,
                   ctx->d_cand, ctx->d_cosmo, ctx->d_z, ctx->d_epochs, ctx->d_search,
                   ctx->d_tab, ctx->d_mass_par, ctx->d_profile, ctx->d_hod, ctx->d_nodes, ctx->d_snodes,
-                  ctx->d_stage_in, ctx->d_stage_in2, ctx->d_stage_out, ctx->d_work};
+                  ctx->d_stage_in, ctx->d_stage_in2, ctx->d_stage_out, ctx->d_work, ctx->d_flags};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   proj_free(ctx->proj);
@@ -433,11 +436,29 @@ int chomp_power_range(chomp_ctx* ctx, int which, size_t epoch0, size_t n, const 
     dout = ctx->d_stage_out;
   }
   const TabLayout& L = ctx->L;
-  unsigned gx = (unsigned)((nk + 255) / 256);
-  if (gx > 2048) gx = 2048;
-  const size_t sh = (size_t)(12 * (L.NK - 1)) * sizeof(double);
-  hipLaunchKernelGGL(k_power, dim3(gx, (unsigned)n), dim3(256), sh, ctx->stream, ctx->cfg, L,
-                     ctx->d_epochs, ctx->d_tab, which, (int)epoch0, dk, nk, dout);
+  if ((which & CHOMP_P_HALOFIT) == 0 &&
+      (reinterpret_cast<uintptr_t>(dk) % 16 == 0) && (reinterpret_cast<uintptr_t>(dout) % 16 == 0)) {
+    // enough blocks to fill 256 CUs: split the epochs over blockIdx.y when nk is small
+    const unsigned gx = (unsigned)((nk + 511) / 512);
+    unsigned gy = (2048 + gx - 1) / gx;
+    if (gy > n) gy = (unsigned)n;
+    const int epy = (int)((n + gy - 1) / gy);
+    gy = (unsigned)((n + epy - 1) / epy);
+    rc = ensure(ctx, &ctx->d_flags, &ctx->cap_flags, (size_t)gx * gy * 4);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_power_grid<false>, dim3(gx, gy), dim3(256), 0, ctx->stream, ctx->cfg, L,
+                       ctx->d_epochs, ctx->d_tab, which & 15, (int)epoch0, (int)n, epy, dk, nk,
+                       dout, ctx->d_flags);
+    hipLaunchKernelGGL(k_power_grid<true>, dim3(gx, gy), dim3(256), 0, ctx->stream, ctx->cfg, L,
+                       ctx->d_epochs, ctx->d_tab, which & 15, (int)epoch0, (int)n, epy, dk, nk,
+                       dout, ctx->d_flags);
+  } else {
+    unsigned gx = (unsigned)((nk + 255) / 256);
+    if (gx > 2048) gx = 2048;
+    const size_t sh = (size_t)(12 * (L.NK - 1)) * sizeof(double);
+    hipLaunchKernelGGL(k_power, dim3(gx, (unsigned)n), dim3(256), sh, ctx->stream, ctx->cfg, L,
+                       ctx->d_epochs, ctx->d_tab, which, (int)epoch0, dk, nk, dout);
+  }
   HIPCHK(hipGetLastError());
   if (mem == CHOMP_HOST) {
     HIPCHK(hipMemcpyAsync(out, dout, nk * n * sizeof(double), hipMemcpyDeviceToHost,

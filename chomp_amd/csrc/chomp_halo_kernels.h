@@ -77,6 +77,11 @@ constexpr int kSearchJ = 2048;        // candidates per walking direction
 constexpr int kEpochDoubles = (int)(sizeof(Epoch) / sizeof(double));
 static_assert(sizeof(Epoch) % sizeof(double) == 0, "Epoch must be 8-byte granular");
 
+__device__ __forceinline__ bool same_cosmology(const Epoch& a, const Epoch& b) {
+  return a.om0 == b.om0 && a.ob0 == b.ob0 && a.ol0 == b.ol0 && a.or0 == b.or0 &&
+         a.tcmb == b.tcmb && a.h == b.h && a.ns == b.ns;
+}
+
 // Cooperative copy of POD blocks as doubles.
 __device__ __forceinline__ void copy_doubles(double* dst, const double* src, int n) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
@@ -833,6 +838,12 @@ __global__ __launch_bounds__(384) void k_halo_finalize(
       t[L.off_knot[f] + i] = v;
     }
   }
+  if (f == 5 && lane == 1) {
+    // Stage-E record: amplitude of Delta^2 and "same cosmology as the previous epoch"
+    const Epoch& E = epochs[e];
+    t[L.off_misc + 1] = E.amp * E.sigma_norm * E.sigma_norm;
+    t[L.off_misc + 2] = (e > 0 && same_cosmology(E, epochs[e - 1])) ? 1.0 : 0.0;
+  }
   if (f == 5 && lane == 0) {
     Epoch E = epochs[e];
     apply_halo_hod(E, profile[e], hod[e], t + L.off_nu_pp, t[L.off_ln_mass], L.NM);
@@ -957,6 +968,181 @@ __global__ __launch_bounds__(256) void k_power(chomp_config cfg, TabLayout L,
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nk;
        i += (size_t)gridDim.x * blockDim.x)
     o[i] = P(k[i]);
+}
+
+// ---------------------------------------------------------------------------
+// k_power_grid: Stage E over a whole (k, epoch) grid in ONE launch, built to run at
+// HBM speed on large grids.  grid ceil(nk / 512), block 256; a thread owns two
+// consecutive k (16-byte loads / stores) and walks the epochs:
+//   * ln k, the knot interval and the Eisenstein-Hu shape (k/H0)^(3+n) T(k)^2 / k^3
+//     are computed once per k and re-used for every epoch that shares the previous
+//     epoch's cosmology (the z-axis of a (k, z) grid): per (k, z) sample that leaves
+//     three cubic evaluations and one multiply;
+//   * when all 128 k of a wavefront fall into one knot interval (the usual case for
+//     a sorted grid) the 12 spline coefficients of an epoch are wave-uniform and
+//     come through the scalar cache; any other wavefront takes the per-lane path.
+// Algorithmic traffic: 8 B read per k + 8 B written per (k, epoch) sample.
+// ---------------------------------------------------------------------------
+// P(k) of epoch table t for one k on the per-lane path (any k, any interval).
+__device__ __forceinline__ double power_lane(const chomp_config& cfg, const TabLayout& L,
+                                             const Epoch& E, const double* t, int fa, int fb,
+                                             int fp, int w, double kv) {
+  if (w == CHOMP_P_LIN) return linear_power(E, kv);
+  const double x0 = log(cfg.k_min);
+  const double dx = (log(cfg.k_max) - x0) / (double)(L.NK - 1);
+  if (kv < cfg.k_min) {
+    const double c_lo = t[L.off_kpp[fa]] * t[L.off_kpp[fb]] +
+                        t[L.off_kpp[fp]] / linear_power(E, cfg.k_min);
+    return linear_power(E, kv) * c_lo;
+  }
+  if (kv <= cfg.k_max) {
+    const double lk = log(kv);
+    const double ha = spline_eval_uniform(x0, dx, t + L.off_kpp[fa], L.NK, lk);
+    const double hb = spline_eval_uniform(x0, dx, t + L.off_kpp[fb], L.NK, lk);
+    const double pp = spline_eval_uniform(x0, dx, t + L.off_kpp[fp], L.NK, lk);
+    return 2.0 * kPi * kPi * delta_k_ln(E, lk, kv) / (kv * kv * kv) * ha * hb + pp;
+  }
+  return 0.0;
+}
+
+// SLOW = false: the streaming kernel; wavefronts that do not qualify for the fast
+// path only raise their flag in `need_slow` (one int per wavefront of the grid).
+// SLOW = true: second launch over the same grid; wavefronts whose flag is clear exit
+// at once, the others evaluate their samples lane by lane.
+template <bool SLOW>
+__global__ __launch_bounds__(256) void k_power_grid(chomp_config cfg, TabLayout L,
+                                                    const Epoch* __restrict__ epochs,
+                                                    const double* __restrict__ tab, int w,
+                                                    int epoch0, int n_epoch, int epochs_per_y,
+                                                    const double* __restrict__ k, size_t nk,
+                                                    double* __restrict__ out,
+                                                    int* __restrict__ need_slow) {
+  const int wave_id = (int)((blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6));
+  if constexpr (SLOW) {
+    if (need_slow[wave_id] == 0) return;
+  }
+  int fa = F_HM, fb = F_HM, fp = F_PPMM;
+  if (w == CHOMP_P_GM) { fa = F_HG; fb = F_HM; fp = F_PPGM; }
+  else if (w == CHOMP_P_GG) { fa = F_HG; fb = F_HG; fp = F_PPGG; }
+  const size_t i0 = 2 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x);
+  const bool have0 = i0 < nk, have1 = i0 + 1 < nk;
+  const bool vec = have1 && ((nk & 1) == 0);     // rows stay 16-byte aligned
+  double k0 = 1.0, k1 = 1.0;
+  if (vec) {
+    const double2 kk = *reinterpret_cast<const double2*>(k + i0);
+    k0 = kk.x; k1 = kk.y;
+  } else {
+    if (have0) k0 = k[i0];
+    if (have1) k1 = k[i0 + 1];
+  }
+  // this block's epochs: [q_lo, q_hi) of the launch's range
+  const int q_lo = blockIdx.y * epochs_per_y;
+  int q_hi = q_lo + epochs_per_y;
+  if (q_hi > n_epoch) q_hi = n_epoch;
+  const int NK = L.NK;
+  const double x0 = log(cfg.k_min);
+  const double dx = (log(cfg.k_max) - x0) / (double)(NK - 1);
+  const double lk0 = log(k0), lk1 = log(k1);
+  int idx0 = (int)floor((lk0 - x0) / dx), idx1 = (int)floor((lk1 - x0) / dx);
+  idx0 = idx0 < 0 ? 0 : (idx0 > NK - 2 ? NK - 2 : idx0);
+  idx1 = idx1 < 0 ? 0 : (idx1 > NK - 2 ? NK - 2 : idx1);
+  const bool in0 = k0 >= cfg.k_min && k0 <= cfg.k_max;
+  const bool in1 = k1 >= cfg.k_min && k1 <= cfg.k_max;
+  const int idxu = __builtin_amdgcn_readfirstlane(idx0);
+  // (lanes past the end of k must not take the unguarded fast path)
+  const bool fast =
+      __all(have0 && have1 && in0 && in1 && idx0 == idxu && idx1 == idxu) && w != CHOMP_P_LIN;
+  if constexpr (SLOW) {
+    // Per-lane path: any k, any knot interval.  In-range k still re-use the
+    // Eisenstein-Hu shape across epochs of one cosmology; their 12 coefficients come
+    // through the vector cache.  k outside [k_min, k_max] take the full formula.
+    const double e0 = lk0 - (x0 + dx * (double)idx0), e1 = lk1 - (x0 + dx * (double)idx1);
+    double sh0 = 0.0, sh1 = 0.0;
+    for (int q = q_lo; q < q_hi; ++q) {
+      const int e = epoch0 + q;
+      const Epoch& E = epochs[e];
+      const double* t = tab + (size_t)e * L.stride;
+      double* o = out + (size_t)q * nk + i0;
+      const bool same = q > q_lo && t[L.off_misc + 2] != 0.0;
+      const double A = t[L.off_misc + 1];
+      if (!same && w != CHOMP_P_LIN) {
+        const double T0 = eh_transfer(E, k0), T1 = eh_transfer(E, k1);
+        sh0 = 2.0 * kPi * kPi * exp((3.0 + E.ns) * (lk0 - E.ln_H0)) * T0 * T0 / (k0 * k0 * k0);
+        sh1 = 2.0 * kPi * kPi * exp((3.0 + E.ns) * (lk1 - E.ln_H0)) * T1 * T1 / (k1 * k1 * k1);
+      }
+      if (have0) {
+        double r;
+        if (in0 && w != CHOMP_P_LIN) {
+          const double ha = pp_poly(t + L.off_kpp[fa], idx0, e0);
+          const double hb = pp_poly(t + L.off_kpp[fb], idx0, e0);
+          const double pp = pp_poly(t + L.off_kpp[fp], idx0, e0);
+          r = fma(A * sh0, ha * hb, pp);
+        } else {
+          r = power_lane(cfg, L, E, t, fa, fb, fp, w, k0);
+        }
+        o[0] = r;
+      }
+      if (have1) {
+        double r;
+        if (in1 && w != CHOMP_P_LIN) {
+          const double ha = pp_poly(t + L.off_kpp[fa], idx1, e1);
+          const double hb = pp_poly(t + L.off_kpp[fb], idx1, e1);
+          const double pp = pp_poly(t + L.off_kpp[fp], idx1, e1);
+          r = fma(A * sh1, ha * hb, pp);
+        } else {
+          r = power_lane(cfg, L, E, t, fa, fb, fp, w, k1);
+        }
+        o[1] = r;
+      }
+    }
+    return;
+  }
+  if ((threadIdx.x & 63) == 0) need_slow[wave_id] = fast ? 0 : 1;
+  if (!fast) return;
+  const double d0 = lk0 - (x0 + dx * (double)idxu), d1 = lk1 - (x0 + dx * (double)idxu);
+  const int oa = L.off_kpp[fa] + 4 * idxu, ob = L.off_kpp[fb] + 4 * idxu,
+            op = L.off_kpp[fp] + 4 * idxu;
+  double shape0 = 0.0, shape1 = 0.0;             // 2 pi^2 (k/H0)^(3+n) T^2 / k^3
+#pragma unroll 4
+  for (int q = q_lo; q < q_hi; ++q) {
+    const int e = epoch0 + q;
+    const double* t = tab + (size_t)e * L.stride;
+    // wave-uniform operands: through the scalar cache
+    const double A = t[L.off_misc + 1];
+    const bool same = q > q_lo && t[L.off_misc + 2] != 0.0;
+    const double a0 = t[oa], a1 = t[oa + 1], a2 = t[oa + 2], a3 = t[oa + 3];
+    const double b0 = t[ob], b1 = t[ob + 1], b2 = t[ob + 2], b3 = t[ob + 3];
+    const double p0 = t[op], p1 = t[op + 1], p2 = t[op + 2], p3 = t[op + 3];
+    if (!same) {
+      const Epoch& E = epochs[e];
+      const double T0 = eh_transfer(E, k0), T1 = eh_transfer(E, k1);
+      shape0 = 2.0 * kPi * kPi * exp((3.0 + E.ns) * (lk0 - E.ln_H0)) * T0 * T0 / (k0 * k0 * k0);
+      shape1 = 2.0 * kPi * kPi * exp((3.0 + E.ns) * (lk1 - E.ln_H0)) * T1 * T1 / (k1 * k1 * k1);
+    }
+    const double ha0 = fma(fma(fma(a3, d0, a2), d0, a1), d0, a0);
+    const double hb0 = fma(fma(fma(b3, d0, b2), d0, b1), d0, b0);
+    const double pp0 = fma(fma(fma(p3, d0, p2), d0, p1), d0, p0);
+    const double ha1 = fma(fma(fma(a3, d1, a2), d1, a1), d1, a0);
+    const double hb1 = fma(fma(fma(b3, d1, b2), d1, b1), d1, b0);
+    const double pp1 = fma(fma(fma(p3, d1, p2), d1, p1), d1, p0);
+    const double r0 = fma(A * shape0, ha0 * hb0, pp0);
+    const double r1 = fma(A * shape1, ha1 * hb1, pp1);
+    double* o = out + (size_t)q * nk + i0;
+    // Streamed once, never re-read by this launch: 16-byte write-through (sc1)
+    // stores.  Plain stores leave ~0.5 GB of dirty lines in the L2s that the
+    // end-of-kernel release then has to write back (MI355X_MICROARCH.md, rows
+    // "boundary" / "publish-large").
+    if (vec) {
+      typedef float v4f __attribute__((ext_vector_type(4)));
+      typedef double v2d __attribute__((ext_vector_type(2)));
+      v2d rr = {r0, r1};
+      v4f bits = __builtin_bit_cast(v4f, rr);
+      asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(o), "v"(bits) : "memory");
+    } else {
+      __builtin_nontemporal_store(r0, o);
+      __builtin_nontemporal_store(r1, o + 1);
+    }
+  }
 }
 
 // sigma_r at arbitrary scales (SingleEpoch.sigma_r): grid n, block 256.
