@@ -325,7 +325,8 @@ int chomp_mass_setup(chomp_ctx* ctx, const chomp_halo_par* par, int mf_kind) {
   if (rcu) return rcu;
   hipLaunchKernelGGL(k_nu_table, dim3(L.NM, (unsigned)n), dim3(256), 0, ctx->stream, ctx->cfg,
                      L, ctx->d_epochs, ctx->d_search, ctx->d_snodes, ctx->d_tab);
-  const size_t sh = (size_t)(2 * L.NM + 8 * (L.NM - 1) + 18 * L.NM + 32 + 8) * sizeof(double);
+  const size_t sh = (size_t)(2 * L.NM + 8 * (L.NM - 1) + 18 * L.NM + 32 + romberg_scratch<4, 1>()) *
+                    sizeof(double);
   hipLaunchKernelGGL(k_mass_setup, dim3((unsigned)n), dim3(256), sh, ctx->stream, ctx->cfg, L,
                      ctx->d_epochs, ctx->d_search, ctx->d_tab, ctx->d_mass_par, mf_kind,
                      ctx->d_tinker, ctx->d_gl16);

@@ -383,6 +383,17 @@ struct FnuLn {          // f(nu) d nu = f(e^t) e^t dt
     return f_nu(*e, nu) * nu;
   }
 };
+struct FnuLin {         // mass_function.py:227-231, as the reference integrates it
+  const Epoch* e;
+  __device__ __forceinline__ double operator()(double nu) const { return f_nu(*e, nu); }
+};
+struct FnuBiasLin {     // mass_function.py:235-240
+  const Epoch* e;
+  __device__ __forceinline__ double operator()(double nu) const {
+    return f_nu(*e, nu) * bias_nu(*e, nu);
+  }
+};
+constexpr int kNormLiteralDivmax = 18;
 struct FnuBiasLn {
   const Epoch* e;
   __device__ __forceinline__ double operator()(double t) const {
@@ -408,7 +419,7 @@ __global__ __launch_bounds__(256) void k_mass_setup(
   double* c_lnm = c_nu + 4 * (NM - 1);   // [4(NM-1)]
   double* work = c_lnm + 4 * (NM - 1);   // [18 NM]
   double* gl = work + 18 * NM;           // [32]
-  double* red = gl + 32;                 // [8]
+  double* red = gl + 32;                 // [romberg_scratch<4, 1>()]
   const int e = blockIdx.x;
   double* t = tab + (size_t)e * L.stride;
   copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
@@ -452,18 +463,36 @@ __global__ __launch_bounds__(256) void k_mass_setup(
   // reference integrates in linear nu with Romberg to rtol 1.48e-8 (8193 nodes);
   // the integrand is analytic, so 8 x 16 Gauss-Legendre nodes in ln nu give the
   // same number to ~4e-11.
+  // With a shallow divmax the reference's Romberg cannot converge and returns its last
+  // row; that (not the true integral) is then the reference's number, so the literal
+  // Romberg in linear nu is run instead (at most 2^17 cheap nodes).
   int flip = 0;
+  const bool literal = cfg.divmax < kNormLiteralDivmax;
   const double a = log(E.nu_min), b = log(E.nu_max);
   if (mf_kind == CHOMP_MF_ST) {
-    FnuLn f{&E};
-    const double norm = gauss_panels<4>(f, a, b, 8, gl, red, flip);
+    double norm;
+    if (literal) {
+      FnuLin f{&E};
+      norm = romberg1<4>(f, E.nu_min, E.nu_max, cfg.global_precision, cfg.mass_precision,
+                         cfg.divmax, red);
+    } else {
+      FnuLn f{&E};
+      norm = gauss_panels<4>(f, a, b, 8, gl, red, flip);
+    }
     __syncthreads();
     if (threadIdx.x == 0) E.f_norm = 1.0 / norm;
     __syncthreads();
   }
   {
-    FnuBiasLn f{&E};
-    const double norm = gauss_panels<4>(f, a, b, 8, gl, red, flip);
+    double norm;
+    if (literal) {
+      FnuBiasLin f{&E};
+      norm = romberg1<4>(f, E.nu_min, E.nu_max, cfg.global_precision, cfg.mass_precision,
+                         cfg.divmax, red);
+    } else {
+      FnuBiasLn f{&E};
+      norm = gauss_panels<4>(f, a, b, 8, gl, red, flip);
+    }
     __syncthreads();
     if (threadIdx.x == 0) E.bias_norm = 1.0 / norm;
     __syncthreads();

@@ -1,0 +1,70 @@
+"""CPU tests of the host-side mirror: argument handling and error behaviour that the
+reference defines (KeyError on missing keys) or that the accelerated scope adds
+(ChompScopeError for reference features outside the hot path)."""
+import numpy
+import pytest
+
+
+def test_missing_keys_raise_keyerror():
+    from chomp_amd import cosmology, halo, hod
+    cd = dict(omega_m0=0.3)
+    with pytest.raises(KeyError):
+        cosmology.SingleEpoch(0.0, cd)
+    with pytest.raises(KeyError):
+        hod.HODZheng({"log_M_min": 12.0})
+    with pytest.raises(KeyError):
+        halo.Halo(0.0, halo_dict={"stq": 0.3})
+
+
+def test_scope_errors():
+    from chomp_amd import cosmology, halo, kernel, _lib
+    with pytest.raises(_lib.ChompScopeError):
+        cosmology.SingleEpoch(0.0, with_bao=True)
+    with pytest.raises(_lib.ChompScopeError):
+        halo.Halo(0.0, extrapolate=True)
+    with pytest.raises(_lib.ChompScopeError):
+        halo.Halo(0.0, halo_dict=dict(stq=0.3, st_little_a=0.707, c0=9.0, beta=-0.13,
+                                      alpha=-1.5, delta_v=-1.0))
+    d = kernel.dNdzGaussian(0.0, 2.0, 1.0, 0.2)
+    w = kernel.WindowFunctionGalaxy(d)
+    with pytest.raises(_lib.ChompScopeError):
+        kernel.Kernel(1e-6, 1.0, w, w, force_quad=True)
+
+
+def test_redshift_distribution_clipping():
+    """Constructor-side rules that are pure host logic (kernel.py:101-104, 164-173)."""
+    from chomp_amd import kernel
+    d = kernel.dNdzGaussian(0.0, 5.0, 1.0, 0.2)
+    assert d.z_min == 0.0 and abs(d.z_max - 2.6) < 1e-15
+    m = kernel.dNdzMagLim(0.0, 2.0, 2.0, 0.3, 2.0)
+    assert abs(m.z_max - 0.3 * numpy.sqrt(-numpy.log(1.48e-8))) < 1e-12
+    mi = kernel.dNdzMagLim(0.0, 2.0, 2, 0.3, 2)        # int b: Python-2 1/b == 0
+    assert abs(mi.z_max - 0.3) < 1e-15
+
+
+def test_hod_derived_constants_match_oracle():
+    from chomp_amd import hod
+    from oracle import chomp_oracle as o
+    for hd in (o.default_hod_dict, dict(o.default_hod_dict, sigma=0.71, log_M_min=14.06)):
+        a, b = hod.HODZheng(hd), o.zheng(hd)
+        assert abs(a.first_moment_zero / b.first_moment_zero - 1) < 1e-12
+        assert a.second_moment_zero == b.second_moment_zero
+        assert a._safe_norm == b.safe_norm
+        m = numpy.logspace(10, 16, 50)
+        assert numpy.allclose(a.first_moment(m), o.zheng_first(b, m), rtol=1e-13, atol=1e-300)
+        assert numpy.allclose(a.second_moment(m), o.zheng_second(b, m), rtol=1e-13, atol=1e-300)
+
+
+def test_theta_bins_match_oracle():
+    from oracle import chomp_oracle as o
+    from chomp_amd import correlation
+
+    class _K(object):        # only the binning part of Correlation.__init__ is exercised
+        pass
+    for args in ((0.001, 1.0, 5.0), (0.01, 10.0, 3.0), (0.5, 0.5, 5.0)):
+        c = correlation.Correlation.__new__(correlation.Correlation)
+        try:
+            correlation.Correlation.__init__(c, args[0], args[1], _K(), bins_per_decade=args[2])
+        except AttributeError:
+            pass            # stops at the kernel access, after theta_array is built
+        assert numpy.allclose(c.theta_array, o.theta_bins(*args), rtol=1e-15)
