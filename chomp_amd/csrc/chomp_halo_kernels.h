@@ -447,6 +447,8 @@ __global__ __launch_bounds__(256) void k_mass_setup(
     E.mf_kind = mf_kind;
     E.f_norm = 1.0;
     E.bias_norm = 1.0;
+    E.ln_st_a = log(hp.st_little_a);
+    E.ln_t_beta = 0.0;
     if (mf_kind == CHOMP_MF_TINKER) {                 // mass_function.py:547-564
       const double ld = log(E.mf_delta_v);
       const double opz = 1.0 + E.z;
@@ -455,6 +457,7 @@ __global__ __launch_bounds__(256) void k_mass_setup(
       E.t_gamma = spline_eval(tinker->x, tinker->c[2], 9, ld) * pow(opz, -0.01);
       E.t_phi = spline_eval(tinker->x, tinker->c[3], 9, ld) * pow(opz, -0.08);
       E.t_eta = spline_eval(tinker->x, tinker->c[4], 9, ld) * pow(opz, 0.27);
+      E.ln_t_beta = log(E.t_beta);
       tinker_bias_constants(E);
     }
   }
@@ -524,22 +527,25 @@ struct IntegrandMM {       // out[0] = h_m, out[1] = pp_mm (x rho_bar)
     const double nu = exp(ln_nu);
     const double lnm = spline_eval(c.nu_knots, c.lnm_pp, c.NM, nu);
     const double y = y_nfw(*c.e, *c.sici, c.ln_k, lnm);
-    const double nf = nu * f_nu(*c.e, nu);
-    out[0] = nf * bias_nu(*c.e, nu) * y;
+    double nf, b;
+    mf_node(*c.e, nu, ln_nu, true, &nf, &b);
+    out[0] = nf * b * y;
     out[1] = nf * exp(lnm) * y * y;
   }
 };
 
 struct IntegrandGM {       // out[0] = h_g, out[1] = pp_gm
   HaloCtx c;
+  bool want_hg;            // false: h_g has converged, skip its bias factor
   __device__ __forceinline__ void operator()(double ln_nu, double (&out)[2]) const {
     const double nu = exp(ln_nu);
     const double lnm = spline_eval(c.nu_knots, c.lnm_pp, c.NM, nu);
     const double mass = exp(lnm);
     const double y = y_nfw(*c.e, *c.sici, c.ln_k, lnm);
-    const double nf = nu * f_nu(*c.e, nu);
-    const double n1 = zheng_first(*c.e, mass);
-    out[0] = nf * bias_nu(*c.e, nu) * y * n1 / mass;
+    double nf, b = 0.0, n1, n2;
+    mf_node(*c.e, nu, ln_nu, want_hg, &nf, &b);
+    zheng_node(*c.e, mass, lnm, &n1, &n2);
+    out[0] = nf * b * y * n1 / mass;
     out[1] = (n1 < 1.0) ? nf * n1 * y : nf * n1 * y * y;
   }
 };
@@ -551,8 +557,9 @@ struct IntegrandGG {       // out[0] = pp_gg
     const double lnm = spline_eval(c.nu_knots, c.lnm_pp, c.NM, nu);
     const double mass = exp(lnm);
     const double y = y_nfw(*c.e, *c.sici, c.ln_k, lnm);
-    const double nf = nu * f_nu(*c.e, nu);
-    const double n2 = zheng_second(*c.e, mass);
+    double nf, b, n1, n2;
+    mf_node(*c.e, nu, ln_nu, false, &nf, &b);
+    zheng_node(*c.e, mass, lnm, &n1, &n2);
     out[0] = (n2 < 1.0) ? nf * n2 * y / mass : nf * n2 * y * y / mass;
   }
 };
@@ -561,8 +568,12 @@ struct IntegrandNbar {     // halo.py:702-707
   HaloCtx c;
   __device__ __forceinline__ double operator()(double ln_nu) const {
     const double nu = exp(ln_nu);
-    const double mass = exp(spline_eval(c.nu_knots, c.lnm_pp, c.NM, nu));
-    return nu * zheng_first(*c.e, mass) * f_nu(*c.e, nu) / mass;
+    const double lnm = spline_eval(c.nu_knots, c.lnm_pp, c.NM, nu);
+    const double mass = exp(lnm);
+    double nf, b, n1, n2;
+    mf_node(*c.e, nu, ln_nu, false, &nf, &b);
+    zheng_node(*c.e, mass, lnm, &n1, &n2);
+    return nf * n1 / mass;
   }
 };
 
@@ -678,7 +689,8 @@ __global__ __launch_bounds__(256) void k_halo_nodes(
   const double nu = exp(x);
   const double lnm = spline_eval(H.nu_knots, H.lnm_pp, L.NM, nu);
   const double mass = exp(lnm);
-  const double nf = nu * f_nu(E, nu);
+  double nf, bias = 0.0;
+  mf_node(E, nu, x, group != 2, &nf, &bias);
   const double ln_c = E.ln_c_const + E.beta * lnm;
   const double ln_rv = (E.ln_rv_const + lnm) * (1.0 / 3.0);
   const double con = exp(ln_c);
@@ -686,18 +698,20 @@ __global__ __launch_bounds__(256) void k_halo_nodes(
   const double ln_cp = log(cp);
   double wA, wB, flag = 0.0;
   if (group == 0) {
-    wA = nf * bias_nu(E, nu);
+    wA = nf * bias;
     wB = nf * mass;
-  } else if (group == 1) {
-    const double n1 = zheng_first(E, mass);
-    wA = nf * bias_nu(E, nu) * n1 / mass;
-    wB = nf * n1;
-    flag = n1 < 1.0 ? 1.0 : 0.0;
   } else {
-    const double n2 = zheng_second(E, mass);
-    wA = 0.0;
-    wB = nf * n2 / mass;
-    flag = n2 < 1.0 ? 1.0 : 0.0;
+    double n1, n2;
+    zheng_node(E, mass, lnm, &n1, &n2);
+    if (group == 1) {
+      wA = nf * bias * n1 / mass;
+      wB = nf * n1;
+      flag = n1 < 1.0 ? 1.0 : 0.0;
+    } else {
+      wA = 0.0;
+      wB = nf * n2 / mass;
+      flag = n2 < 1.0 ? 1.0 : 0.0;
+    }
   }
   double* n = nodes + ((size_t)e * 3 + group) * kNodeStride + idx;
   n[0 * kNodeCount] = wA;
@@ -813,7 +827,7 @@ __global__ __launch_bounds__(256) void k_halo_knots_deep(
                                                 cfg.divmax, red);
     va = r.value[0]; vb = r.value[1]; la = r.level[0]; lb = r.level[1];
   } else if (group == 1) {
-    IntegrandGM f{c};
+    IntegrandGM f{c, pa};
     const RombergOut<2> r = romberg_group<4, 2>(f, group_lower(E, 1), ln_nu_max,
                                                 cfg.global_precision, cfg.halo_precision,
                                                 cfg.divmax, red);
@@ -1132,7 +1146,6 @@ __global__ __launch_bounds__(256) void k_power_grid(chomp_config cfg, TabLayout 
   const int oa = L.off_kpp[fa] + 4 * idxu, ob = L.off_kpp[fb] + 4 * idxu,
             op = L.off_kpp[fp] + 4 * idxu;
   double shape0 = 0.0, shape1 = 0.0;             // 2 pi^2 (k/H0)^(3+n) T^2 / k^3
-#pragma unroll 4
   for (int q = q_lo; q < q_hi; ++q) {
     const int e = epoch0 + q;
     const double* t = tab + (size_t)e * L.stride;

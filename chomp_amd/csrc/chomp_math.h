@@ -428,7 +428,7 @@ struct Epoch {
   // HaloFit (halo.py:1261-1319)
   double hf_f1, hf_f2, hf_f3, hf_k_s, hf_n_eff, hf_C, hf_a_n, hf_b_n, hf_c_n,
       hf_gamma_n, hf_alpha_n, hf_beta_n, hf_mu_n, hf_nu_n;
-  double pad_[2];
+  double ln_st_a, ln_t_beta;       // logs used by mf_node
 };
 static_assert(sizeof(Epoch) % 16 == 0, "Epoch must keep LDS carve-ups 16-byte aligned");
 
@@ -602,6 +602,31 @@ CHOMP_HD double bias_nu(const Epoch& e, double nu) {
                         e.tb_C * pow(sq, 2.4));
 }
 
+// nu f(nu) and b(nu) at a Romberg node, where ln nu is the integration variable
+// itself: every power of nu becomes one exp of a multiple of ln nu (fp64 pow costs
+// ~5 exps on the device).  Same quantities as f_nu / bias_nu to ~1e-15 relative.
+CHOMP_HD void mf_node(const Epoch& e, double nu, double ln_nu, bool want_bias, double* nu_f,
+                      double* bias) {
+  if (e.mf_kind == 0) {
+    const double np_ = nu * e.st_a;
+    const double ln_np = ln_nu + e.ln_st_a;
+    const double e1 = exp(-e.stq * ln_np);                       // nu'^-q
+    *nu_f = e.f_norm * (1.0 + e1) * exp(0.5 * ln_np - 0.5 * np_);   // nu f(nu)
+    if (want_bias)
+      *bias = e.bias_norm * (1.0 + (np_ - 1.0) / e.delta_c +
+                             2.0 * e.stq / (e.delta_c * (1.0 + 1.0 / e1)));
+  } else {
+    const double e1 = exp(-2.0 * e.t_phi * (e.ln_t_beta + 0.5 * ln_nu));   // (beta sqrt nu)^-2phi
+    *nu_f = e.t_alpha * (1.0 + e1) *
+            exp((e.t_eta + 0.5) * ln_nu - 0.5 * e.t_gamma * nu);   // nu * nu^eta e^(-g nu/2) / sqrt nu
+    if (want_bias) {
+      const double sa = exp(0.5 * e.tb_a * ln_nu);
+      *bias = e.bias_norm * (1.0 - e.tb_A * sa / (sa + e.tb_dca) + 0.183 * exp(0.75 * ln_nu) +
+                             e.tb_C * exp(1.2 * ln_nu));
+    }
+  }
+}
+
 // Tinker bias constants from delta_v (mass_function.py:521-528).
 CHOMP_HD void tinker_bias_constants(Epoch& e) {
   const double y = log10(e.mf_delta_v);
@@ -625,6 +650,23 @@ CHOMP_HD double zheng_satellite(const Epoch& e, double mass) {
   if (!(diff > 0.0)) return 0.0;
   return zheng_central(e, mass) * pow(diff / e.hod_M1p, e.hod_alpha);
 }
+// HOD moments at a node where ln M is already known (no log10, no pow for alpha = 1).
+CHOMP_HD void zheng_node(const Epoch& e, double mass, double ln_mass, double* n_first,
+                         double* n_second) {
+  const double lm = ln_mass * 0.43429448190325182765;            // log10 M
+  double nc;
+  if (e.hod_sigma <= 0.0) nc = lm > e.hod_log_M_min ? 1.0 : 0.0;
+  else nc = 0.5 * (1.0 + erf((lm - e.hod_log_M_min) / e.hod_sigma));
+  const double diff = mass - e.hod_M0;
+  double ns = 0.0;
+  if (diff > 0.0) {
+    const double r = diff / e.hod_M1p;
+    ns = nc * (e.hod_alpha == 1.0 ? r : exp(e.hod_alpha * log(r)));
+  }
+  *n_first = nc + ns;
+  *n_second = (2.0 + ns) * ns;
+}
+
 CHOMP_HD double zheng_first(const Epoch& e, double mass) {
   return zheng_central(e, mass) + zheng_satellite(e, mass);
 }
