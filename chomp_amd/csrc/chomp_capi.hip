@@ -447,12 +447,17 @@ int chomp_power_range(chomp_ctx* ctx, int which, size_t epoch0, size_t n, const 
     gy = (unsigned)((n + epy - 1) / epy);
     rc = ensure(ctx, &ctx->d_flags, &ctx->cap_flags, (size_t)gx * gy * 4);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_power_grid<false>, dim3(gx, gy), dim3(256), 0, ctx->stream, ctx->cfg, L,
+    hipLaunchKernelGGL(k_power_grid, dim3(gx, gy), dim3(256), 0, ctx->stream, ctx->cfg, L,
                        ctx->d_epochs, ctx->d_tab, which & 15, (int)epoch0, (int)n, epy, dk, nk,
                        dout, ctx->d_flags);
-    hipLaunchKernelGGL(k_power_grid<true>, dim3(gx, gy), dim3(256), 0, ctx->stream, ctx->cfg, L,
-                       ctx->d_epochs, ctx->d_tab, which & 15, (int)epoch0, (int)n, epy, dk, nk,
-                       dout, ctx->d_flags);
+    // per-lane pass over the flagged wavefronts, in items of <= 8 epochs
+    const int per_item = epy < 8 ? epy : 8;
+    const long items = (long)gx * gy * 4 * ((epy + per_item - 1) / per_item);
+    unsigned gl = (unsigned)((items + 3) / 4);
+    if (gl > 1024) gl = 1024;
+    hipLaunchKernelGGL(k_power_grid_lanes, dim3(gl), dim3(256), 0, ctx->stream, ctx->cfg, L,
+                       ctx->d_epochs, ctx->d_tab, which & 15, (int)epoch0, (int)n, (int)gx,
+                       (int)gy, epy, per_item, dk, nk, dout, ctx->d_flags);
   } else {
     unsigned gx = (unsigned)((nk + 255) / 256);
     if (gx > 2048) gx = 2048;

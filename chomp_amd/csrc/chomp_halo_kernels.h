@@ -1014,8 +1014,8 @@ __global__ __launch_bounds__(256) void k_power(chomp_config cfg, TabLayout L,
 }
 
 // ---------------------------------------------------------------------------
-// k_power_grid: Stage E over a whole (k, epoch) grid in ONE launch, built to run at
-// HBM speed on large grids.  grid ceil(nk / 512), block 256; a thread owns two
+// k_power_grid (+ k_power_grid_lanes): Stage E over a whole (k, epoch) grid, built to
+// run at HBM speed on large grids.  grid ceil(nk / 512), block 256; a thread owns two
 // consecutive k (16-byte loads / stores) and walks the epochs:
 //   * ln k, the knot interval and the Eisenstein-Hu shape (k/H0)^(3+n) T(k)^2 / k^3
 //     are computed once per k and re-used for every epoch that shares the previous
@@ -1048,11 +1048,54 @@ __device__ __forceinline__ double power_lane(const chomp_config& cfg, const TabL
   return 0.0;
 }
 
-// SLOW = false: the streaming kernel; wavefronts that do not qualify for the fast
-// path only raise their flag in `need_slow` (one int per wavefront of the grid).
-// SLOW = true: second launch over the same grid; wavefronts whose flag is clear exit
-// at once, the others evaluate their samples lane by lane.
-template <bool SLOW>
+// What one wavefront knows about its 128 k (two per lane).
+struct KLanes {
+  size_t i0;
+  bool have0, have1, vec, in0, in1;
+  double k0, k1, lk0, lk1;
+  int idx0, idx1;
+};
+
+__device__ __forceinline__ KLanes load_k_lanes(const chomp_config& cfg, int NK,
+                                               const double* __restrict__ k, size_t nk,
+                                               size_t thread_index) {
+  KLanes s;
+  s.i0 = 2 * thread_index;
+  s.have0 = s.i0 < nk;
+  s.have1 = s.i0 + 1 < nk;
+  s.vec = s.have1 && ((nk & 1) == 0);            // rows stay 16-byte aligned
+  s.k0 = 1.0;
+  s.k1 = 1.0;
+  if (s.vec) {
+    const double2 kk = *reinterpret_cast<const double2*>(k + s.i0);
+    s.k0 = kk.x; s.k1 = kk.y;
+  } else {
+    if (s.have0) s.k0 = k[s.i0];
+    if (s.have1) s.k1 = k[s.i0 + 1];
+  }
+  const double x0 = log(cfg.k_min);
+  const double dx = (log(cfg.k_max) - x0) / (double)(NK - 1);
+  s.lk0 = log(s.k0);
+  s.lk1 = log(s.k1);
+  s.idx0 = (int)floor((s.lk0 - x0) / dx);
+  s.idx1 = (int)floor((s.lk1 - x0) / dx);
+  s.idx0 = s.idx0 < 0 ? 0 : (s.idx0 > NK - 2 ? NK - 2 : s.idx0);
+  s.idx1 = s.idx1 < 0 ? 0 : (s.idx1 > NK - 2 ? NK - 2 : s.idx1);
+  s.in0 = s.k0 >= cfg.k_min && s.k0 <= cfg.k_max;
+  s.in1 = s.k1 >= cfg.k_min && s.k1 <= cfg.k_max;
+  return s;
+}
+
+struct PowerFam { int fa, fb, fp; };
+__device__ __forceinline__ PowerFam power_families(int w) {
+  if (w == CHOMP_P_GM) return PowerFam{F_HG, F_HM, F_PPGM};
+  if (w == CHOMP_P_GG) return PowerFam{F_HG, F_HG, F_PPGG};
+  return PowerFam{F_HM, F_HM, F_PPMM};
+}
+
+// The streaming pass.  grid (ceil(nk / 512), ceil(n_epoch / epochs_per_y)), block 256.
+// A wavefront whose k do not qualify for the fast path only raises its flag in
+// `need_slow` (one int per wavefront of the grid) for k_power_grid_lanes.
 __global__ __launch_bounds__(256) void k_power_grid(chomp_config cfg, TabLayout L,
                                                     const Epoch* __restrict__ epochs,
                                                     const double* __restrict__ tab, int w,
@@ -1061,90 +1104,30 @@ __global__ __launch_bounds__(256) void k_power_grid(chomp_config cfg, TabLayout 
                                                     double* __restrict__ out,
                                                     int* __restrict__ need_slow) {
   const int wave_id = (int)((blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6));
-  if constexpr (SLOW) {
-    if (need_slow[wave_id] == 0) return;
-  }
-  int fa = F_HM, fb = F_HM, fp = F_PPMM;
-  if (w == CHOMP_P_GM) { fa = F_HG; fb = F_HM; fp = F_PPGM; }
-  else if (w == CHOMP_P_GG) { fa = F_HG; fb = F_HG; fp = F_PPGG; }
-  const size_t i0 = 2 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x);
-  const bool have0 = i0 < nk, have1 = i0 + 1 < nk;
-  const bool vec = have1 && ((nk & 1) == 0);     // rows stay 16-byte aligned
-  double k0 = 1.0, k1 = 1.0;
-  if (vec) {
-    const double2 kk = *reinterpret_cast<const double2*>(k + i0);
-    k0 = kk.x; k1 = kk.y;
-  } else {
-    if (have0) k0 = k[i0];
-    if (have1) k1 = k[i0 + 1];
-  }
-  // this block's epochs: [q_lo, q_hi) of the launch's range
+  const PowerFam F = power_families(w);
+  const int NK = L.NK;
+  const KLanes s = load_k_lanes(cfg, NK, k, nk, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+  const int idxu = __builtin_amdgcn_readfirstlane(s.idx0);
+  // Fast path: every k of the wavefront present, in range and in knot interval idxu or
+  // idxu + 1 (a sorted grid straddles at most one knot per wavefront once nk >~ 6500).
+  const bool fast = __all(s.have0 && s.have1 && s.in0 && s.in1 &&
+                          (s.idx0 == idxu || s.idx0 == idxu + 1) &&
+                          (s.idx1 == idxu || s.idx1 == idxu + 1)) &&
+                    idxu + 1 <= NK - 2 && w != CHOMP_P_LIN;
+  if ((threadIdx.x & 63) == 0) need_slow[wave_id] = fast ? 0 : 1;
+  if (!fast) return;
   const int q_lo = blockIdx.y * epochs_per_y;
   int q_hi = q_lo + epochs_per_y;
   if (q_hi > n_epoch) q_hi = n_epoch;
-  const int NK = L.NK;
   const double x0 = log(cfg.k_min);
   const double dx = (log(cfg.k_max) - x0) / (double)(NK - 1);
-  const double lk0 = log(k0), lk1 = log(k1);
-  int idx0 = (int)floor((lk0 - x0) / dx), idx1 = (int)floor((lk1 - x0) / dx);
-  idx0 = idx0 < 0 ? 0 : (idx0 > NK - 2 ? NK - 2 : idx0);
-  idx1 = idx1 < 0 ? 0 : (idx1 > NK - 2 ? NK - 2 : idx1);
-  const bool in0 = k0 >= cfg.k_min && k0 <= cfg.k_max;
-  const bool in1 = k1 >= cfg.k_min && k1 <= cfg.k_max;
-  const int idxu = __builtin_amdgcn_readfirstlane(idx0);
-  // (lanes past the end of k must not take the unguarded fast path)
-  const bool fast =
-      __all(have0 && have1 && in0 && in1 && idx0 == idxu && idx1 == idxu) && w != CHOMP_P_LIN;
-  if constexpr (SLOW) {
-    // Per-lane path: any k, any knot interval.  In-range k still re-use the
-    // Eisenstein-Hu shape across epochs of one cosmology; their 12 coefficients come
-    // through the vector cache.  k outside [k_min, k_max] take the full formula.
-    const double e0 = lk0 - (x0 + dx * (double)idx0), e1 = lk1 - (x0 + dx * (double)idx1);
-    double sh0 = 0.0, sh1 = 0.0;
-    for (int q = q_lo; q < q_hi; ++q) {
-      const int e = epoch0 + q;
-      const Epoch& E = epochs[e];
-      const double* t = tab + (size_t)e * L.stride;
-      double* o = out + (size_t)q * nk + i0;
-      const bool same = q > q_lo && t[L.off_misc + 2] != 0.0;
-      const double A = t[L.off_misc + 1];
-      if (!same && w != CHOMP_P_LIN) {
-        const double T0 = eh_transfer(E, k0), T1 = eh_transfer(E, k1);
-        sh0 = 2.0 * kPi * kPi * exp((3.0 + E.ns) * (lk0 - E.ln_H0)) * T0 * T0 / (k0 * k0 * k0);
-        sh1 = 2.0 * kPi * kPi * exp((3.0 + E.ns) * (lk1 - E.ln_H0)) * T1 * T1 / (k1 * k1 * k1);
-      }
-      if (have0) {
-        double r;
-        if (in0 && w != CHOMP_P_LIN) {
-          const double ha = pp_poly(t + L.off_kpp[fa], idx0, e0);
-          const double hb = pp_poly(t + L.off_kpp[fb], idx0, e0);
-          const double pp = pp_poly(t + L.off_kpp[fp], idx0, e0);
-          r = fma(A * sh0, ha * hb, pp);
-        } else {
-          r = power_lane(cfg, L, E, t, fa, fb, fp, w, k0);
-        }
-        o[0] = r;
-      }
-      if (have1) {
-        double r;
-        if (in1 && w != CHOMP_P_LIN) {
-          const double ha = pp_poly(t + L.off_kpp[fa], idx1, e1);
-          const double hb = pp_poly(t + L.off_kpp[fb], idx1, e1);
-          const double pp = pp_poly(t + L.off_kpp[fp], idx1, e1);
-          r = fma(A * sh1, ha * hb, pp);
-        } else {
-          r = power_lane(cfg, L, E, t, fa, fb, fp, w, k1);
-        }
-        o[1] = r;
-      }
-    }
-    return;
-  }
-  if ((threadIdx.x & 63) == 0) need_slow[wave_id] = fast ? 0 : 1;
-  if (!fast) return;
-  const double d0 = lk0 - (x0 + dx * (double)idxu), d1 = lk1 - (x0 + dx * (double)idxu);
-  const int oa = L.off_kpp[fa] + 4 * idxu, ob = L.off_kpp[fb] + 4 * idxu,
-            op = L.off_kpp[fp] + 4 * idxu;
+  const bool two = !__all(s.idx0 == idxu && s.idx1 == idxu);  // wave-uniform
+  const bool s0 = s.idx0 != idxu, s1 = s.idx1 != idxu;         // lane uses the upper interval
+  const double xa = x0 + dx * (double)idxu, xb = x0 + dx * (double)(idxu + 1);
+  const double d0 = s.lk0 - (s0 ? xb : xa), d1 = s.lk1 - (s1 ? xb : xa);
+  const double k0 = s.k0, k1 = s.k1;
+  const int oa = L.off_kpp[F.fa] + 4 * idxu, ob = L.off_kpp[F.fb] + 4 * idxu,
+            op = L.off_kpp[F.fp] + 4 * idxu;
   double shape0 = 0.0, shape1 = 0.0;             // 2 pi^2 (k/H0)^(3+n) T^2 / k^3
   for (int q = q_lo; q < q_hi; ++q) {
     const int e = epoch0 + q;
@@ -1158,23 +1141,37 @@ __global__ __launch_bounds__(256) void k_power_grid(chomp_config cfg, TabLayout 
     if (!same) {
       const Epoch& E = epochs[e];
       const double T0 = eh_transfer(E, k0), T1 = eh_transfer(E, k1);
-      shape0 = 2.0 * kPi * kPi * exp((3.0 + E.ns) * (lk0 - E.ln_H0)) * T0 * T0 / (k0 * k0 * k0);
-      shape1 = 2.0 * kPi * kPi * exp((3.0 + E.ns) * (lk1 - E.ln_H0)) * T1 * T1 / (k1 * k1 * k1);
+      shape0 = 2.0 * kPi * kPi * exp((3.0 + E.ns) * (s.lk0 - E.ln_H0)) * T0 * T0 / (k0 * k0 * k0);
+      shape1 = 2.0 * kPi * kPi * exp((3.0 + E.ns) * (s.lk1 - E.ln_H0)) * T1 * T1 / (k1 * k1 * k1);
     }
-    const double ha0 = fma(fma(fma(a3, d0, a2), d0, a1), d0, a0);
-    const double hb0 = fma(fma(fma(b3, d0, b2), d0, b1), d0, b0);
-    const double pp0 = fma(fma(fma(p3, d0, p2), d0, p1), d0, p0);
-    const double ha1 = fma(fma(fma(a3, d1, a2), d1, a1), d1, a0);
-    const double hb1 = fma(fma(fma(b3, d1, b2), d1, b1), d1, b0);
-    const double pp1 = fma(fma(fma(p3, d1, p2), d1, p1), d1, p0);
+    double ha0 = fma(fma(fma(a3, d0, a2), d0, a1), d0, a0);
+    double hb0 = fma(fma(fma(b3, d0, b2), d0, b1), d0, b0);
+    double pp0 = fma(fma(fma(p3, d0, p2), d0, p1), d0, p0);
+    double ha1 = fma(fma(fma(a3, d1, a2), d1, a1), d1, a0);
+    double hb1 = fma(fma(fma(b3, d1, b2), d1, b1), d1, b0);
+    double pp1 = fma(fma(fma(p3, d1, p2), d1, p1), d1, p0);
+    if (two) {       // the wavefront straddles a knot: lanes above it use the next piece
+      const double A0 = t[oa + 4], A1 = t[oa + 5], A2 = t[oa + 6], A3 = t[oa + 7];
+      const double B0 = t[ob + 4], B1 = t[ob + 5], B2 = t[ob + 6], B3 = t[ob + 7];
+      const double P0 = t[op + 4], P1 = t[op + 5], P2 = t[op + 6], P3 = t[op + 7];
+      if (s0) {
+        ha0 = fma(fma(fma(A3, d0, A2), d0, A1), d0, A0);
+        hb0 = fma(fma(fma(B3, d0, B2), d0, B1), d0, B0);
+        pp0 = fma(fma(fma(P3, d0, P2), d0, P1), d0, P0);
+      }
+      if (s1) {
+        ha1 = fma(fma(fma(A3, d1, A2), d1, A1), d1, A0);
+        hb1 = fma(fma(fma(B3, d1, B2), d1, B1), d1, B0);
+        pp1 = fma(fma(fma(P3, d1, P2), d1, P1), d1, P0);
+      }
+    }
     const double r0 = fma(A * shape0, ha0 * hb0, pp0);
     const double r1 = fma(A * shape1, ha1 * hb1, pp1);
-    double* o = out + (size_t)q * nk + i0;
-    // Streamed once, never re-read by this launch: 16-byte write-through (sc1)
-    // stores.  Plain stores leave ~0.5 GB of dirty lines in the L2s that the
-    // end-of-kernel release then has to write back (MI355X_MICROARCH.md, rows
-    // "boundary" / "publish-large").
-    if (vec) {
+    double* o = out + (size_t)q * nk + s.i0;
+    // Streamed once, never re-read by this launch: 16-byte write-through (sc1) stores
+    // (plain stores leave ~0.5 GB of dirty lines for the end-of-kernel release to
+    // write back; MI355X_MICROARCH.md rows "boundary" / "publish-large").
+    if (s.vec) {
       typedef float v4f __attribute__((ext_vector_type(4)));
       typedef double v2d __attribute__((ext_vector_type(2)));
       v2d rr = {r0, r1};
@@ -1183,6 +1180,79 @@ __global__ __launch_bounds__(256) void k_power_grid(chomp_config cfg, TabLayout 
     } else {
       __builtin_nontemporal_store(r0, o);
       __builtin_nontemporal_store(r1, o + 1);
+    }
+  }
+}
+
+// The per-lane pass: any k, any knot interval, any order.  1-D grid; every wavefront
+// walks work items (fast-pass wavefront, chunk of <= epochs_per_item epochs) and
+// skips those whose flag is clear.  The per-epoch coefficient loads of this path are
+// a dependent chain, hence the short chunks.  In-range k still re-use the
+// Eisenstein-Hu shape across epochs of one cosmology; k outside [k_min, k_max] take
+// the full formula (halo.py:314-320).
+__global__ __launch_bounds__(256) void k_power_grid_lanes(
+    chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs,
+    const double* __restrict__ tab, int w, int epoch0, int n_epoch, int fast_gx, int fast_gy,
+    int fast_epochs_per_y, int epochs_per_item, const double* __restrict__ k, size_t nk,
+    double* __restrict__ out, const int* __restrict__ need_slow) {
+  const PowerFam F = power_families(w);
+  const int NK = L.NK;
+  const double x0 = log(cfg.k_min);
+  const double dx = (log(cfg.k_max) - x0) / (double)(NK - 1);
+  const int chunks = (fast_epochs_per_y + epochs_per_item - 1) / epochs_per_item;
+  const long n_items = (long)fast_gx * fast_gy * 4 * chunks;
+  const long n_waves = (long)gridDim.x * 4;
+  const int lane = threadIdx.x & 63;
+  for (long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6); item < n_items; item += n_waves) {
+    const int fast_wave = (int)(item / chunks), c = (int)(item % chunks);
+    if (need_slow[fast_wave] == 0) continue;               // wave-uniform
+    const int fy = (fast_wave >> 2) / fast_gx, bx = (fast_wave >> 2) % fast_gx;
+    const int q_lo = fy * fast_epochs_per_y + c * epochs_per_item;
+    int q_hi = q_lo + epochs_per_item;
+    if (q_hi > (fy + 1) * fast_epochs_per_y) q_hi = (fy + 1) * fast_epochs_per_y;
+    if (q_hi > n_epoch) q_hi = n_epoch;
+    const KLanes s = load_k_lanes(cfg, NK, k, nk,
+                                  (size_t)bx * 256 + (size_t)(fast_wave & 3) * 64 + lane);
+    const double e0 = s.lk0 - (x0 + dx * (double)s.idx0), e1 = s.lk1 - (x0 + dx * (double)s.idx1);
+    double sh0 = 0.0, sh1 = 0.0;
+    for (int q = q_lo; q < q_hi; ++q) {
+      const int e = epoch0 + q;
+      const Epoch& E = epochs[e];
+      const double* t = tab + (size_t)e * L.stride;
+      double* o = out + (size_t)q * nk + s.i0;
+      const bool same = q > q_lo && t[L.off_misc + 2] != 0.0;
+      const double A = t[L.off_misc + 1];
+      if (!same && w != CHOMP_P_LIN) {
+        const double T0 = eh_transfer(E, s.k0), T1 = eh_transfer(E, s.k1);
+        sh0 = 2.0 * kPi * kPi * exp((3.0 + E.ns) * (s.lk0 - E.ln_H0)) * T0 * T0 /
+              (s.k0 * s.k0 * s.k0);
+        sh1 = 2.0 * kPi * kPi * exp((3.0 + E.ns) * (s.lk1 - E.ln_H0)) * T1 * T1 /
+              (s.k1 * s.k1 * s.k1);
+      }
+      if (s.have0) {
+        double r;
+        if (s.in0 && w != CHOMP_P_LIN) {
+          const double ha = pp_poly(t + L.off_kpp[F.fa], s.idx0, e0);
+          const double hb = pp_poly(t + L.off_kpp[F.fb], s.idx0, e0);
+          const double pp = pp_poly(t + L.off_kpp[F.fp], s.idx0, e0);
+          r = fma(A * sh0, ha * hb, pp);
+        } else {
+          r = power_lane(cfg, L, E, t, F.fa, F.fb, F.fp, w, s.k0);
+        }
+        o[0] = r;
+      }
+      if (s.have1) {
+        double r;
+        if (s.in1 && w != CHOMP_P_LIN) {
+          const double ha = pp_poly(t + L.off_kpp[F.fa], s.idx1, e1);
+          const double hb = pp_poly(t + L.off_kpp[F.fb], s.idx1, e1);
+          const double pp = pp_poly(t + L.off_kpp[F.fp], s.idx1, e1);
+          r = fma(A * sh1, ha * hb, pp);
+        } else {
+          r = power_lane(cfg, L, E, t, F.fa, F.fb, F.fp, w, s.k1);
+        }
+        o[1] = r;
+      }
     }
   }
 }
