@@ -27,10 +27,27 @@
 
 namespace chomp {
 
+// 64-lane all-reduce of a double on the DPP path: xor-1 / xor-2 inside quads, two
+// row rotations inside the 16-lane rows, then the four row totals through v_readlane
+// (the generic __shfl_xor butterfly lowers to six dependent ds_bpermute round trips
+// per 32-bit half, ~10x the latency).
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v += dpp_move<0xB1>(v);       // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E>(v);       // quad_perm [2,3,0,1]
+  v += dpp_move<0x124>(v);      // row_ror:4
+  v += dpp_move<0x128>(v);      // row_ror:8  -> every lane holds its row's total
+  return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
 }
 
 // Sum over the group.  NW == 1: the group is one wavefront (any number of groups
