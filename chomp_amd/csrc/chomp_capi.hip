@@ -47,13 +47,15 @@ struct chomp_ctx {
   chomp_halo_par* d_profile = nullptr;
   HodDev* d_hod = nullptr;
   double* d_nodes = nullptr;       // node tables of the halo integrals
-  double* d_snodes = nullptr;      // node tables of the sigma(R) integrals
+  double* d_snodes = nullptr;      // node tables of the sigma(R) integrals (per cosmology slot)
+  int* d_slot = nullptr;           // epoch -> cosmology slot
+  int* d_first = nullptr;          // slot -> an epoch with that cosmology
   bool have_epochs = false, have_mass = false, have_halo = false;
   unsigned fam_mask = 0;          // families (F_* bits) with valid splines
   std::vector<char> have_halofit;
   // host shadows of the uploaded parameter blocks: an unchanged block is not
   // re-uploaded (MCMC-style loops re-run the set-up with mostly identical inputs)
-  std::vector<char> sh_cosmo, sh_z, sh_mass, sh_profile, sh_hod;
+  std::vector<char> sh_cosmo, sh_z, sh_mass, sh_profile, sh_hod, sh_slot, sh_first;
 
   // staging for host-pointer calls
   double* d_stage_in = nullptr;
@@ -177,7 +179,8 @@ int setup_constants(chomp_ctx* ctx) {
 int alloc_epochs(chomp_ctx* ctx, size_t n) {
   if (n <= ctx->cap_epoch) return CHOMP_OK;
   void* old[] = {ctx->d_cosmo, ctx->d_z, ctx->d_epochs, ctx->d_search, ctx->d_tab,
-                 ctx->d_mass_par, ctx->d_profile, ctx->d_hod, ctx->d_nodes, ctx->d_snodes};
+                 ctx->d_mass_par, ctx->d_profile, ctx->d_hod, ctx->d_nodes, ctx->d_snodes,
+                 ctx->d_slot, ctx->d_first};
   for (void* p : old)
     if (p) HIPCHK(hipFree(p));
   HIPCHK(hipMalloc(&ctx->d_cosmo, n * sizeof(chomp_cosmo)));
@@ -190,9 +193,11 @@ int alloc_epochs(chomp_ctx* ctx, size_t n) {
   HIPCHK(hipMalloc(&ctx->d_hod, n * sizeof(HodDev)));
   HIPCHK(hipMalloc(&ctx->d_nodes, n * 3 * (size_t)kNodeStride * sizeof(double)));
   HIPCHK(hipMalloc(&ctx->d_snodes, n * (size_t)kSigmaStride * sizeof(double)));
+  HIPCHK(hipMalloc(&ctx->d_slot, n * sizeof(int)));
+  HIPCHK(hipMalloc(&ctx->d_first, n * sizeof(int)));
   ctx->cap_epoch = n;
   ctx->sh_cosmo.clear(); ctx->sh_z.clear(); ctx->sh_mass.clear();
-  ctx->sh_profile.clear(); ctx->sh_hod.clear();
+  ctx->sh_profile.clear(); ctx->sh_hod.clear(); ctx->sh_slot.clear(); ctx->sh_first.clear();
   return CHOMP_OK;
 }
 
@@ -263,7 +268,7 @@ void chomp_ctx_destroy(chomp_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   void* ptrs[] = {ctx->d_sici, ctx->d_j0, ctx->d_j2, ctx->d_tinker, ctx->d_gl16,
                   ctx->d_cand, ctx->d_cosmo, ctx->d_z, ctx->d_epochs, ctx->d_search,
-                  ctx->d_tab, ctx->d_mass_par, ctx->d_profile, ctx->d_hod, ctx->d_nodes, ctx->d_snodes,
+                  ctx->d_tab, ctx->d_mass_par, ctx->d_profile, ctx->d_hod, ctx->d_nodes, ctx->d_snodes, ctx->d_slot, ctx->d_first,
                   ctx->d_stage_in, ctx->d_stage_in2, ctx->d_stage_out, ctx->d_work, ctx->d_flags};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -303,11 +308,28 @@ int chomp_epochs_set(chomp_ctx* ctx, size_t n_epoch, const chomp_cosmo* cosmo,
   if (rc) return rc;
   rc = upload(ctx, ctx->d_z, z, n_epoch * sizeof(double), ctx->sh_z);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_sigma_nodes, dim3((kSigmaCount + 255) / 256, (unsigned)n_epoch), dim3(256),
-                     0, ctx->stream, ctx->cfg, ctx->d_cosmo, ctx->d_z, ctx->d_snodes);
+  // cosmology-only work (sigma node table, sigma_8 integral) is shared by the epochs of
+  // one cosmology: slot = index of the first epoch with identical parameters
+  std::vector<int> slot(n_epoch), first;
+  for (size_t i = 0; i < n_epoch; ++i) {
+    int s_found = -1;
+    for (size_t s = 0; s < first.size(); ++s)
+      if (std::memcmp(&cosmo[first[s]], &cosmo[i], sizeof(chomp_cosmo)) == 0) { s_found = (int)s; break; }
+    if (s_found < 0) { s_found = (int)first.size(); first.push_back((int)i); }
+    slot[i] = s_found;
+  }
+  const size_t n_slots = first.size();
+  first.resize(n_epoch, 0);
+  rc = upload(ctx, ctx->d_slot, slot.data(), n_epoch * sizeof(int), ctx->sh_slot);
+  if (rc) return rc;
+  rc = upload(ctx, ctx->d_first, first.data(), n_epoch * sizeof(int), ctx->sh_first);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_sigma_nodes, dim3((kSigmaCount + 255) / 256 + 1, (unsigned)n_slots),
+                     dim3(256), 0, ctx->stream, ctx->cfg, ctx->d_cosmo, ctx->d_z, ctx->d_first,
+                     ctx->d_snodes);
   hipLaunchKernelGGL(k_epoch_init, dim3((unsigned)n_epoch, 2), dim3(64 * kInitNW), 0, ctx->stream,
                      ctx->cfg, ctx->d_cosmo, ctx->d_z, ctx->d_epochs, ctx->d_search,
-                     ctx->d_cand, ctx->d_snodes);
+                     ctx->d_cand, ctx->d_snodes, ctx->d_slot);
   HIPCHK(hipGetLastError());
   ctx->have_epochs = true;
   return CHOMP_OK;

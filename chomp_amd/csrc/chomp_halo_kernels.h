@@ -95,15 +95,22 @@ __device__ __forceinline__ void copy_doubles(double* dst, const double* src, int
 // level-kSigmaLevel Romberg grid (level-major order) by k_sigma_nodes.
 constexpr int kSigmaLevel = 13;
 constexpr int kSigmaCount = (1 << kSigmaLevel) + 1;
-constexpr int kSigmaStride = 2 * kSigmaCount;      // doubles per epoch: k[], d2[]
+constexpr int kSigmaStride = 2 * kSigmaCount + 8;  // doubles per cosmology: k[], d2[], then
+                                                   // I8 = int dlnk d2 W(8k)^2 (sigma_8 norm.)
 
-// grid (ceil(kSigmaCount / 256), n_epoch), block 256.
+// Everything here depends on the cosmology only, not on z, so it is built once per
+// distinct cosmology of the batch ("slot"; the z-axis of a (k, z) grid is one slot).
+// grid (ceil(kSigmaCount / 256) + 1, n_slots), block 256; first[s] = an epoch that
+// has cosmology s.  The extra x-block does the sigma_8 integral (cosmology.py:118-119)
+// by direct evaluation.
 __global__ __launch_bounds__(256) void k_sigma_nodes(chomp_config cfg,
                                                      const chomp_cosmo* __restrict__ cosmo,
                                                      const double* __restrict__ zin,
+                                                     const int* __restrict__ first,
                                                      double* __restrict__ snodes) {
   __shared__ Epoch E;
-  const int e = blockIdx.y;
+  __shared__ double red[romberg_scratch<4, 1>()];
+  const int slot = blockIdx.y, e = first[slot];
   if (threadIdx.x == 0) {
     const chomp_cosmo c = cosmo[e];
     E.om0 = c.omega_m0; E.ob0 = c.omega_b0; E.ol0 = c.omega_l0; E.or0 = c.omega_r0;
@@ -112,6 +119,16 @@ __global__ __launch_bounds__(256) void k_sigma_nodes(chomp_config cfg,
     epoch_background(E, cfg.cosmo_precision, cfg.k_min, cfg.k_max);
   }
   __syncthreads();
+  double* n = snodes + (size_t)slot * kSigmaStride;
+  if (blockIdx.x == gridDim.x - 1) {
+    double lo, hi;
+    sigma_limits(E, 8.0, &lo, &hi);
+    SigmaIntegrand f{&E, 8.0};                    // sigma_norm = 1: amp * I8
+    const double s2 = romberg1<4>(f, lo, hi, cfg.global_precision, cfg.cosmo_precision,
+                                  cfg.divmax, red);
+    if (threadIdx.x == 0) n[2 * kSigmaCount] = s2 / E.amp;
+    return;
+  }
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= kSigmaCount) return;
   const double a = log(cfg.k_min), b = log(cfg.k_max);
@@ -127,7 +144,6 @@ __global__ __launch_bounds__(256) void k_sigma_nodes(chomp_config cfg,
   }
   const double k = exp(x);
   const double T = eh_transfer(E, k);
-  double* n = snodes + (size_t)e * kSigmaStride;
   n[idx] = k;
   n[kSigmaCount + idx] = exp((3.0 + E.ns) * (x - E.ln_H0)) * T * T;
 }
@@ -231,7 +247,7 @@ constexpr int kInitNW = 8;       // wavefronts per k_epoch_init block
 __global__ __launch_bounds__(64 * kInitNW) void k_epoch_init(
     chomp_config cfg, const chomp_cosmo* __restrict__ cosmo, const double* __restrict__ zin,
     Epoch* __restrict__ epochs, double* __restrict__ search, const double* __restrict__ cand,
-    const double* __restrict__ snodes) {
+    const double* __restrict__ snodes, const int* __restrict__ slots) {
   __shared__ Epoch E;
   __shared__ double red[romberg_scratch<kInitNW, 1>()];
   const int e = blockIdx.x, side = blockIdx.y;
@@ -243,12 +259,13 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_init(
     E.tcmb = c.cmb_temp; E.h = c.h; E.sigma8 = c.sigma_8; E.ns = c.n_scalar;
     E.z = zin[e];
     epoch_background(E, cfg.cosmo_precision, cfg.k_min, cfg.k_max);
+    E.cosmo_slot = slots[e];
   }
   __syncthreads();
-  const double* snode = snodes + (size_t)e * kSigmaStride;
-  {   // sigma_8 normalisation, cosmology.py:118-119
-    const double s2 = sigma2_block<kInitNW>(E, snode, 8.0, cfg, cfg.cosmo_precision, red);
-    __syncthreads();
+  const double* snode = snodes + (size_t)E.cosmo_slot * kSigmaStride;
+  {   // sigma_8 normalisation, cosmology.py:118-119: sigma_r(8)^2 = amp * I8 with the
+      // cosmology-only integral I8 from k_sigma_nodes
+    const double s2 = E.amp * snode[2 * kSigmaCount];
     if (threadIdx.x == 0) E.sigma_norm = E.sigma8 * E.growth / sqrt(s2);
     __syncthreads();
   }
@@ -359,7 +376,7 @@ __global__ __launch_bounds__(256) void k_nu_table(chomp_config cfg, TabLayout L,
   __syncthreads();
   const double ln_lo = search[(e * 2 + 0) * 2], ln_hi = search[(e * 2 + 1) * 2];
   const double lnm = linspace_at(ln_lo, ln_hi, L.NM, i);
-  const double nu = nu_of_mass_block<4>(E, snodes + (size_t)e * kSigmaStride, exp(lnm), cfg,
+  const double nu = nu_of_mass_block<4>(E, snodes + (size_t)E.cosmo_slot * kSigmaStride, exp(lnm), cfg,
                                         cfg.cosmo_precision, red);
   if (threadIdx.x == 0) {
     double* t = tab + (size_t)e * L.stride;
@@ -1268,7 +1285,7 @@ __global__ __launch_bounds__(256) void k_sigma_r(chomp_config cfg,
   copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
                kEpochDoubles);
   __syncthreads();
-  const double s2 = sigma2_block<4>(E, snodes + (size_t)e * kSigmaStride, scale[blockIdx.x], cfg,
+  const double s2 = sigma2_block<4>(E, snodes + (size_t)E.cosmo_slot * kSigmaStride, scale[blockIdx.x], cfg,
                                     cfg.cosmo_precision, red);
   if (threadIdx.x == 0) out[blockIdx.x] = sqrt(s2);
 }

@@ -417,7 +417,7 @@ struct Epoch {
   double ln_mass_min, ln_mass_max, nu_min, nu_max, m_star, f_norm, bias_norm;
   double t_alpha, t_beta, t_gamma, t_phi, t_eta;     // Tinker f(nu)
   double tb_A, tb_a, tb_C, tb_dca;                   // Tinker bias constants
-  int n_search, pad0;
+  int n_search, cosmo_slot;        // cosmo_slot: index of this epoch's cosmology-only tables
   // halo profile (halo.py:71-83, 873-902)
   double c0, beta, prof_delta_v, ln_rv_const, ln_c_const;
   // HOD (hod.py:156-186)
