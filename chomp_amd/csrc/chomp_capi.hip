@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -62,8 +63,12 @@ struct chomp_ctx {
   double* d_stage_in2 = nullptr;
   double* d_stage_out = nullptr;
   double* d_work = nullptr;
-  int* d_flags = nullptr;          // per-wavefront slow-path flags of k_power_grid
-  size_t cap_flags = 0;
+  int* d_slow = nullptr;           // Stage E: 2 counters + list of k groups for the per-lane pass
+  int* d_winfo = nullptr;          // Stage E: per k group knot interval / flags (k_power_prep)
+  double* d_ktab = nullptr;        // Stage E: per-k (offset, shape) table (k_power_prep)
+  size_t cap_slow = 0, cap_winfo = 0, cap_ktab = 0;
+  int slow_parity = 0;
+  std::vector<int> slot;           // host copy: epoch -> cosmology slot
   size_t cap_in = 0, cap_in2 = 0, cap_out = 0, cap_work = 0;
 
   // projection
@@ -269,7 +274,8 @@ void chomp_ctx_destroy(chomp_ctx* ctx) {
   void* ptrs[] = {ctx->d_sici, ctx->d_j0, ctx->d_j2, ctx->d_tinker, ctx->d_gl16,
                   ctx->d_cand, ctx->d_cosmo, ctx->d_z, ctx->d_epochs, ctx->d_search,
                   ctx->d_tab, ctx->d_mass_par, ctx->d_profile, ctx->d_hod, ctx->d_nodes, ctx->d_snodes, ctx->d_slot, ctx->d_first,
-                  ctx->d_stage_in, ctx->d_stage_in2, ctx->d_stage_out, ctx->d_work, ctx->d_flags};
+                  ctx->d_stage_in, ctx->d_stage_in2, ctx->d_stage_out, ctx->d_work, ctx->d_slow,
+                  ctx->d_winfo, ctx->d_ktab};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   proj_free(ctx->proj);
@@ -319,6 +325,7 @@ int chomp_epochs_set(chomp_ctx* ctx, size_t n_epoch, const chomp_cosmo* cosmo,
     slot[i] = s_found;
   }
   const size_t n_slots = first.size();
+  ctx->slot = slot;
   first.resize(n_epoch, 0);
   rc = upload(ctx, ctx->d_slot, slot.data(), n_epoch * sizeof(int), ctx->sh_slot);
   if (rc) return rc;
@@ -461,25 +468,56 @@ int chomp_power_range(chomp_ctx* ctx, int which, size_t epoch0, size_t n, const 
   const TabLayout& L = ctx->L;
   if ((which & CHOMP_P_HALOFIT) == 0 &&
       (reinterpret_cast<uintptr_t>(dk) % 16 == 0) && (reinterpret_cast<uintptr_t>(dout) % 16 == 0)) {
-    // enough blocks to fill 256 CUs: split the epochs over blockIdx.y when nk is small
     const unsigned gx = (unsigned)((nk + 511) / 512);
-    unsigned gy = (2048 + gx - 1) / gx;
-    if (gy > n) gy = (unsigned)n;
-    const int epy = (int)((n + gy - 1) / gy);
-    gy = (unsigned)((n + epy - 1) / epy);
-    rc = ensure(ctx, &ctx->d_flags, &ctx->cap_flags, (size_t)gx * gy * 4);
+    const size_t groups = (nk + 127) / 128;
+    const size_t had = ctx->cap_slow;
+    rc = ensure(ctx, &ctx->d_slow, &ctx->cap_slow, groups + 2);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_power_grid, dim3(gx, gy), dim3(256), 0, ctx->stream, ctx->cfg, L,
-                       ctx->d_epochs, ctx->d_tab, which & 15, (int)epoch0, (int)n, epy, dk, nk,
-                       dout, ctx->d_flags);
-    // per-lane pass over the flagged wavefronts, in items of <= 8 epochs
-    const int per_item = epy < 8 ? epy : 8;
-    const long items = (long)gx * gy * 4 * ((epy + per_item - 1) / per_item);
-    unsigned gl = (unsigned)((items + 3) / 4);
-    if (gl > 1024) gl = 1024;
-    hipLaunchKernelGGL(k_power_grid_lanes, dim3(gl), dim3(256), 0, ctx->stream, ctx->cfg, L,
-                       ctx->d_epochs, ctx->d_tab, which & 15, (int)epoch0, (int)n, (int)gx,
-                       (int)gy, epy, per_item, dk, nk, dout, ctx->d_flags);
+    if (ctx->cap_slow != had) {                    // fresh buffer: clear both counters
+      HIPCHK(hipMemsetAsync(ctx->d_slow, 0, 2 * sizeof(int), ctx->stream));
+    }
+    const int parity = ctx->slow_parity;
+    ctx->slow_parity ^= 1;
+    bool one_cosmology = true;
+    for (size_t i = 1; i < n; ++i) one_cosmology &= ctx->slot[epoch0 + i] == ctx->slot[epoch0];
+    const int w = which & 15;
+    size_t stream_min = (size_t)1 << 22;           // samples; below this the launches dominate
+    if (const char* ev = getenv("CHOMP_E_STREAM_MIN")) stream_min = (size_t)atoll(ev);
+    if (one_cosmology && w != CHOMP_P_LIN && nk % 2 == 0 && nk * n >= stream_min) {
+      const unsigned gx8 = (gx + 7) / 8 * 8;
+      rc = ensure(ctx, &ctx->d_winfo, &ctx->cap_winfo, (size_t)gx8 * 4);
+      if (rc) return rc;
+      rc = ensure(ctx, &ctx->d_ktab, &ctx->cap_ktab, (size_t)gx8 * 1024);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_power_prep, dim3(gx8), dim3(256), 0, ctx->stream, ctx->cfg, L,
+                         ctx->d_epochs, (int)epoch0, w, dk, nk, ctx->d_ktab, ctx->d_winfo,
+                         ctx->d_slow, parity);
+      int per = n % 2 == 0 ? 2 : 1;
+      if (const char* ev = getenv("CHOMP_E_PER")) { int v = atoi(ev); if (v > 0 && n % v == 0) per = v; }
+      const unsigned gy = (unsigned)(n / per);
+#define CHOMP_STREAM(P)                                                                   \
+      hipLaunchKernelGGL(k_power_stream<P>, dim3(gx8, gy), dim3(256), 0, ctx->stream, L,  \
+                         ctx->d_tab, w, (int)epoch0, ctx->d_ktab, ctx->d_winfo, nk, dout)
+      switch (per) {
+        case 1: CHOMP_STREAM(1); break;
+        case 4: CHOMP_STREAM(4); break;
+        default: CHOMP_STREAM(2); break;
+      }
+#undef CHOMP_STREAM
+    } else {
+      // enough blocks to fill 256 CUs: split the epochs over blockIdx.y when nk is small
+      unsigned gy = (2048 + gx - 1) / gx;
+      if (gy > n) gy = (unsigned)n;
+      const int epy = (int)((n + gy - 1) / gy);
+      gy = (unsigned)((n + epy - 1) / epy);
+      hipLaunchKernelGGL(k_power_grid, dim3(gx, gy), dim3(256), 0, ctx->stream, ctx->cfg, L,
+                         ctx->d_epochs, ctx->d_tab, w, (int)epoch0, (int)n, epy, 1, dk, nk,
+                         dout, ctx->d_slow, parity);
+    }
+    // per-lane pass over the listed k groups
+    hipLaunchKernelGGL(k_power_grid_lanes, dim3(1024), dim3(256), 0, ctx->stream, ctx->cfg, L,
+                       ctx->d_epochs, ctx->d_tab, w, (int)epoch0, (int)n, dk, nk, dout,
+                       ctx->d_slow, parity);
   } else {
     unsigned gx = (unsigned)((nk + 255) / 256);
     if (gx > 2048) gx = 2048;

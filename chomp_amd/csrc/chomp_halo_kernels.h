@@ -1092,16 +1092,29 @@ __device__ __forceinline__ KLanes load_k_lanes(const chomp_config& cfg, int NK,
   }
   const double x0 = log(cfg.k_min);
   const double dx = (log(cfg.k_max) - x0) / (double)(NK - 1);
-  s.lk0 = log(s.k0);
-  s.lk1 = log(s.k1);
-  s.idx0 = (int)floor((s.lk0 - x0) / dx);
-  s.idx1 = (int)floor((s.lk1 - x0) / dx);
+  const double inv_dx = 1.0 / dx;
+  s.lk0 = fast_log(s.k0);
+  s.lk1 = fast_log(s.k1);
+  s.idx0 = (int)floor((s.lk0 - x0) * inv_dx);
+  s.idx1 = (int)floor((s.lk1 - x0) * inv_dx);
   s.idx0 = s.idx0 < 0 ? 0 : (s.idx0 > NK - 2 ? NK - 2 : s.idx0);
   s.idx1 = s.idx1 < 0 ? 0 : (s.idx1 > NK - 2 ? NK - 2 : s.idx1);
   s.in0 = s.k0 >= cfg.k_min && s.k0 <= cfg.k_max;
   s.in1 = s.k1 >= cfg.k_min && s.k1 <= cfg.k_max;
   return s;
 }
+
+// 16-byte write-through store (sc1).  Issued from inline asm, so the compiler's hazard
+// recogniser does not see a VMEM store: a store of more than 64 bits must not be
+// followed directly by a VALU write of its data registers, hence the trailing s_nop.
+__device__ __forceinline__ void store_wt16(double* p, double r0, double r1) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  v2d rr = {r0, r1};
+  v4f bits = __builtin_bit_cast(v4f, rr);
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" : : "v"(p), "v"(bits) : "memory");
+}
+
 
 struct PowerFam { int fa, fb, fp; };
 __device__ __forceinline__ PowerFam power_families(int w) {
@@ -1110,29 +1123,48 @@ __device__ __forceinline__ PowerFam power_families(int w) {
   return PowerFam{F_HM, F_HM, F_PPMM};
 }
 
-// The streaming pass.  grid (ceil(nk / 512), ceil(n_epoch / epochs_per_y)), block 256.
-// A wavefront whose k do not qualify for the fast path only raises its flag in
-// `need_slow` (one int per wavefront of the grid) for k_power_grid_lanes.
+// Wavefronts (groups of 128 consecutive k) that cannot take a streaming path are
+// collected in a compact list for k_power_grid_lanes.  slow[0..1] are two counters used
+// by alternate launches (`parity`): a launch appends through slow[parity] and clears
+// slow[parity ^ 1] for the next one, so no separate memset is needed (launches of one
+// context are stream-ordered).  slow[2...] is the list.
+__device__ __forceinline__ void slow_list_begin(int* slow, int parity) {
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) slow[parity ^ 1] = 0;
+}
+__device__ __forceinline__ void slow_list_append(int* slow, int parity, int k_group) {
+  const int at = atomicAdd(&slow[parity], 1);
+  slow[2 + at] = k_group;
+}
+
+// The row-walking streaming pass (epochs of different cosmologies, or small grids).
+// grid (ceil(nk / 512), ceil(n_epoch / epochs_per_y)), block 256.  A wavefront whose k
+// do not qualify for the fast path only enters itself in the slow list.
 __global__ __launch_bounds__(256) void k_power_grid(chomp_config cfg, TabLayout L,
                                                     const Epoch* __restrict__ epochs,
                                                     const double* __restrict__ tab, int w,
                                                     int epoch0, int n_epoch, int epochs_per_y,
+                                                    int rot,
                                                     const double* __restrict__ k, size_t nk,
                                                     double* __restrict__ out,
-                                                    int* __restrict__ need_slow) {
-  const int wave_id = (int)((blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6));
+                                                    int* __restrict__ slow, int parity) {
+  slow_list_begin(slow, parity);
+  const int k_group = (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
   const PowerFam F = power_families(w);
   const int NK = L.NK;
   const KLanes s = load_k_lanes(cfg, NK, k, nk, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
   const int idxu = __builtin_amdgcn_readfirstlane(s.idx0);
   // Fast path: every k of the wavefront present, in range and in knot interval idxu or
-  // idxu + 1 (a sorted grid straddles at most one knot per wavefront once nk >~ 6500).
+  // idxu + 1 (a sorted grid straddles at most one knot per wavefront once nk >~ 6500;
+  // indices are clamped to NK - 2, so idxu + 1 never runs past the last piece).
   const bool fast = __all(s.have0 && s.have1 && s.in0 && s.in1 &&
                           (s.idx0 == idxu || s.idx0 == idxu + 1) &&
                           (s.idx1 == idxu || s.idx1 == idxu + 1)) &&
-                    idxu + 1 <= NK - 2 && w != CHOMP_P_LIN;
-  if ((threadIdx.x & 63) == 0) need_slow[wave_id] = fast ? 0 : 1;
-  if (!fast) return;
+                    w != CHOMP_P_LIN;
+  if (!fast) {
+    if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && (size_t)k_group * 128 < nk)
+      slow_list_append(slow, parity, k_group);
+    return;
+  }
   const int q_lo = blockIdx.y * epochs_per_y;
   int q_hi = q_lo + epochs_per_y;
   if (q_hi > n_epoch) q_hi = n_epoch;
@@ -1146,28 +1178,41 @@ __global__ __launch_bounds__(256) void k_power_grid(chomp_config cfg, TabLayout 
   const int oa = L.off_kpp[F.fa] + 4 * idxu, ob = L.off_kpp[F.fb] + 4 * idxu,
             op = L.off_kpp[F.fp] + 4 * idxu;
   double shape0 = 0.0, shape1 = 0.0;             // 2 pi^2 (k/H0)^(3+n) T^2 / k^3
-  for (int q = q_lo; q < q_hi; ++q) {
-    const int e = epoch0 + q;
-    const double* t = tab + (size_t)e * L.stride;
-    // wave-uniform operands: through the scalar cache
-    const double A = t[L.off_misc + 1];
-    const bool same = q > q_lo && t[L.off_misc + 2] != 0.0;
-    const double a0 = t[oa], a1 = t[oa + 1], a2 = t[oa + 2], a3 = t[oa + 3];
-    const double b0 = t[ob], b1 = t[ob + 1], b2 = t[ob + 2], b3 = t[ob + 3];
-    const double p0 = t[op], p1 = t[op + 1], p2 = t[op + 2], p3 = t[op + 3];
+  // Blocks start their walk at different rows (rows of a large grid are a power-of-two
+  // stride apart: in lockstep every wavefront would hit the same HBM channels).
+  const int cnt = q_hi - q_lo;
+  int q = q_lo + (int)((blockIdx.x * (unsigned)rot) % (unsigned)cnt);
+  // wave-uniform operands of one epoch: through the scalar cache, fetched one epoch
+  // ahead of their use so that the loop never waits on a scalar load
+  struct Row { double A, flag, a0, a1, a2, a3, b0, b1, b2, b3, p0, p1, p2, p3; };
+  auto fetch = [&](int qq) {
+    const double* t = tab + (size_t)(epoch0 + qq) * L.stride;
+    return Row{t[L.off_misc + 1], t[L.off_misc + 2],
+               t[oa], t[oa + 1], t[oa + 2], t[oa + 3],
+               t[ob], t[ob + 1], t[ob + 2], t[ob + 3],
+               t[op], t[op + 1], t[op + 2], t[op + 3]};
+  };
+  Row nxt = fetch(q);
+  for (int j = 0; j < cnt; ++j) {
+    const Row c = nxt;
+    const int qc = q;
+    ++q;
+    if (q == q_hi) q = q_lo;
+    nxt = fetch(q);                              // (one harmless re-fetch on the last trip)
+    const bool same = j > 0 && qc > q_lo && c.flag != 0.0;
     if (!same) {
-      const Epoch& E = epochs[e];
-      const double T0 = eh_transfer(E, k0), T1 = eh_transfer(E, k1);
-      shape0 = 2.0 * kPi * kPi * exp((3.0 + E.ns) * (s.lk0 - E.ln_H0)) * T0 * T0 / (k0 * k0 * k0);
-      shape1 = 2.0 * kPi * kPi * exp((3.0 + E.ns) * (s.lk1 - E.ln_H0)) * T1 * T1 / (k1 * k1 * k1);
+      const Epoch& E = epochs[epoch0 + qc];
+      shape0 = power_shape(E, s.lk0, k0);
+      shape1 = power_shape(E, s.lk1, k1);
     }
-    double ha0 = fma(fma(fma(a3, d0, a2), d0, a1), d0, a0);
-    double hb0 = fma(fma(fma(b3, d0, b2), d0, b1), d0, b0);
-    double pp0 = fma(fma(fma(p3, d0, p2), d0, p1), d0, p0);
-    double ha1 = fma(fma(fma(a3, d1, a2), d1, a1), d1, a0);
-    double hb1 = fma(fma(fma(b3, d1, b2), d1, b1), d1, b0);
-    double pp1 = fma(fma(fma(p3, d1, p2), d1, p1), d1, p0);
+    double ha0 = fma(fma(fma(c.a3, d0, c.a2), d0, c.a1), d0, c.a0);
+    double hb0 = fma(fma(fma(c.b3, d0, c.b2), d0, c.b1), d0, c.b0);
+    double pp0 = fma(fma(fma(c.p3, d0, c.p2), d0, c.p1), d0, c.p0);
+    double ha1 = fma(fma(fma(c.a3, d1, c.a2), d1, c.a1), d1, c.a0);
+    double hb1 = fma(fma(fma(c.b3, d1, c.b2), d1, c.b1), d1, c.b0);
+    double pp1 = fma(fma(fma(c.p3, d1, c.p2), d1, c.p1), d1, c.p0);
     if (two) {       // the wavefront straddles a knot: lanes above it use the next piece
+      const double* t = tab + (size_t)(epoch0 + qc) * L.stride;
       const double A0 = t[oa + 4], A1 = t[oa + 5], A2 = t[oa + 6], A3 = t[oa + 7];
       const double B0 = t[ob + 4], B1 = t[ob + 5], B2 = t[ob + 6], B3 = t[ob + 7];
       const double P0 = t[op + 4], P1 = t[op + 5], P2 = t[op + 6], P3 = t[op + 7];
@@ -1182,18 +1227,14 @@ __global__ __launch_bounds__(256) void k_power_grid(chomp_config cfg, TabLayout 
         pp1 = fma(fma(fma(P3, d1, P2), d1, P1), d1, P0);
       }
     }
-    const double r0 = fma(A * shape0, ha0 * hb0, pp0);
-    const double r1 = fma(A * shape1, ha1 * hb1, pp1);
-    double* o = out + (size_t)q * nk + s.i0;
+    const double r0 = fma(c.A * shape0, ha0 * hb0, pp0);
+    const double r1 = fma(c.A * shape1, ha1 * hb1, pp1);
+    double* o = out + (size_t)qc * nk + s.i0;
     // Streamed once, never re-read by this launch: 16-byte write-through (sc1) stores
     // (plain stores leave ~0.5 GB of dirty lines for the end-of-kernel release to
     // write back; MI355X_MICROARCH.md rows "boundary" / "publish-large").
     if (s.vec) {
-      typedef float v4f __attribute__((ext_vector_type(4)));
-      typedef double v2d __attribute__((ext_vector_type(2)));
-      v2d rr = {r0, r1};
-      v4f bits = __builtin_bit_cast(v4f, rr);
-      asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(o), "v"(bits) : "memory");
+      store_wt16(o, r0, r1);
     } else {
       __builtin_nontemporal_store(r0, o);
       __builtin_nontemporal_store(r1, o + 1);
@@ -1201,35 +1242,154 @@ __global__ __launch_bounds__(256) void k_power_grid(chomp_config cfg, TabLayout 
   }
 }
 
+// ---- large grids of one cosmology: k_power_prep + k_power_stream ------------------
+// HBM likes the output written in address order by short-lived wavefronts (a kernel
+// whose threads each walk all rows of a 2^20 x 64 grid reaches ~4.5 TB/s of stores, the
+// same stores issued row-major by (k chunk, few rows) blocks ~6.5 TB/s).  So everything
+// that depends on k alone is tabulated once by k_power_prep -- 16 B per k: the offset of
+// ln k in its knot interval and the Eisenstein-Hu shape 2 pi^2 (k/H0)^(3+n) T^2 / k^3 --
+// and k_power_stream, launched row-major over (k chunk, PER rows), re-reads that table
+// from L2 (a k chunk always lands on the same XCD: gridDim.x is a multiple of 8) and
+// does 3 cubics + 1 multiply-add per sample.
+constexpr int kWaveIdxMask = 0xffff, kWaveSlow = 1 << 16, kWaveTwo = 1 << 17;
+
+// grid roundup8(ceil(nk / 512)), block 256.  ktab[2 i] = ln k_i - x_idx, ktab[2 i + 1] = shape_i,
+// negative when k_i lies in the upper one of the wavefront's two knot intervals;
+// winfo[g] = lowest knot interval of k group g | kWaveTwo | kWaveSlow.
+__global__ __launch_bounds__(256) void k_power_prep(chomp_config cfg, TabLayout L,
+                                                    const Epoch* __restrict__ epochs,
+                                                    int e_shape, int w,
+                                                    const double* __restrict__ k, size_t nk,
+                                                    double* __restrict__ ktab,
+                                                    int* __restrict__ winfo,
+                                                    int* __restrict__ slow, int parity) {
+  slow_list_begin(slow, parity);
+  const int k_group = (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int NK = L.NK;
+  const size_t ti = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const KLanes s = load_k_lanes(cfg, NK, k, nk, ti);
+  const int idxu = __builtin_amdgcn_readfirstlane(s.idx0);
+  const bool fast = __all(s.have0 && s.have1 && s.in0 && s.in1 &&
+                          (s.idx0 == idxu || s.idx0 == idxu + 1) &&
+                          (s.idx1 == idxu || s.idx1 == idxu + 1)) &&
+                    w != CHOMP_P_LIN;
+  const bool two = !__all(s.idx0 == idxu && s.idx1 == idxu);
+  if ((threadIdx.x & 63) == 0) {
+    winfo[k_group] = idxu | (two ? kWaveTwo : 0) | (fast ? 0 : kWaveSlow);
+    if (!fast && (size_t)k_group * 128 < nk) slow_list_append(slow, parity, k_group);
+  }
+  if (!fast) return;
+  const Epoch& E = epochs[e_shape];
+  const double x0 = log(cfg.k_min);
+  const double dx = (log(cfg.k_max) - x0) / (double)(NK - 1);
+  const bool s0 = s.idx0 != idxu, s1 = s.idx1 != idxu;
+  const double xa = x0 + dx * (double)idxu, xb = x0 + dx * (double)(idxu + 1);
+  const double sh0 = power_shape(E, s.lk0, s.k0), sh1 = power_shape(E, s.lk1, s.k1);
+  double4 v;
+  v.x = s.lk0 - (s0 ? xb : xa); v.y = s0 ? -sh0 : sh0;
+  v.z = s.lk1 - (s1 ? xb : xa); v.w = s1 ? -sh1 : sh1;
+  *reinterpret_cast<double4*>(ktab + 4 * ti) = v;
+}
+
+// grid (roundup8(ceil(nk / 512)), ceil(n_epoch / PER)), block 256; blockIdx.x fastest =
+// row-major over the output.  nk even, out 16-byte aligned; winfo covers every k group
+// of the (padded) grid, groups past nk are marked slow.  n_epoch is a multiple of PER
+// (the host picks PER accordingly).
+template <int PER>
+__global__ __launch_bounds__(256) void k_power_stream(TabLayout L, const double* __restrict__ tab,
+                                                      int w, int epoch0,
+                                                      const double* __restrict__ ktab,
+                                                      const int* __restrict__ winfo, size_t nk,
+                                                      double* __restrict__ out) {
+  const int k_group = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  const int info = winfo[k_group];
+  const size_t ti = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const double4 v = *reinterpret_cast<const double4*>(ktab + 4 * ti);   // (padded: in bounds)
+  if (info & kWaveSlow) return;
+  const int idxu = info & kWaveIdxMask;
+  const bool two = (info & kWaveTwo) != 0;
+  const PowerFam F = power_families(w);
+  const int oa = L.off_kpp[F.fa] + 4 * idxu, ob = L.off_kpp[F.fb] + 4 * idxu,
+            op = L.off_kpp[F.fp] + 4 * idxu;
+  const int q_lo = blockIdx.y * PER;
+  // wave-uniform operands of the PER rows: all fetched through the scalar cache before
+  // the first use
+  struct Row { double A, a0, a1, a2, a3, b0, b1, b2, b3, p0, p1, p2, p3; };
+  Row r[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const double* t = tab + (size_t)(epoch0 + q_lo + j) * L.stride;
+    r[j] = Row{t[L.off_misc + 1], t[oa], t[oa + 1], t[oa + 2], t[oa + 3],
+               t[ob], t[ob + 1], t[ob + 2], t[ob + 3], t[op], t[op + 1], t[op + 2], t[op + 3]};
+  }
+  const double d0 = v.x, d1 = v.z;
+  const bool s0 = v.y < 0.0, s1 = v.w < 0.0;
+  const double shape0 = fabs(v.y), shape1 = fabs(v.w);
+  double* o = out + (size_t)q_lo * nk + 2 * ti;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const Row& c = r[j];
+    double ha0 = fma(fma(fma(c.a3, d0, c.a2), d0, c.a1), d0, c.a0);
+    double hb0 = fma(fma(fma(c.b3, d0, c.b2), d0, c.b1), d0, c.b0);
+    double pp0 = fma(fma(fma(c.p3, d0, c.p2), d0, c.p1), d0, c.p0);
+    double ha1 = fma(fma(fma(c.a3, d1, c.a2), d1, c.a1), d1, c.a0);
+    double hb1 = fma(fma(fma(c.b3, d1, c.b2), d1, c.b1), d1, c.b0);
+    double pp1 = fma(fma(fma(c.p3, d1, c.p2), d1, c.p1), d1, c.p0);
+    if (two) {       // the wavefront straddles a knot: lanes above it use the next piece
+      const double* t = tab + (size_t)(epoch0 + q_lo + j) * L.stride;
+      const double A0 = t[oa + 4], A1 = t[oa + 5], A2 = t[oa + 6], A3 = t[oa + 7];
+      const double B0 = t[ob + 4], B1 = t[ob + 5], B2 = t[ob + 6], B3 = t[ob + 7];
+      const double P0 = t[op + 4], P1 = t[op + 5], P2 = t[op + 6], P3 = t[op + 7];
+      if (s0) {
+        ha0 = fma(fma(fma(A3, d0, A2), d0, A1), d0, A0);
+        hb0 = fma(fma(fma(B3, d0, B2), d0, B1), d0, B0);
+        pp0 = fma(fma(fma(P3, d0, P2), d0, P1), d0, P0);
+      }
+      if (s1) {
+        ha1 = fma(fma(fma(A3, d1, A2), d1, A1), d1, A0);
+        hb1 = fma(fma(fma(B3, d1, B2), d1, B1), d1, B0);
+        pp1 = fma(fma(fma(P3, d1, P2), d1, P1), d1, P0);
+      }
+    }
+    const double r0 = fma(c.A * shape0, ha0 * hb0, pp0);
+    const double r1 = fma(c.A * shape1, ha1 * hb1, pp1);
+    // write-through: the output is never re-read by this launch, and the k table must
+    // stay in L2 next to it
+    store_wt16(o, r0, r1);
+    o += nk;
+  }
+}
+
 // The per-lane pass: any k, any knot interval, any order.  1-D grid; every wavefront
-// walks work items (fast-pass wavefront, chunk of <= epochs_per_item epochs) and
-// skips those whose flag is clear.  The per-epoch coefficient loads of this path are
-// a dependent chain, hence the short chunks.  In-range k still re-use the
-// Eisenstein-Hu shape across epochs of one cosmology; k outside [k_min, k_max] take
-// the full formula (halo.py:314-320).
+// walks work items (listed k group, chunk of epochs).  The chunk length adapts to the
+// length of the list: few listed groups -> short chunks over many wavefronts (the
+// per-epoch coefficient loads of this path are a dependent chain), a fully listed grid
+// -> one item per group.  In-range k still re-use the Eisenstein-Hu shape across epochs
+// of one cosmology; k outside [k_min, k_max] take the full formula (halo.py:314-320).
 __global__ __launch_bounds__(256) void k_power_grid_lanes(
     chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs,
-    const double* __restrict__ tab, int w, int epoch0, int n_epoch, int fast_gx, int fast_gy,
-    int fast_epochs_per_y, int epochs_per_item, const double* __restrict__ k, size_t nk,
-    double* __restrict__ out, const int* __restrict__ need_slow) {
+    const double* __restrict__ tab, int w, int epoch0, int n_epoch,
+    const double* __restrict__ k, size_t nk, double* __restrict__ out,
+    const int* __restrict__ slow, int parity) {
+  const int count = slow[parity];
+  if (count == 0) return;
   const PowerFam F = power_families(w);
   const int NK = L.NK;
   const double x0 = log(cfg.k_min);
   const double dx = (log(cfg.k_max) - x0) / (double)(NK - 1);
-  const int chunks = (fast_epochs_per_y + epochs_per_item - 1) / epochs_per_item;
-  const long n_items = (long)fast_gx * fast_gy * 4 * chunks;
   const long n_waves = (long)gridDim.x * 4;
+  int chunks = (int)(n_waves / count);
+  chunks = chunks < 1 ? 1 : (chunks > n_epoch ? n_epoch : chunks);
+  const int epochs_per_item = (n_epoch + chunks - 1) / chunks;
+  chunks = (n_epoch + epochs_per_item - 1) / epochs_per_item;
+  const long n_items = (long)count * chunks;
   const int lane = threadIdx.x & 63;
   for (long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6); item < n_items; item += n_waves) {
-    const int fast_wave = (int)(item / chunks), c = (int)(item % chunks);
-    if (need_slow[fast_wave] == 0) continue;               // wave-uniform
-    const int fy = (fast_wave >> 2) / fast_gx, bx = (fast_wave >> 2) % fast_gx;
-    const int q_lo = fy * fast_epochs_per_y + c * epochs_per_item;
+    const int k_group = slow[2 + (int)(item / chunks)], c = (int)(item % chunks);
+    const int q_lo = c * epochs_per_item;
     int q_hi = q_lo + epochs_per_item;
-    if (q_hi > (fy + 1) * fast_epochs_per_y) q_hi = (fy + 1) * fast_epochs_per_y;
     if (q_hi > n_epoch) q_hi = n_epoch;
-    const KLanes s = load_k_lanes(cfg, NK, k, nk,
-                                  (size_t)bx * 256 + (size_t)(fast_wave & 3) * 64 + lane);
+    const KLanes s = load_k_lanes(cfg, NK, k, nk, (size_t)k_group * 64 + lane);
     const double e0 = s.lk0 - (x0 + dx * (double)s.idx0), e1 = s.lk1 - (x0 + dx * (double)s.idx1);
     double sh0 = 0.0, sh1 = 0.0;
     for (int q = q_lo; q < q_hi; ++q) {
@@ -1240,11 +1400,8 @@ __global__ __launch_bounds__(256) void k_power_grid_lanes(
       const bool same = q > q_lo && t[L.off_misc + 2] != 0.0;
       const double A = t[L.off_misc + 1];
       if (!same && w != CHOMP_P_LIN) {
-        const double T0 = eh_transfer(E, s.k0), T1 = eh_transfer(E, s.k1);
-        sh0 = 2.0 * kPi * kPi * exp((3.0 + E.ns) * (s.lk0 - E.ln_H0)) * T0 * T0 /
-              (s.k0 * s.k0 * s.k0);
-        sh1 = 2.0 * kPi * kPi * exp((3.0 + E.ns) * (s.lk1 - E.ln_H0)) * T1 * T1 /
-              (s.k1 * s.k1 * s.k1);
+        sh0 = power_shape(E, s.lk0, s.k0);
+        sh1 = power_shape(E, s.lk1, s.k1);
       }
       if (s.have0) {
         double r;

@@ -71,6 +71,14 @@ int hc_sizeof_epoch() { return (int)sizeof(Epoch); }
 void hc_linear_power(const Epoch* e, const double* k, int n, double* out) {
   for (int i = 0; i < n; ++i) out[i] = linear_power(*e, k[i]);
 }
+void hc_fast_log(const double* x, int n, double* out) {
+  for (int i = 0; i < n; ++i) out[i] = fast_log(x[i]);
+}
+// Stage E: amp * sigma_norm^2 * power_shape(k) == linear_power(k)
+void hc_power_shape(const Epoch* e, const double* k, int n, double* out) {
+  for (int i = 0; i < n; ++i)
+    out[i] = e->amp * e->sigma_norm * e->sigma_norm * power_shape(*e, fast_log(k[i]), k[i]);
+}
 void hc_sigma_integrand(const Epoch* e, double scale, const double* lnk, int n, double* out) {
   SigmaIntegrand f{e, scale};
   for (int i = 0; i < n; ++i) out[i] = f(lnk[i]);

@@ -45,6 +45,18 @@ def test_sici(hc):
     assert numpy.max(numpy.abs(ci - rci)) < 3e-15     # |Ci| up to 18 at x=1e-8
 
 
+def test_fast_log(hc):
+    rng = numpy.random.default_rng(7)
+    x = numpy.concatenate([numpy.logspace(-300, 300, 20001), 1.0 + rng.uniform(-1e-3, 1e-3, 5000),
+                           rng.uniform(0.5, 2.0, 20000), [1.0, 2.0, 0.5, numpy.sqrt(0.5), numpy.sqrt(2.0)]])
+    out = numpy.empty_like(x)
+    hc.hc_fast_log(_p(x), x.size, _p(out))
+    ref = numpy.log(x)
+    big = numpy.abs(ref) > 1e-3
+    assert numpy.max(numpy.abs(out - ref)[big] / numpy.abs(ref)[big]) < 4e-16
+    assert numpy.max(numpy.abs(out - ref)[~big]) < 4e-19
+
+
 def test_bessel(hc):
     x = numpy.concatenate([numpy.linspace(0, 32, 4001), numpy.linspace(32, 200, 3000),
                            numpy.logspace(2.3, 5, 200)])
@@ -124,6 +136,9 @@ def test_background_and_linear_power(hc, z):
     k = numpy.logspace(-5, 4, 500)
     out = numpy.empty_like(k)
     hc.hc_linear_power(buf, _p(k), k.size, _p(out))
+    assert rel_err(out, o.linear_power(e, k)) < 2e-13
+    # Stage E's two-division arrangement with the short logarithm
+    hc.hc_power_shape(buf, _p(k), k.size, _p(out))
     assert rel_err(out, o.linear_power(e, k)) < 2e-13
     for R in (0.05, 8.0, 120.0):
         lo, hi = o.sigma_limits(e, R)
