@@ -493,7 +493,7 @@ int chomp_power_range(chomp_ctx* ctx, int which, size_t epoch0, size_t n, const 
                          ctx->d_epochs, (int)epoch0, w, dk, nk, ctx->d_ktab, ctx->d_winfo,
                          ctx->d_slow, parity);
       int per = n % 2 == 0 ? 2 : 1;
-      if (const char* ev = getenv("CHOMP_E_PER")) { int v = atoi(ev); if (v > 0 && n % v == 0) per = v; }
+      if (const char* ev = getenv("CHOMP_E_PER")) { int v = atoi(ev); if ((v == 1 || v == 2 || v == 4) && n % v == 0) per = v; }
       const unsigned gy = (unsigned)(n / per);
 #define CHOMP_STREAM(P)                                                                   \
       hipLaunchKernelGGL(k_power_stream<P>, dim3(gx8, gy), dim3(256), 0, ctx->stream, L,  \

@@ -61,6 +61,54 @@ def test_c2_full_grid_properties(torch_mod):
         assert rel_err(pk[i], lin[i] * hm * hm + pp) < 1e-11
 
 
+def test_stage_e_launch_shapes_agree(torch_mod, monkeypatch):
+    """Stage E has three launch shapes -- the row-major streaming pair (k_power_prep +
+    k_power_stream, large grids of one cosmology), the row-walking kernel and the generic
+    per-sample kernel -- plus the per-lane pass for k groups that are unsorted, ragged or
+    out of range.  All must return the same numbers on the same input."""
+    torch = torch_mod
+    from chomp_amd import grid
+    gen = torch.Generator("cuda").manual_seed(5)
+
+    def run(hg, which, k, stream):
+        monkeypatch.setenv("CHOMP_E_STREAM_MIN", "0" if stream else str(1 << 62))
+        out = hg.power(which, k).clone()
+        torch.cuda.synchronize()
+        return out
+
+    hg = grid.HaloGrid(numpy.linspace(0.0, 1.5, 6), mass_function="tinker")
+    hg.setup("power_gg")
+    cases = {
+        "sorted": torch.logspace(-3, 2, 1 << 16, dtype=torch.float64, device="cuda"),
+        "ragged, beyond both ends": torch.logspace(-4, 3, 70002, dtype=torch.float64, device="cuda"),
+        "tiny": torch.logspace(-3, 2, 6, dtype=torch.float64, device="cuda"),
+    }
+    sh = torch.logspace(-3.5, 2.5, 1 << 15, dtype=torch.float64, device="cuda")
+    cases["shuffled"] = sh[torch.randperm(sh.numel(), device="cuda", generator=gen)].contiguous()
+    bad = cases["sorted"].clone()
+    bad[::1000] = float("nan"); bad[1::1000] = 0.0; bad[2::1000] = -1.0; bad[3::1000] = float("inf")
+    cases["nan / zero / negative / inf"] = bad
+    for name, k in cases.items():
+        for which in ("power_mm", "power_gm", "power_gg"):
+            a = run(hg, which, k, True)
+            b = run(hg, which, k, False)
+            assert a.shape == (6, k.numel())
+            assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)), (name, which)
+            # generic kernel: an 8-byte-aligned (not 16) slice cannot take either fast shape
+            c = run(hg, which, k[1:], True)
+            fin = torch.isfinite(a[:, 1:])
+            assert torch.equal(fin, torch.isfinite(c)), (name, which)
+            err = ((a[:, 1:] - c).abs() / c.abs().clamp_min(1e-300))[fin].max().item()
+            assert err < 1e-12, (name, which, err)
+    # odd number of rows (one row per block) and a sub-range of the epochs
+    k = cases["sorted"]
+    monkeypatch.setenv("CHOMP_E_STREAM_MIN", "0")
+    part = torch.empty((3, k.numel()), dtype=torch.float64, device="cuda")
+    hg.ctx.power(3, k, 2, 3, out=part)               # P_gg, epochs 2..4
+    full = run(hg, "power_gg", k, False)
+    assert torch.equal(part, full[2:5])
+
+
 def test_range_branches_and_bad_inputs():
     """halo.py:314-320 semantics for every kind of k the reference accepts."""
     from chomp_amd import halo

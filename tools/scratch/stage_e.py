@@ -10,7 +10,7 @@ hg.setup("power_mm")
 nk = int(os.environ.get("STAGE_E_NK", 1 << 20))
 k = torch.logspace(-3, 2, nk, dtype=torch.float64, device=dev)
 buf = torch.empty((64, nk), dtype=torch.float64, device=dev)
-def timed(reps=10):
+def timed(reps=200):
     buf.zero_()
     hg.power("power_mm", k, out=buf); torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -23,7 +23,7 @@ os.environ["CHOMP_E_STREAM_MIN"] = str(1 << 62)
 us = timed(); ref = buf.clone()
 print("row-walk path      %7.1f us  %7.1f GB/s" % (us, by / us / 1e3), flush=True)
 os.environ["CHOMP_E_STREAM_MIN"] = "0"
-pers = [2] if os.environ.get("STAGE_E_ONE") else [1, 2, 4]
+pers = [2] if os.environ.get("STAGE_E_ONE") else [1, 2, 4, 2, 4, 2, 4]
 for per in pers:
     os.environ["CHOMP_E_PER"] = str(per)
     us = timed()
