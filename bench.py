@@ -29,25 +29,42 @@ NK, NZ, Z_MAX = 4096, 64, 1.5
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 measured copy)
 
 
-def cpu_baseline(which, mass_function, sample_z):
-    """Time the oracle (port of the reference's CPU algorithm) on `sample_z`
-    redshifts x the 4096-point k grid; one host thread."""
+def _oracle_row(args):
+    """One redshift row through the oracle (module-level: used by the process pool)."""
+    which, mass_function, z = args
     from oracle import chomp_oracle as o
-    k = numpy.logspace(-3, 2, NK)
     fam = {"power_mm": ("mm",), "power_gm": ("gm",)}[which]
+    k = numpy.logspace(-3, 2, NK)
+    e = o.epoch(None, float(z))
+    m = o.mass_table(e, kind=mass_function)
+    t = o.halo_table(e, m, families=fam)
+    return float(o.halo_power(t, fam[0], k).sum())
+
+
+def cpu_baseline(which, mass_function, sample_z, pool_z):
+    """Time the oracle (port of the reference's CPU algorithm) on `sample_z` redshifts x
+    the 4096-point k grid with one host thread (what a user of the reference gets: it is
+    single-threaded Python), then on `pool_z` with one process per core of this box's
+    CPU share.  Called before anything touches the GPU (the pool forks)."""
+    import multiprocessing
     t0 = time.perf_counter()
     for z in sample_z:
-        e = o.epoch(None, float(z))
-        m = o.mass_table(e, kind=mass_function)
-        t = o.halo_table(e, m, families=fam)
-        o.halo_power(t, fam[0], k)
+        _oracle_row((which, mass_function, z))
     dt = time.perf_counter() - t0
+    cores = min(16, len(os.sched_getaffinity(0)))
+    with multiprocessing.get_context("fork").Pool(cores) as pool:
+        pool.map(_oracle_row, [(which, mass_function, pool_z[0])] * cores)     # warm the workers
+        t0 = time.perf_counter()
+        pool.map(_oracle_row, [(which, mass_function, z) for z in pool_z], chunksize=1)
+        dtp = time.perf_counter() - t0
     return {"value": len(sample_z) * NK / dt, "unit": "samples/s", "cores": 1,
             "kind": "port",
-            "sample": "%d of the %d redshifts (z=%s) x %d k, oracle/chomp_oracle.py "
-                      "(NumPy/SciPy restatement of the reference, adaptive Romberg), "
-                      "%.1f s" % (len(sample_z), NZ,
-                                  ",".join("%.3g" % z for z in sample_z), NK, dt),
+            "sample": "%d of the %d redshifts x %d k, oracle/chomp_oracle.py (NumPy/SciPy "
+                      "restatement of the reference, adaptive Romberg), %.1f s"
+                      % (len(sample_z), NZ, NK, dt),
+            "pool": {"value": len(pool_z) * NK / dtp, "unit": "samples/s", "cores": cores,
+                     "sample": "%d redshifts x %d k over %d forked processes, %.1f s"
+                               % (len(pool_z), NK, cores, dtp)},
             "host_cores_available": os.cpu_count()}
 
 
@@ -61,12 +78,23 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node N"
+    which = "power_mm" if args.workload == "c2" else "power_gm"
+    mf = "st" if args.workload == "c2" else "tinker"
+    baseline = None
+    if world == 1 and not args.no_cpu_baseline:
+        # before the GPU is initialised: the pool forks
+        z1 = numpy.linspace(0.0, Z_MAX, NZ)
+        if args.workload == "c2":
+            baseline = cpu_baseline(which, mf, z1, numpy.concatenate([z1, z1]))
+        else:
+            baseline = cpu_baseline(which, mf, z1[[0, 21, 42, 63]], z1[::4])
+
+    import torch
+    import torch.distributed as dist
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -75,8 +103,6 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from chomp_amd import grid
-    which = "power_mm" if args.workload == "c2" else "power_gm"
-    mf = "st" if args.workload == "c2" else "tinker"
     # weak scaling: every GPU carries configs[1]'s 64 redshift rows, so the global
     # grid is 4096 k x (64 N) z; at N = 1 this is exactly configs[1].
     nz = NZ * world
@@ -131,7 +157,7 @@ def main():
     nk_big = args.roofline_nk
     k_big = torch.logspace(-3, 2, nk_big, dtype=torch.float64, device=dev)
     buf_big = torch.empty((n_local, nk_big), dtype=torch.float64, device=dev)
-    t_e_big = timed(lambda: hg.power(which, k_big, out=buf_big), 10)
+    t_e_big = timed(lambda: hg.power(which, k_big, out=buf_big), 100)
     # Algorithmic bytes of one Stage-E launch: k is read once (8 B per k) and one
     # P value is written per (k, z) sample (8 B).  SURVEY 8(d) prices the per-z
     # explicit-k call at 16 B/sample (k re-read for every z); the grid launch shares
@@ -147,7 +173,9 @@ def main():
             traffic = pmc["hbm_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
-    roof = {"bound": "hbm", "kernel": "k_power_grid (Stage E: fast + per-lane pass)",
+    roof = {"bound": "hbm", "kernel": "Stage E = one chomp_power call: k_power_prep + k_power_stream + "
+                      "k_power_grid_lanes (HIP events around the call; the three rocprof "
+                      "averages add up to avg_launch_us)",
             "workload": "%d k x %d z (enlarged grid, SURVEY 8(d))" % (nk_big, n_local),
             "achieved": bytes_big / t_e_big / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": bytes_big / t_e_big / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
@@ -176,10 +204,8 @@ def main():
                                   "n_local_z": n_local},
             "roofline": roof,
         }
-        if not args.no_cpu_baseline:
-            z1 = numpy.linspace(0.0, Z_MAX, NZ)
-            sz = z1[::8] if args.workload == "c2" else z1[[0, 21, 42, 63]]
-            res["cpu_baseline"] = cpu_baseline(which, mf, sz)
+        if baseline is not None:
+            res["cpu_baseline"] = baseline
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

@@ -21,6 +21,7 @@ MF_ST, MF_TINKER = 0, 1
 T_H_M, T_PP_MM, T_H_G, T_PP_GM, T_PP_GG = 1, 2, 4, 8, 16
 FAM_MM, FAM_GM, FAM_GG = T_H_M | T_PP_MM, T_H_M | T_H_G | T_PP_GM, T_H_G | T_PP_GG
 P_LIN, P_MM, P_GM, P_GG, P_HALOFIT = 0, 1, 2, 3, 16
+PREC_F64, PREC_F32_EVAL, PREC_F32_TABLES, PREC_F32_ALL = 0, 1, 2, 3
 DNDZ_MAGLIM, DNDZ_GAUSSIAN = 0, 1
 WINDOW_GALAXY, WINDOW_CONVERGENCE = 0, 1
 
@@ -94,6 +95,7 @@ EXPORTS = [
     "chomp_multi_epoch_setup", "chomp_me_eval",
     "chomp_kernel_setup", "chomp_kernel_info", "chomp_kernel_table",
     "chomp_kernel_eval", "chomp_window_eval", "chomp_wtheta", "chomp_cell",
+    "chomp_set_precision",
 ]
 
 
@@ -200,6 +202,7 @@ def lib():
         L.chomp_window_eval.argtypes = [vp, i, vp, sz, vp, i]
         L.chomp_wtheta.argtypes = [vp, i, sz, d, d, d, vp, sz, vp, i]
         L.chomp_cell.argtypes = [vp, i, sz, d, vp, sz, vp, i]
+        L.chomp_set_precision.argtypes = [vp, i]
         for name in EXPORTS:
             if name not in ("chomp_default_config", "chomp_ctx_destroy",
                             "chomp_last_error"):
@@ -487,6 +490,11 @@ class Context(object):
     def wtheta(self, which, epoch, k_min, k_max, D_z, theta):
         return self._map1(self._L.chomp_wtheta, theta, int(which), epoch,
                           float(k_min), float(k_max), float(D_z))
+
+    def set_precision(self, mode):
+        """Arithmetic of the w(theta) integral: PREC_F64 (default, the only mode held to
+        the parity bar) or one of the narrowed modes of the configs[4] precision sweep."""
+        self._check(self._L.chomp_set_precision(self._h, int(mode)))
 
     def cell(self, which, epoch, D_z, ell):
         return self._map1(self._L.chomp_cell, ell, int(which), epoch, float(D_z))

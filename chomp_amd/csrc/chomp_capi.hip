@@ -68,6 +68,7 @@ struct chomp_ctx {
   double* d_ktab = nullptr;        // Stage E: per-k (offset, shape) table (k_power_prep)
   size_t cap_slow = 0, cap_winfo = 0, cap_ktab = 0;
   int slow_parity = 0;
+  int precision = CHOMP_PREC_F64;  // chomp_set_precision
   std::vector<int> slot;           // host copy: epoch -> cosmology slot
   size_t cap_in = 0, cap_in2 = 0, cap_out = 0, cap_work = 0;
 

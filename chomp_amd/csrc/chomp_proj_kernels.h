@@ -520,6 +520,202 @@ __global__ __launch_bounds__(256) void k_wtheta(chomp_config cfg, TabLayout HL, 
   if (threadIdx.x == 0) out[blockIdx.x] = v;
 }
 
+// ---------------------------------------------------------------------------
+// Precision sweep of w(theta) (BASELINE.json configs[4]): the same
+// integral with parts of the arithmetic in fp32.
+//   CHOMP_PREC_F32_EVAL    integrand evaluated in fp32 from the fp64 tables, fp64 sums
+//   CHOMP_PREC_F32_TABLES  spline coefficients rounded to fp32, fp64 evaluation and sums
+//   CHOMP_PREC_F32_ALL     fp32 tables, fp32 evaluation, fp32 sums and extrapolation
+// The fp64 mode (k_wtheta) is the product path; these exist to measure what each
+// narrowing costs against the reference's numbers.
+// ---------------------------------------------------------------------------
+namespace f32 {
+
+// fp32 restatement of PowerEval + KernelView (same branches, halo.py:314-320, 649-672,
+// 1339-1360; kernel.py:714-729); tables are read as stored and narrowed on the fly.
+struct Eval {
+  const PowerEval* P;
+  const KernelView* K;
+  float theta, inv_D2;
+  float eh_s, eh_omh, eh_alpha, eh_theta, amp2, ns, ln_H0;
+  float k_s, beta_n, alpha_n, a_n, b_n, c_n, gamma_n, mu_n, nu_n, f1, f2, f3;
+
+  __device__ __forceinline__ void init(const PowerEval* P_, const KernelView* K_, double th,
+                                       double invD2) {
+    P = P_; K = K_; theta = (float)th; inv_D2 = (float)invD2;
+    const Epoch& E = *P->E;
+    eh_s = (float)E.eh_s; eh_omh = (float)E.eh_omh; eh_alpha = (float)E.eh_alpha;
+    eh_theta = (float)E.eh_theta; amp2 = (float)(E.amp * E.sigma_norm * E.sigma_norm);
+    ns = (float)E.ns; ln_H0 = (float)E.ln_H0;
+    k_s = (float)E.hf_k_s; beta_n = (float)E.hf_beta_n; alpha_n = (float)E.hf_alpha_n;
+    a_n = (float)E.hf_a_n; b_n = (float)E.hf_b_n; c_n = (float)E.hf_c_n;
+    gamma_n = (float)E.hf_gamma_n; mu_n = (float)E.hf_mu_n; nu_n = (float)E.hf_nu_n;
+    f1 = (float)E.hf_f1; f2 = (float)E.hf_f2; f3 = (float)E.hf_f3;
+  }
+  __device__ __forceinline__ float poly(const double* c, int i, float d) const {
+    const double* q = c + 4 * i;
+    return fmaf(fmaf(fmaf((float)q[3], d, (float)q[2]), d, (float)q[1]), d, (float)q[0]);
+  }
+  __device__ __forceinline__ float spline(float x0, float dx, const double* c, int n,
+                                          float xv) const {
+    int i = (int)floorf((xv - x0) / dx);
+    i = i < 0 ? 0 : (i > n - 2 ? n - 2 : i);
+    return poly(c, i, xv - (x0 + dx * (float)i));
+  }
+  __device__ __forceinline__ float delta_k(float lk, float k) const {
+    const float t = 1.0f + 0.43f * k * eh_s;
+    const float t2 = t * t;
+    const float G = eh_omh * (eh_alpha + (1.0f - eh_alpha) / (t2 * t2));
+    const float q = k * eh_theta / G;
+    const float L0 = logf(2.0f * 2.7182818f + 1.8f * q);
+    const float C0 = 14.2f + 731.0f / (1.0f + 62.5f * q);
+    const float T = L0 / (L0 + C0 * q * q);
+    return amp2 * expf((3.0f + ns) * (lk - ln_H0)) * T * T;
+  }
+  __device__ __forceinline__ float halofit(float lk, float k) const {
+    const float dk = delta_k(lk, k);
+    const float y = k / k_s;
+    const float d2q = dk * (powf(1.0f + dk, beta_n) / (1.0f + alpha_n * dk) *
+                            expf(-(y / 4.0f + y * y / 8.0f)));
+    const float d2h = (a_n * powf(y, 3.0f * f1) /
+                       (1.0f + b_n * powf(y, f2) + powf(c_n * f3 * y, 3.0f - gamma_n))) /
+                      (1.0f + mu_n / y + nu_n / (y * y));
+    return 2.0f * 9.8696044f / (k * k * k) * (d2q + d2h);
+  }
+  __device__ __forceinline__ float power(float lk, float k) const {
+    const float x0 = (float)P->x0, dx = (float)P->dx;
+    const float k_min = (float)P->k_min, k_max = (float)P->k_max;
+    const float plin = 2.0f * 9.8696044f * delta_k(lk, k) / (k * k * k);
+    if (P->w == CHOMP_P_LIN) return plin;
+    const bool in = k >= k_min && k <= k_max;
+    if (P->halofit) {
+      const float pmm = halofit(lk, k);
+      if (P->w == CHOMP_P_MM) return pmm;
+      float ha = 0.0f, hb = 0.0f, pp = 0.0f;
+      if (in) {
+        ha = spline(x0, dx, P->ca, P->NK, lk);
+        hb = spline(x0, dx, P->cb, P->NK, lk);
+        pp = spline(x0, dx, P->cp, P->NK, lk);
+      }
+      return pmm * ha * hb + pp;
+    }
+    if (k < k_min) return plin * (float)P->c_lo;
+    if (in) {
+      return plin * spline(x0, dx, P->ca, P->NK, lk) * spline(x0, dx, P->cb, P->NK, lk) +
+             spline(x0, dx, P->cp, P->NK, lk);
+    }
+    return 0.0f;
+  }
+  __device__ __forceinline__ float kernel(float x) const {
+    const float lo = (float)K->lo, hi = (float)K->hi;
+    const float dx = (hi - lo) / (float)(K->N - 1);
+    if (x < lo) return poly(K->pp, 0, 0.0f);
+    if (x <= hi) return spline(lo, dx, K->pp, K->N, x);
+    return 0.0f;
+  }
+  // correlation.py:270-275
+  __device__ __forceinline__ float operator()(float ln_k) const {
+    const float k = expf(ln_k);
+    return k * k / (2.0f * 3.14159265f) * power(ln_k, k) * inv_D2 * kernel(logf(k * theta));
+  }
+};
+
+struct EvalAsDouble {          // fp32 integrand under the fp64 Romberg driver
+  const Eval* f;
+  __device__ __forceinline__ double operator()(double ln_k) const {
+    return (double)(*f)((float)ln_k);
+  }
+};
+
+// scipy.integrate.romberg in single precision, one integral per 256-thread block
+// (plain level-by-level version: this path is for the accuracy sweep, not for speed).
+// red: 8 floats of LDS.
+template <class F>
+__device__ float romberg_block(const F& f, float a, float b, float tol, float rtol, int divmax,
+                               float* red) {
+  const float len = b - a;
+  float ordsum = 0.5f * (f(a) + f(b));
+  float prev[24], cur[24];
+  prev[0] = len * ordsum;
+  float result = prev[0];
+  int n = 1;
+  for (int i = 1; i <= divmax; ++i) {
+    const float h = len / (float)n;
+    float part = 0.0f;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) part += f(a + 0.5f * h + h * (float)j);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    float tot = 0.0f;
+    for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) tot += red[wv];
+    ordsum += tot;
+    n *= 2;
+    cur[0] = len * ordsum / (float)n;
+    float p4 = 1.0f;
+    for (int m = 1; m <= i; ++m) {
+      p4 *= 4.0f;
+      cur[m] = (p4 * cur[m - 1] - prev[m - 1]) / (p4 - 1.0f);
+    }
+    result = cur[i];
+    const float err = fabsf(result - prev[i - 1]);
+    for (int m = 0; m <= i; ++m) prev[m] = cur[m];
+    if (err < tol || err < rtol * fabsf(result)) break;
+  }
+  return result;
+}
+
+}  // namespace f32
+
+// grid n_theta, block 256: k_wtheta with a narrowed precision mode (MODE = CHOMP_PREC_*).
+template <int MODE>
+__global__ __launch_bounds__(256) void k_wtheta_mixed(chomp_config cfg, TabLayout HL, ProjLayout L,
+                                                      const Epoch* __restrict__ epochs, int e,
+                                                      const double* __restrict__ htab, int which,
+                                                      const ProjDev* __restrict__ pd,
+                                                      const double* __restrict__ ptab,
+                                                      double k_min, double k_max, double D_z,
+                                                      const double* __restrict__ theta,
+                                                      double* __restrict__ out) {
+  extern __shared__ __align__(16) double sm[];
+  __shared__ Epoch E;
+  __shared__ double red[romberg_scratch<4, 2>()];
+  copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
+               kEpochDoubles);
+  PowerEval P;
+  P.stage(cfg, HL, &E, htab + (size_t)e * HL.stride, which, sm);
+  double* kpp = sm + 12 * (HL.NK - 1);
+  copy_doubles(kpp, ptab + L.k_pp, 4 * (L.NKT - 1));
+  __syncthreads();
+  if (MODE == CHOMP_PREC_F32_TABLES || MODE == CHOMP_PREC_F32_ALL) {
+    const int n_tab = 12 * (HL.NK - 1) + 4 * (L.NKT - 1);
+    for (int i = threadIdx.x; i < n_tab; i += blockDim.x) sm[i] = (double)(float)sm[i];
+    __syncthreads();
+  }
+  P.finish();
+  const KernelView K{kpp, L.NKT, pd->ln_kt_min, pd->ln_kt_max};
+  double v;
+  if (MODE == CHOMP_PREC_F32_TABLES) {
+    WthetaIntegrand f{&P, &K, theta[blockIdx.x], 1.0 / (D_z * D_z)};
+    v = romberg1<4>(f, log(k_min), log(k_max), cfg.global_precision, cfg.corr_precision,
+                    cfg.divmax, red);
+  } else {
+    f32::Eval f;
+    f.init(&P, &K, theta[blockIdx.x], 1.0 / (D_z * D_z));
+    if (MODE == CHOMP_PREC_F32_EVAL) {
+      f32::EvalAsDouble g{&f};
+      v = romberg1<4>(g, log(k_min), log(k_max), cfg.global_precision, cfg.corr_precision,
+                      cfg.divmax, red);
+    } else {
+      v = (double)f32::romberg_block(f, (float)log(k_min), (float)log(k_max),
+                                     (float)cfg.global_precision, (float)cfg.corr_precision,
+                                     cfg.divmax, reinterpret_cast<float*>(red));
+    }
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = v;
+}
+
 // correlation.py:387-392
 struct CellIntegrand {
   const PowerEval* P;

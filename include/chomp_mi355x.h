@@ -317,6 +317,19 @@ int chomp_wtheta(chomp_ctx* ctx, int which, size_t epoch, double k_min,
 int chomp_cell(chomp_ctx* ctx, int which, size_t epoch, double D_z,
                const double* ell, size_t n, double* out, int mem);
 
+/* Arithmetic of the w(theta) integral (BASELINE.json configs[4]: "mixed fp32/fp64 with
+ * tolerance sweep").  The reference computes everything in fp64; F64 is the
+ * default and the only mode held to the 1e-4 parity bar -- the others exist so that the
+ * cost of each narrowing can be measured against the same golden vectors
+ * (tests/test_gpu_projection.py::test_c5_precision_sweep). */
+enum {
+  CHOMP_PREC_F64 = 0,        /* tables, evaluation and sums in fp64 */
+  CHOMP_PREC_F32_EVAL = 1,   /* fp32 integrand evaluation, fp64 tables and sums */
+  CHOMP_PREC_F32_TABLES = 2, /* spline coefficients rounded to fp32, fp64 evaluation and sums */
+  CHOMP_PREC_F32_ALL = 3     /* fp32 tables, evaluation, sums and Richardson extrapolation */
+};
+int chomp_set_precision(chomp_ctx* ctx, int mode);
+
 #ifdef __cplusplus
 }
 #endif

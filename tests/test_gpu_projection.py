@@ -109,3 +109,42 @@ def test_c5_halofit_ggl(mods):
     assert rel_err(hf.power_gm(g["k"]), g["hf_gm_zbar"]) < RTOL
     cf = correlation.CorrelationFourier(10, 1e4, kern, input_halo=hf, powSpec="power_gm")
     assert rel_err(cf.correlation(g["ell"]), g["cl_ggl"]) < RTOL
+
+
+def test_c5_precision_sweep(mods):
+    """configs[4] "mixed fp32/fp64 with tolerance sweep" (SURVEY 8(d) C5): w_GGL(theta) with
+    HaloFit power_gm in the four arithmetic modes against G7.  fp64 is held to the 1e-4
+    bar; the narrowed modes are measured and only bounded loosely (they are not a product
+    path) -- the numbers land in gpurun_out/precision_sweep.json for DESIGN.md."""
+    import json
+    import os
+    from chomp_amd import _lib
+    cosmology, kernel, correlation, halo = mods
+    g = load_golden("g7_ggl_halofit")
+    cm, kern = _projection(mods, True)
+    hf = halo.HaloFit(0.0)
+    hf.power_mm(g["k"])          # fixture call order: sigma spline built at z = 0
+    corr = correlation.Correlation(0.001, 1.0, kern, input_halo=hf, power_spec="power_gm")
+    ctx, _ = corr._prepare()
+    errs = {}
+    try:
+        for name, mode in (("fp64", _lib.PREC_F64), ("fp32_eval", _lib.PREC_F32_EVAL),
+                           ("fp32_tables", _lib.PREC_F32_TABLES), ("fp32_all", _lib.PREC_F32_ALL)):
+            ctx.set_precision(mode)
+            errs[name] = float(rel_err(corr.correlation(g["theta"]), g["w_ggl"]))
+    finally:
+        ctx.set_precision(_lib.PREC_F64)
+    with pytest.raises(ValueError):
+        ctx.set_precision(7)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "precision_sweep.json"), "w") as fh:
+        json.dump({"case": "G7 w_GGL(theta), 33 theta, HaloFit power_gm, J2 kernel",
+                   "max_rel_err_vs_reference": errs}, fh, indent=1)
+    print("precision sweep:", errs)
+    assert errs["fp64"] < RTOL
+    # measured on MI355X (profiles/round1_c5_precision_sweep.json): fp64 7e-12, fp32 tables
+    # 3e-8, fp32 evaluation 2e-6, all-fp32 2e-6 -- every mode is inside the 1e-4 bar here
+    assert errs["fp32_tables"] < 1e-6
+    assert errs["fp32_eval"] < RTOL and errs["fp32_all"] < RTOL
+    assert errs["fp64"] <= min(errs["fp32_eval"], errs["fp32_all"])

@@ -10,26 +10,31 @@ import sys
 
 
 def per_launch(d, counter):
+    """Sum the counter over the Stage-E dispatches (k_power_prep, k_power_stream,
+    k_power_grid_lanes) and divide by the number of chomp_power calls."""
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
-    vals = {}
+    total, calls, per_kernel = 0.0, set(), {}
     for r in csv.DictReader(open(f)):
-        if "k_power_grid" in r["Kernel_Name"] and r["Counter_Name"] == counter:
-            vals.setdefault(r["Dispatch_Id"], 0.0)
-            vals[r["Dispatch_Id"]] += float(r["Counter_Value"])
-    # the fast and the per-lane kernels of one chomp_power call are consecutive
-    # dispatches; group pairs and average over calls
-    v = [vals[k] for k in sorted(vals, key=int)]
-    calls = [v[i] + v[i + 1] for i in range(0, len(v) - 1, 2)]
-    return sum(calls) / len(calls), len(calls)
+        name = r["Kernel_Name"]
+        if "k_power_" in name and r["Counter_Name"] == counter:
+            v = float(r["Counter_Value"])
+            total += v
+            short = name.split("(")[0].split("::")[-1]
+            per_kernel[short] = per_kernel.get(short, 0.0) + v
+            if "k_power_grid_lanes" in name:
+                calls.add(r["Dispatch_Id"])
+    n = len(calls)
+    return total / n, n, {k: v / n for k, v in per_kernel.items()}
 
 
-fetch_kib, n1 = per_launch(sys.argv[1], "FETCH_SIZE")
-write_kib, n2 = per_launch(sys.argv[2], "WRITE_SIZE")
+fetch_kib, n1, fetch_k = per_launch(sys.argv[1], "FETCH_SIZE")
+write_kib, n2, write_k = per_launch(sys.argv[2], "WRITE_SIZE")
 nk, nz = 1 << 20, 64
 out = {
-    "kernel": "k_power_grid<false> + k_power_grid<true> (one chomp_power call)",
+    "kernel": "k_power_prep + k_power_stream + k_power_grid_lanes (one chomp_power call)",
     "nk": nk, "nz": nz, "calls_averaged": min(n1, n2),
     "FETCH_SIZE_KiB_raw": fetch_kib, "WRITE_SIZE_KiB_raw": write_kib,
+    "FETCH_SIZE_KiB_raw_by_kernel": fetch_k, "WRITE_SIZE_KiB_raw_by_kernel": write_k,
     "fetch_bytes_corrected_x2": 2.0 * fetch_kib * 1024.0,
     "write_bytes": write_kib * 1024.0,
     "hbm_bytes_per_launch": 2.0 * fetch_kib * 1024.0 + write_kib * 1024.0,
