@@ -160,7 +160,7 @@ struct SigmaTabIntegrand {
       const int idx = node_index(lev, j);
       const double kR = scale * node[idx];
       double s, c;
-      sincos(kR, &s, &c);
+      fast_sincos(kR, &s, &c);
       const double W = 3.0 * (s - kR * c) / (kR * kR * kR);
       out[0] = node[kSigmaCount + idx] * W * W;
     } else {

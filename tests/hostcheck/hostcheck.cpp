@@ -71,6 +71,9 @@ int hc_sizeof_epoch() { return (int)sizeof(Epoch); }
 void hc_linear_power(const Epoch* e, const double* k, int n, double* out) {
   for (int i = 0; i < n; ++i) out[i] = linear_power(*e, k[i]);
 }
+void hc_fast_sincos(const double* x, int n, double* s, double* c) {
+  for (int i = 0; i < n; ++i) fast_sincos(x[i], &s[i], &c[i]);
+}
 void hc_fast_log(const double* x, int n, double* out) {
   for (int i = 0; i < n; ++i) out[i] = fast_log(x[i]);
 }

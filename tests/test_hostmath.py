@@ -57,6 +57,25 @@ def test_fast_log(hc):
     assert numpy.max(numpy.abs(out - ref)[~big]) < 4e-19
 
 
+def test_fast_sincos(hc):
+    rng = numpy.random.default_rng(11)
+    x = numpy.concatenate([numpy.logspace(-12, 6, 40001), -numpy.logspace(-8, 5, 5001),
+                           rng.uniform(0, 1e4, 50000), numpy.arange(0, 2000) * numpy.pi / 4,
+                           [0.0, numpy.pi / 2, numpy.pi, 1e8, 3.3e9]])
+    s, c = numpy.empty_like(x), numpy.empty_like(x)
+    hc.hc_fast_sincos(_p(x), x.size, _p(s), _p(c))
+    assert numpy.max(numpy.abs(s - numpy.sin(x))) < 2.3e-16
+    assert numpy.max(numpy.abs(c - numpy.cos(x))) < 2.3e-16
+    small = numpy.abs(x) < 1e-3                      # relative accuracy where sin x ~ x
+    assert numpy.max(numpy.abs(s[small] - numpy.sin(x[small])) /
+                     numpy.maximum(numpy.abs(x[small]), 1e-300)) < 2.3e-16
+    big = numpy.array([1e12, 7.7e14, -3e13])          # degrades gracefully, stays in [-1, 1]
+    sb, cb = numpy.empty_like(big), numpy.empty_like(big)
+    hc.hc_fast_sincos(_p(big), big.size, _p(sb), _p(cb))
+    assert numpy.all(numpy.abs(sb) <= 1.0 + 1e-15) and numpy.all(numpy.abs(cb) <= 1.0 + 1e-15)
+    assert numpy.max(numpy.abs(sb - numpy.sin(big))) < 1e-15 * 1e15 * 1e-15 + 1e-3
+
+
 def test_bessel(hc):
     x = numpy.concatenate([numpy.linspace(0, 32, 4001), numpy.linspace(32, 200, 3000),
                            numpy.logspace(2.3, 5, 200)])
