@@ -19,8 +19,9 @@ OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_SCOPE = 0, -1, -2, -3, -4
 HOST, DEVICE = 0, 1
 MF_ST, MF_TINKER = 0, 1
 T_H_M, T_PP_MM, T_H_G, T_PP_GM, T_PP_GG = 1, 2, 4, 8, 16
+T_EXCLUSION = 64
 FAM_MM, FAM_GM, FAM_GG = T_H_M | T_PP_MM, T_H_M | T_H_G | T_PP_GM, T_H_G | T_PP_GG
-P_LIN, P_MM, P_GM, P_GG, P_HALOFIT = 0, 1, 2, 3, 16
+P_LIN, P_MM, P_GM, P_GG, P_HALOFIT, P_EXTRAPOLATE = 0, 1, 2, 3, 16, 32
 PREC_F64, PREC_F32_EVAL, PREC_F32_TABLES, PREC_F32_ALL = 0, 1, 2, 3
 DNDZ_MAGLIM, DNDZ_GAUSSIAN = 0, 1
 WINDOW_GALAXY, WINDOW_CONVERGENCE = 0, 1
@@ -95,7 +96,7 @@ EXPORTS = [
     "chomp_multi_epoch_setup", "chomp_me_eval",
     "chomp_kernel_setup", "chomp_kernel_info", "chomp_kernel_table",
     "chomp_kernel_eval", "chomp_window_eval", "chomp_wtheta", "chomp_cell",
-    "chomp_set_precision",
+    "chomp_set_precision", "chomp_xi3d", "chomp_spline_eval",
 ]
 
 
@@ -203,6 +204,9 @@ def lib():
         L.chomp_wtheta.argtypes = [vp, i, sz, d, d, d, vp, sz, vp, i]
         L.chomp_cell.argtypes = [vp, i, sz, d, vp, sz, vp, i]
         L.chomp_set_precision.argtypes = [vp, i]
+        L.chomp_xi3d.argtypes = [vp, i, sz, d, d, vp, sz, vp, i]
+        L.chomp_spline_eval.argtypes = [vp, c_double_p, c_double_p, sz, c_double_p, sz,
+                                        c_double_p]
         for name in EXPORTS:
             if name not in ("chomp_default_config", "chomp_ctx_destroy",
                             "chomp_last_error"):
@@ -490,6 +494,21 @@ class Context(object):
     def wtheta(self, which, epoch, k_min, k_max, D_z, theta):
         return self._map1(self._L.chomp_wtheta, theta, int(which), epoch,
                           float(k_min), float(k_max), float(D_z))
+
+    def xi3d(self, which, epoch, k_min, k_max, r):
+        return self._map1(self._L.chomp_xi3d, r, int(which), epoch, float(k_min), float(k_max))
+
+    def spline_eval(self, xk, yk, x):
+        """Not-a-knot cubic spline through (xk, yk) at x (FITPACK k=3, s=0)."""
+        xk = numpy.ascontiguousarray(xk, dtype=numpy.float64)
+        yk = numpy.ascontiguousarray(yk, dtype=numpy.float64)
+        xa = numpy.ascontiguousarray(numpy.atleast_1d(x), dtype=numpy.float64).ravel()
+        out = numpy.empty_like(xa)
+        if xa.size:
+            self._check(self._L.chomp_spline_eval(
+                self._h, xk.ctypes.data_as(c_double_p), yk.ctypes.data_as(c_double_p), xk.size,
+                xa.ctypes.data_as(c_double_p), xa.size, out.ctypes.data_as(c_double_p)))
+        return out
 
     def set_precision(self, mode):
         """Arithmetic of the w(theta) integral: PREC_F64 (default, the only mode held to

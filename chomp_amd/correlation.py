@@ -1,6 +1,7 @@
-"""correlation.Correlation / CorrelationFourier with the reference's constructors
-and methods (correlation.py:33-289, 297-405): one Romberg integral per theta (over
-ln k) or per multipole (Limber, over chi), each on its own group of wavefronts.
+"""correlation.Correlation / CorrelationFourier / Correlation3d with the reference's
+constructors and methods (correlation.py:33-289, 297-405, 408-510): one Romberg integral
+per theta or r (over ln k) or per multipole (Limber, over chi), each on its own group of
+wavefronts.
 """
 import numpy
 
@@ -47,7 +48,7 @@ class Correlation(object):
             self.halo.set_redshift(self.kernel.z_bar)
         if ((k_min is not None and k_min < self.halo._k_min) or
                 (k_max is not None and k_max > self.halo._k_max)):
-            self.halo.set_extrapolation(True)         # raises: not accelerated yet
+            self.halo.set_extrapolation(True)
         if k_min is None:
             k_min = self.halo._k_min
         self._ln_k_min = numpy.log(k_min)
@@ -116,7 +117,7 @@ class Correlation(object):
                 need = 0
         ctx = self.halo._sync(need)
         self.kernel._setup_on(ctx)
-        return ctx, code
+        return ctx, self.halo._power_code(code)
 
     def compute_correlation(self):
         self.wtheta_array = numpy.asarray(self.correlation(self.theta_array))
@@ -170,3 +171,75 @@ class CorrelationFourier(Correlation):
             f.write("#ttype1 = l [deg]\n#ttype2 = power\n")
             for l, power in zip(self.l_array, self.power_array):
                 f.write("%1.10f %1.10f\n" % (l, power))
+
+
+class Correlation3d(Correlation):
+    """xi(r) from a halo-model spectrum (correlation.py:408-510): corr_npoints
+    log-spaced separations, one Romberg integral of k^2/(2 pi) P(k) J0(k r) each -- the
+    cylindrical J0, as the reference has it -- and a cubic spline in r."""
+
+    def __init__(self, r_min, r_max, redshift=0.0, input_halo=None, powSpec=None,
+                 k_min=None, k_max=None):
+        from . import defaults
+        self.log_r_min = numpy.log10(r_min)
+        self.log_r_max = numpy.log10(r_max)
+        self.r_array = numpy.logspace(self.log_r_min, self.log_r_max,
+                                      defaults.default_precision["corr_npoints"])
+        if r_min == r_max:
+            self.r_array = numpy.array([r_min])
+        self.xi_array = numpy.zeros(self.r_array.size)
+        if input_halo is None:
+            input_halo = halo_mod.Halo(redshift)
+        self.halo = input_halo
+        self.halo.set_redshift(redshift)
+        if ((k_min is not None or k_max is not None) and
+                not self.halo.get_extrapolation() and
+                (k_min < self.halo._k_min or k_max > self.halo._k_max)):
+            self.halo.set_extrapolation(True)
+        if k_min is None:
+            k_min = self.halo._k_min
+        self._ln_k_min = numpy.log(k_min)
+        if k_max is None:
+            k_max = self.halo._k_max
+        self._ln_k_max = numpy.log(k_max)
+        self._k_lim = (float(k_min), float(k_max))
+        self.set_power_spectrum(powSpec)
+        self.initialized_spline = False
+
+    def _prepare(self):
+        code, need = _POWER[self._power_name]
+        if isinstance(self.halo, halo_mod.HaloFit) and code != _lib.P_LIN:
+            self.halo._ensure_halofit()
+            code |= _lib.P_HALOFIT
+            if (code & 15) == _lib.P_MM:
+                need = 0
+        return self.halo._sync(need), self.halo._power_code(code)
+
+    def compute_correlation(self):
+        self.xi_array = numpy.asarray(self.raw_correlation(self.r_array))
+        self.initialized_spline = True
+
+    def raw_correlation(self, r):
+        ra = numpy.asarray(r, dtype=numpy.float64)
+        ctx, code = self._prepare()
+        out = ctx.xi3d(code, 0, self._k_lim[0], self._k_lim[1],
+                       numpy.ascontiguousarray(ra).ravel())
+        return float(out[0]) if ra.ndim == 0 else out.reshape(ra.shape)
+
+    def correlation(self, r):
+        if not self.initialized_spline:
+            self.compute_correlation()
+        ra = numpy.asarray(r, dtype=numpy.float64)
+        r_min, r_max = 10. ** self.log_r_min, 10. ** self.log_r_max
+        inside = numpy.logical_and(ra <= r_max, ra > r_min)
+        out = numpy.zeros(ra.shape)
+        if numpy.any(inside):
+            ctx, _ = self._prepare()
+            out[inside] = ctx.spline_eval(self.r_array, self.xi_array, ra[inside])
+        return out
+
+    def write(self, output_file_name):
+        with open(output_file_name, "w") as f:
+            f.write("#ttype1 = r [Mpc/h]\n#ttype2 = xi\n")
+            for r, xi in zip(self.r_array, self.xi_array):
+                f.write("%1.10g %1.10g\n" % (r, xi))

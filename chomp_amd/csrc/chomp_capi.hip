@@ -398,6 +398,7 @@ int chomp_halo_setup(chomp_ctx* ctx, const chomp_halo_par* profile,
   if (rcu) return rcu;
   // header bits CHOMP_T_* are (1 << F_*) by construction
   const unsigned fam = tables & 31u;
+  const unsigned kmask = fam | ((tables & CHOMP_T_EXCLUSION) ? kMaskExclusion : 0u);
   int groups[3] = {-1, -1, -1};
   int ng = 0;
   if (fam & ((1u << F_HM) | (1u << F_PPMM))) groups[ng++] = 0;
@@ -412,11 +413,11 @@ int chomp_halo_setup(chomp_ctx* ctx, const chomp_halo_par* profile,
   if (groups[0] != 3)
   hipLaunchKernelGGL(k_halo_knots, dim3(L.NK, (unsigned)n, ng), dim3(256), 0, ctx->stream,
                      ctx->cfg, L, ctx->d_tab, ctx->d_sici, ctx->d_nodes, groups[0], groups[1],
-                     groups[2], fam);
+                     groups[2], kmask);
   if (ctx->cfg.divmax > kNodeLevel && groups[0] != 3)
     hipLaunchKernelGGL(k_halo_knots_deep, dim3(L.NK, (unsigned)n, ng), dim3(256), sh, ctx->stream,
                        ctx->cfg, L, ctx->d_epochs, ctx->d_tab, ctx->d_profile, ctx->d_hod,
-                       ctx->d_sici, groups[0], groups[1], groups[2], fam);
+                       ctx->d_sici, groups[0], groups[1], groups[2], kmask);
   const size_t sh2 = (size_t)(51 * L.NK) * sizeof(double);
   hipLaunchKernelGGL(k_halo_finalize, dim3((unsigned)n), dim3(384), sh2, ctx->stream, ctx->cfg,
                      L, ctx->d_epochs, ctx->d_tab, ctx->d_profile, ctx->d_hod, fam);
@@ -448,12 +449,27 @@ static int check_power(chomp_ctx* ctx, int which, size_t epoch0, size_t n) {
   return CHOMP_OK;
 }
 
+// Halo(extrapolate=True): refresh the constants of the continuation above k_max for the
+// epochs about to be evaluated (cheap: one 64-thread block per epoch).
+static int prepare_extrapolation(chomp_ctx* ctx, int which, size_t epoch0, size_t n) {
+  const int w = which & 15;
+  if (!(which & CHOMP_P_EXTRAPOLATE) || (which & CHOMP_P_HALOFIT) || w == CHOMP_P_LIN)
+    return CHOMP_OK;
+  hipLaunchKernelGGL(k_power_extrap, dim3((unsigned)n), dim3(64), 0, ctx->stream, ctx->cfg,
+                     ctx->L, ctx->d_epochs, ctx->d_tab, w, (int)epoch0);
+  HIPCHK(hipGetLastError());
+  return CHOMP_OK;
+}
+
 int chomp_power_range(chomp_ctx* ctx, int which, size_t epoch0, size_t n, const double* k,
                       size_t nk, double* out, int mem) {
   int rc = check_power(ctx, which, epoch0, n);
   if (rc) return rc;
   if (!k || !out || nk == 0) return fail(ctx, CHOMP_ERR_ARG, "power: null buffer");
   HIPCHK(hipSetDevice(ctx->device));
+  rc = prepare_extrapolation(ctx, which, epoch0, n);
+  if (rc) return rc;
+  const bool extrap = (which & CHOMP_P_EXTRAPOLATE) && !(which & CHOMP_P_HALOFIT);
   const double* dk = k;
   double* dout = out;
   if (mem == CHOMP_HOST) {
@@ -517,7 +533,7 @@ int chomp_power_range(chomp_ctx* ctx, int which, size_t epoch0, size_t n, const 
     }
     // per-lane pass over the listed k groups
     hipLaunchKernelGGL(k_power_grid_lanes, dim3(1024), dim3(256), 0, ctx->stream, ctx->cfg, L,
-                       ctx->d_epochs, ctx->d_tab, w, (int)epoch0, (int)n, dk, nk, dout,
+                       ctx->d_epochs, ctx->d_tab, w, extrap, (int)epoch0, (int)n, dk, nk, dout,
                        ctx->d_slow, parity);
   } else {
     unsigned gx = (unsigned)((nk + 255) / 256);

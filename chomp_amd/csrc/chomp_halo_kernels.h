@@ -536,6 +536,12 @@ struct HaloCtx {
   const double* lnm_pp;      // [4(NM-1)]
   int NM;
   double ln_k;
+  bool exclusion;            // HaloExclusion: the 2-halo integrands carry the mass window
+  __device__ __forceinline__ double window(double lnm) const {
+    if (!exclusion) return 1.0;
+    const double ln_rv = (e->ln_rv_const + lnm) * (1.0 / 3.0);
+    return exclusion_window(*sici, 2.0 * exp(ln_k + ln_rv));
+  }
 };
 
 struct IntegrandMM {       // out[0] = h_m, out[1] = pp_mm (x rho_bar)
@@ -546,7 +552,7 @@ struct IntegrandMM {       // out[0] = h_m, out[1] = pp_mm (x rho_bar)
     const double y = y_nfw(*c.e, *c.sici, c.ln_k, lnm);
     double nf, b;
     mf_node(*c.e, nu, ln_nu, true, &nf, &b);
-    out[0] = nf * b * y;
+    out[0] = nf * b * y * c.window(lnm);
     out[1] = nf * exp(lnm) * y * y;
   }
 };
@@ -562,7 +568,7 @@ struct IntegrandGM {       // out[0] = h_g, out[1] = pp_gm
     double nf, b = 0.0, n1, n2;
     mf_node(*c.e, nu, ln_nu, want_hg, &nf, &b);
     zheng_node(*c.e, mass, lnm, &n1, &n2);
-    out[0] = nf * b * y * n1 / mass;
+    out[0] = nf * b * y * n1 / mass * (want_hg ? c.window(lnm) : 1.0);
     out[1] = (n1 < 1.0) ? nf * n1 * y : nf * n1 * y * y;
   }
 };
@@ -678,7 +684,7 @@ __global__ __launch_bounds__(256) void k_halo_nodes(
   HaloLds H;
   H.stage(L, E, S, epochs, e, tab + (size_t)e * L.stride, profile, hod, sici_g, sm);
   if (nbar_block) {
-    HaloCtx c{&E, &S, H.nu_knots, H.lnm_pp, L.NM, 0.0};
+    HaloCtx c{&E, &S, H.nu_knots, H.lnm_pp, L.NM, 0.0, false};
     IntegrandNbar f{c};
     const double v = romberg1<4>(f, E.ln_nu_lo_first, log(E.nu_max), cfg.global_precision,
                                  cfg.halo_precision, cfg.divmax, H.rest);
@@ -746,11 +752,14 @@ struct NodeIntegrand {
   const SiCiTab* sici;
   const double* node;     // this (epoch, group)'s table
   double ln_k;
+  bool exclusion;         // HaloExclusion (halo.py:1208-1233): window on the 2-halo term
   __device__ __forceinline__ void operator()(double, double (&out)[2], int lev, long j) const {
     const double* n = node + node_index(lev, j);
+    double z;             // k r_s; k * 2 r_v = 2 c z
     const double y = y_nfw_core(*sici, ln_k, n[2 * kNodeCount], n[3 * kNodeCount],
-                                n[4 * kNodeCount], n[5 * kNodeCount]);
+                                n[4 * kNodeCount], n[5 * kNodeCount], &z);
     out[0] = n[0] * y;
+    if (exclusion) out[0] *= exclusion_window(*sici, 2.0 * n[3 * kNodeCount] * z);
     out[1] = n[kNodeCount] * (n[6 * kNodeCount] != 0.0 ? y : y * y);
   }
 };
@@ -760,6 +769,7 @@ __device__ __forceinline__ int group_fb(int group) {
   return group == 0 ? F_PPMM : (group == 1 ? F_PPGM : F_PPGG);
 }
 constexpr double kPendingLevel = -1.0;   // levels-table marker: needs the deep pass
+constexpr unsigned kMaskExclusion = 1u << 8;   // bit of the kernels' family mask: HaloExclusion
 
 // ---------------------------------------------------------------------------
 // k_halo_knots: grid (NK, n_epoch, n_groups), block 256 (4 wavefronts per integral
@@ -785,7 +795,7 @@ __global__ __launch_bounds__(256) void k_halo_knots(
   __syncthreads();
   double* t = tab + (size_t)e * L.stride;
   const double ln_k = linspace_at(log(cfg.k_min), log(cfg.k_max), NK, ik);   // halo.py:52-54
-  NodeIntegrand f{&S, node, ln_k};
+  NodeIntegrand f{&S, node, ln_k, (mask & kMaskExclusion) != 0};
   const int dmax = cfg.divmax < kNodeLevel ? cfg.divmax : kNodeLevel;
   const RombergOut<2> r = romberg_group<4, 2>(f, a, b, cfg.global_precision,
                                               cfg.halo_precision, dmax, red);
@@ -834,7 +844,7 @@ __global__ __launch_bounds__(256) void k_halo_knots_deep(
   double* red = H.rest;
   const double ln_nu_max = log(E.nu_max);
   HaloCtx c{&E, &S, H.nu_knots, H.lnm_pp, L.NM,
-            linspace_at(log(cfg.k_min), log(cfg.k_max), NK, ik)};
+            linspace_at(log(cfg.k_min), log(cfg.k_max), NK, ik), (mask & kMaskExclusion) != 0};
   double va = 0.0, vb = 0.0;
   int la = 0, lb = 0;
   if (group == 0) {
@@ -922,6 +932,22 @@ __global__ __launch_bounds__(384) void k_halo_finalize(
 // its epoch's scalars and the pp-coefficients of the (up to 3) knot splines it
 // needs in LDS, then streams k -> P with coalesced 8-byte accesses.
 // ---------------------------------------------------------------------------
+struct PowerFam { int fa, fb, fp; };
+__device__ __forceinline__ PowerFam power_families(int w) {
+  if (w == CHOMP_P_GM) return PowerFam{F_HG, F_HM, F_PPGM};
+  if (w == CHOMP_P_GG) return PowerFam{F_HG, F_HG, F_PPGG};
+  return PowerFam{F_HM, F_HM, F_PPMM};
+}
+
+// Above k_max with Halo(extrapolate=True) (halo.py:300-312, 341-367, 405-431); x[] are
+// the epoch's misc[3..7] written by k_power_extrap.
+__device__ __forceinline__ double power_tail(const Epoch& E, const double* x, int w, double kv,
+                                             double k_max) {
+  if (w == CHOMP_P_MM) return linear_power(E, kv) * x[0];
+  const double* vs = w == CHOMP_P_GM ? x + 1 : x + 3;          // value at k_max, log-slope
+  return pow(kv / k_max, vs[1]) * vs[0];
+}
+
 __device__ __forceinline__ double halofit_mm(const Epoch& E, double k) {
   // halo.py:1339-1360
   const double lk = log(k);
@@ -942,7 +968,8 @@ struct PowerEval {
   const Epoch* E;
   const double *ca, *cb, *cp;     // pp coefficients: h_a, h_b, 1-halo term
   int NK, w;
-  bool halofit;
+  bool halofit, extrap;
+  const double* tail;             // misc[3..7] of the epoch (k_power_extrap)
   double x0, dx, k_min, k_max, c_lo;
 
   // Stage the coefficient sets of spectrum `which` of epoch table `t` into `sm`
@@ -954,6 +981,8 @@ struct PowerEval {
     E = Els;
     NK = L.NK;
     halofit = (which & CHOMP_P_HALOFIT) != 0;
+    extrap = (which & CHOMP_P_EXTRAPOLATE) != 0 && !halofit;   // HaloFit ignores it
+    tail = t + L.off_misc + 3;
     w = which & 15;
     int fa = F_HM, fb = F_HM, fp = F_PPMM;
     if (w == CHOMP_P_GM) { fa = F_HG; fb = F_HM; fp = F_PPGM; }
@@ -998,7 +1027,7 @@ struct PowerEval {
       return pmm * ha * hb + pp;
     }
     if (kv < k_min) return linear_power(*E, kv) * c_lo;
-    if (kv <= k_max) {
+    if (extrap ? kv < k_max : kv <= k_max) {
       const double lk = log(kv);
       const double ha = spline_eval_uniform(x0, dx, ca, NK, lk);
       const double hb = spline_eval_uniform(x0, dx, cb, NK, lk);
@@ -1006,9 +1035,47 @@ struct PowerEval {
       const double plin = 2.0 * kPi * kPi * delta_k_ln(*E, lk, kv) / (kv * kv * kv);
       return plin * ha * hb + pp;
     }
+    if (extrap) return power_tail(*E, tail, w, kv, k_max);
     return 0.0;                                           // k > k_max (or NaN)
   }
 };
+
+// Halo(extrapolate=True): the constants of the continuation above k_max, from the knot
+// tables of spectrum w (halo.py:300-312: misc[3]; :341-352 / :405-416: value at k_max and
+// mean log-slope over knots -7..-1 into misc[4,5] (gm) / misc[6,7] (gg)).  grid n, block 64.
+__global__ void k_power_extrap(chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs,
+                               double* __restrict__ tab, int w, int epoch0) {
+  __shared__ double lv[6], lx[6];
+  const int e = epoch0 + blockIdx.x;
+  const Epoch& E = epochs[e];
+  double* t = tab + (size_t)e * L.stride;
+  const PowerFam F = power_families(w);
+  const int NK = L.NK;
+  const double* ka = t + L.off_knot[F.fa];
+  const double* kb = t + L.off_knot[F.fb];
+  const double* kp = t + L.off_knot[F.fp];
+  const int i = threadIdx.x;
+  if (i < 6) {
+    const int j = NK - 7 + i;
+    const double x = linspace_at(log(cfg.k_min), log(cfg.k_max), NK, j);
+    lx[i] = x;
+    lv[i] = log(linear_power(E, exp(x)) * ka[j] * kb[j] + kp[j]);
+  }
+  __syncthreads();
+  if (i == 0) {
+    const double plin = linear_power(E, cfg.k_max);
+    const double ha = ka[NK - 1], hb = kb[NK - 1], pp = kp[NK - 1];
+    if (w == CHOMP_P_MM) {
+      t[L.off_misc + 3] = ha * hb + pp / plin;
+    } else {
+      double slope = 0.0;
+      for (int m = 0; m < 5; ++m) slope += (lv[m + 1] - lv[m]) / (lx[m + 1] - lx[m]);
+      double* vs = t + L.off_misc + (w == CHOMP_P_GM ? 4 : 6);
+      vs[0] = plin * ha * hb + pp;
+      vs[1] = slope / 5.0;
+    }
+  }
+}
 
 __global__ __launch_bounds__(256) void k_power(chomp_config cfg, TabLayout L,
                                                const Epoch* __restrict__ epochs,
@@ -1046,7 +1113,7 @@ __global__ __launch_bounds__(256) void k_power(chomp_config cfg, TabLayout L,
 // P(k) of epoch table t for one k on the per-lane path (any k, any interval).
 __device__ __forceinline__ double power_lane(const chomp_config& cfg, const TabLayout& L,
                                              const Epoch& E, const double* t, int fa, int fb,
-                                             int fp, int w, double kv) {
+                                             int fp, int w, bool extrap, double kv) {
   if (w == CHOMP_P_LIN) return linear_power(E, kv);
   const double x0 = log(cfg.k_min);
   const double dx = (log(cfg.k_max) - x0) / (double)(L.NK - 1);
@@ -1055,13 +1122,14 @@ __device__ __forceinline__ double power_lane(const chomp_config& cfg, const TabL
                         t[L.off_kpp[fp]] / linear_power(E, cfg.k_min);
     return linear_power(E, kv) * c_lo;
   }
-  if (kv <= cfg.k_max) {
+  if (extrap ? kv < cfg.k_max : kv <= cfg.k_max) {
     const double lk = log(kv);
     const double ha = spline_eval_uniform(x0, dx, t + L.off_kpp[fa], L.NK, lk);
     const double hb = spline_eval_uniform(x0, dx, t + L.off_kpp[fb], L.NK, lk);
     const double pp = spline_eval_uniform(x0, dx, t + L.off_kpp[fp], L.NK, lk);
     return 2.0 * kPi * kPi * delta_k_ln(E, lk, kv) / (kv * kv * kv) * ha * hb + pp;
   }
+  if (extrap) return power_tail(E, t + L.off_misc + 3, w, kv, cfg.k_max);
   return 0.0;
 }
 
@@ -1116,12 +1184,6 @@ __device__ __forceinline__ void store_wt16(double* p, double r0, double r1) {
 }
 
 
-struct PowerFam { int fa, fb, fp; };
-__device__ __forceinline__ PowerFam power_families(int w) {
-  if (w == CHOMP_P_GM) return PowerFam{F_HG, F_HM, F_PPGM};
-  if (w == CHOMP_P_GG) return PowerFam{F_HG, F_HG, F_PPGG};
-  return PowerFam{F_HM, F_HM, F_PPMM};
-}
 
 // Wavefronts (groups of 128 consecutive k) that cannot take a streaming path are
 // collected in a compact list for k_power_grid_lanes.  slow[0..1] are two counters used
@@ -1368,7 +1430,7 @@ __global__ __launch_bounds__(256) void k_power_stream(TabLayout L, const double*
 // of one cosmology; k outside [k_min, k_max] take the full formula (halo.py:314-320).
 __global__ __launch_bounds__(256) void k_power_grid_lanes(
     chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs,
-    const double* __restrict__ tab, int w, int epoch0, int n_epoch,
+    const double* __restrict__ tab, int w, bool extrap, int epoch0, int n_epoch,
     const double* __restrict__ k, size_t nk, double* __restrict__ out,
     const int* __restrict__ slow, int parity) {
   const int count = slow[parity];
@@ -1411,7 +1473,7 @@ __global__ __launch_bounds__(256) void k_power_grid_lanes(
           const double pp = pp_poly(t + L.off_kpp[F.fp], s.idx0, e0);
           r = fma(A * sh0, ha * hb, pp);
         } else {
-          r = power_lane(cfg, L, E, t, F.fa, F.fb, F.fp, w, s.k0);
+          r = power_lane(cfg, L, E, t, F.fa, F.fb, F.fp, w, extrap, s.k0);
         }
         o[0] = r;
       }
@@ -1423,7 +1485,7 @@ __global__ __launch_bounds__(256) void k_power_grid_lanes(
           const double pp = pp_poly(t + L.off_kpp[F.fp], s.idx1, e1);
           r = fma(A * sh1, ha * hb, pp);
         } else {
-          r = power_lane(cfg, L, E, t, F.fa, F.fb, F.fp, w, s.k1);
+          r = power_lane(cfg, L, E, t, F.fa, F.fb, F.fp, w, extrap, s.k1);
         }
         o[1] = r;
       }

@@ -754,6 +754,15 @@ CHOMP_HD double zheng_second(const Epoch& e, double mass) {
 // ln r_v and ln c through splines of exactly linear functions of ln M
 // (halo.py:839-855, 873-902); they are evaluated in closed form here.
 // ---------------------------------------------------------------------------
+// HaloExclusion._mass_window (halo.py:1223-1233): transform of the window that removes
+// halo pairs closer than two virial radii, kR = 2 k r_v.
+CHOMP_HD double exclusion_window(const SiCiTab& T, double kR) {
+  double s, c, si, ci;
+  fast_sincos(kR, &s, &c);
+  sici_sc(kR, s, c, T, &si, &ci);
+  return (kR * c + kR * kR * kR * ci + (2.0 - kR * kR) * s) / (3.0 * kR);
+}
+
 CHOMP_HD double y_nfw(const Epoch& e, const SiCiTab& T, double ln_k, double ln_mass) {
   const double ln_c = e.ln_c_const + e.beta * ln_mass;
   const double ln_rv = (e.ln_rv_const + ln_mass) * (1.0 / 3.0);
@@ -778,9 +787,10 @@ CHOMP_HD double y_nfw(const Epoch& e, const SiCiTab& T, double ln_k, double ln_m
 // The k-dependent core of y_nfw for a halo whose concentration con, ln(1+con),
 // ln r_s and 1/(ln(1+c) - c/(1+c)) are already known (per-node tables).
 CHOMP_HD double y_nfw_core(const SiCiTab& T, double ln_k, double ln_rs, double con,
-                           double ln_cp, double inv_mass_k) {
+                           double ln_cp, double inv_mass_k, double* z_out = nullptr) {
   const double ln_z = ln_k + ln_rs;
   const double z = exp(ln_z);
+  if (z_out) *z_out = z;                         // k r_s
   const double cp = 1.0 + con;
   const double cz = con * z;
   double sz, cz_c, scz, ccz;

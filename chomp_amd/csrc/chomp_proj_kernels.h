@@ -716,6 +716,54 @@ __global__ __launch_bounds__(256) void k_wtheta_mixed(chomp_config cfg, TabLayou
   if (threadIdx.x == 0) out[blockIdx.x] = v;
 }
 
+// correlation.py:496-501 (Correlation3d._correlation_integrand)
+struct Xi3dIntegrand {
+  const PowerEval* P;
+  const BesselTab* B;
+  double r;
+  __device__ __forceinline__ double operator()(double ln_k) const {
+    const double k = exp(ln_k);
+    return k * k / (2.0 * kPi) * (*P)(k) * bessel_j<0>(k * r, *B);
+  }
+};
+
+// grid n_r, block 256: one separation per workgroup.
+__global__ __launch_bounds__(256) void k_xi3d(chomp_config cfg, TabLayout HL,
+                                              const Epoch* __restrict__ epochs, int e,
+                                              const double* __restrict__ htab, int which,
+                                              const BesselTab* __restrict__ bess_g,
+                                              double k_min, double k_max,
+                                              const double* __restrict__ r,
+                                              double* __restrict__ out) {
+  extern __shared__ __align__(16) double sm[];
+  __shared__ Epoch E;
+  __shared__ BesselTab B;
+  __shared__ double red[romberg_scratch<4, 2>()];
+  copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
+               kEpochDoubles);
+  copy_doubles(reinterpret_cast<double*>(&B), reinterpret_cast<const double*>(bess_g),
+               (int)(sizeof(BesselTab) / sizeof(double)));
+  PowerEval P;
+  P.stage(cfg, HL, &E, htab + (size_t)e * HL.stride, which, sm);
+  __syncthreads();
+  P.finish();
+  Xi3dIntegrand f{&P, &B, r[blockIdx.x]};
+  const double v = romberg1<4>(f, log(k_min), log(k_max), cfg.global_precision,
+                               cfg.corr_precision, cfg.divmax, red);
+  if (threadIdx.x == 0) out[blockIdx.x] = v;
+}
+
+// Not-a-knot cubic spline through (xk, yk) evaluated at x: one block; c: 4 (nk - 1)
+// doubles, w: 2 nk doubles of scratch.
+__global__ void k_spline_eval(const double* __restrict__ xk, const double* __restrict__ yk, int nk,
+                              double* __restrict__ c, double* __restrict__ w,
+                              const double* __restrict__ x, int n, double* __restrict__ out) {
+  if (threadIdx.x == 0) spline_build(xk, yk, nk, c, w);
+  __threadfence_block();
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = spline_eval(xk, c, nk, x[i]);
+}
+
 // correlation.py:387-392
 struct CellIntegrand {
   const PowerEval* P;

@@ -59,9 +59,6 @@ class Halo(object):
         if input_hod is None:
             input_hod = hod.HODZheng()
         self.local_hod = input_hod
-        if extrapolate:
-            raise _lib.ChompScopeError(
-                "extrapolate=True (halo.py:300-312, 341-367) is not accelerated yet")
         self._extrapolate = extrapolate
         # the dictionary the PROFILE sees: fixed here, untouched by set_halo
         self._profile_dict = dict(halo_dict)
@@ -108,7 +105,8 @@ class Halo(object):
             if (need_tables & bit) and not getattr(self, flag):
                 build |= bit
         if build or not self._nbar_valid:
-            ctx.halo_setup(self._profile(), self.local_hod, build)
+            ctx.halo_setup(self._profile(), self.local_hod,
+                           build | (_lib.T_EXCLUSION if self._exclusion else 0))
             for flag, bit in _FLAG_BITS:
                 if build & bit:
                     setattr(self, flag, True)
@@ -131,20 +129,24 @@ class Halo(object):
         dv = self._profile()['delta_v']
         return float(self._scalars()["delta_v"]) if dv == -1 else dv
 
+    _exclusion = False          # HaloExclusion sets it: CHOMP_T_EXCLUSION on every build
+
+    def _power_code(self, which):
+        """CHOMP_P_* code of a spectrum of this object (extrapolation flag included)."""
+        if self._extrapolate and which != _lib.P_LIN and not (which & _lib.P_HALOFIT):
+            which |= _lib.P_EXTRAPOLATE
+        return which
+
     def _power(self, which, need, k):
         ka = numpy.asarray(k, dtype=numpy.float64)
         ctx = self._sync(need)
-        return ctx.power(which, ka, 0, 1).reshape(ka.shape)
+        return ctx.power(self._power_code(which), ka, 0, 1).reshape(ka.shape)
 
     # -- reference surface -----------------------------------------------------
     def get_extrapolation(self):
         return self._extrapolate
 
     def set_extrapolation(self, boolean):
-        if boolean:
-            raise _lib.ChompScopeError(
-                "extrapolation beyond [k_min, k_max] (halo.py:300-312) is not "
-                "accelerated yet")
         self._extrapolate = boolean
 
     def get_cosmology(self):
@@ -270,6 +272,62 @@ class Halo(object):
             raise _lib.ChompScopeError(
                 "_%s(k) is only served at the spline knots" % name)
         return numpy.where(ok, knots[idx], 0.0)
+
+
+    # -- ASCII writers (halo.py:587-647) -----------------------------------------
+    def write(self, output_file_name):
+        """halo.py:587-603.  The last knot is exp(ln k_max) = 100.00000000000004 > k_max,
+        so -- as in the reference -- its row holds zeros unless extrapolating."""
+        k = numpy.exp(self._ln_k_array)
+        cols = (k, self.linear_power(k), self.power_mm(k), self.power_gg(k), self.power_gm(k))
+        with open(output_file_name, "w") as f:
+            f.write("#ttype1 = k [Mpc/h]\n#ttype2 = linear_power [(Mpc/h)^3]\n"
+                    "#ttype3 = power_mm\n#ttype4 = power_gg\n"
+                    "#ttype5 = power_gm\n")
+            for row in zip(*cols):
+                f.write("%1.10f %1.10f %1.10f %1.10f %1.10f\n" % row)
+
+    def write_halo(self, output_file_name, k=None):
+        """halo.py:605-627 (the halo_normalization column needs scipy's hyp2f1 and is
+        unused by the NFW path: written as nan)."""
+        if k is None:
+            k = 0.01
+        ln_k = numpy.log(k)
+        mass = self.mass.mass(self.mass._nu_array)
+        cols = (mass, self.y(ln_k, mass), self.concentration(mass),
+                numpy.full(mass.shape, numpy.nan), self.virial_radius(mass))
+        with open(output_file_name, "w") as f:
+            f.write("#ttype1 = mass [M_solar/h]\n"
+                    "#ttype2 = y(k, M), NFW Fourier Transform\n"
+                    "#ttype3 = concentration\n#ttype4 = halo_norm\n"
+                    "#ttype4 = halo_normalization"
+                    "#ttype5 = virial_radius [M_solar/h]\n")
+            for row in zip(*cols):
+                f.write("%1.10f %1.10f %1.10f %1.10f %1.10f\n" % row)
+
+    def write_power_components(self, output_file_name):
+        """halo.py:629-647."""
+        k = numpy.exp(self._ln_k_array)
+        cols = (k, self._h_m(k), self._pp_mm(k), self._h_g(k), self._pp_gm(k), self._pp_gg(k))
+        with open(output_file_name, "w") as f:
+            f.write("#ttype1 = k [Mpc/h]\n#ttype2 = 2 halo dark matter component\n"
+                    "#ttype3 = dark matter poisson component\n"
+                    "#ttype4 = 2 halo galaxy component\n"
+                    "#ttype5 = matter-galaxy poisson component\n"
+                    "#ttype6 = galaxy-galaxy poisson component\n")
+            for row in zip(*cols):
+                f.write("%1.10f %1.10f %1.10f %1.10f %1.10f %1.10f\n" % row)
+
+
+class HaloExclusion(Halo):
+    """halo.py:1201-1233: the 2-halo integrands h_m, h_g carry the transform of a window
+    that excludes halo pairs closer than two virial radii."""
+    _exclusion = True
+
+    def __init__(self, redshift=0.0, input_hod=None, cosmo_single_epoch=None,
+                 mass_func=None, halo_dict=None, **kws):
+        Halo.__init__(self, redshift, input_hod, cosmo_single_epoch,
+                      mass_func, halo_dict, **kws)
 
 
 class HaloFit(Halo):

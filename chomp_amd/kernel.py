@@ -165,6 +165,13 @@ class WindowFunction(object):
     def set_cosmology(self, cosmo_dict):
         self.cosmo = cosmology.MultiEpoch(self.z_min, self.z_max, cosmo_dict)
 
+    def write(self, output_file_name):
+        """kernel.py:342-355 (header text as in the reference, "/n" included)."""
+        with open(output_file_name, "w") as f:
+            f.write("#ttype1 = chi [Mpc/h]/n#ttype2 = window function value\n")
+            for chi, wf in zip(self._chi_array, self._wf_array):
+                f.write("%1.10f %1.10f\n" % (chi, wf))
+
     def window_function(self, chi):
         return self._dev().window_eval(0, numpy.asarray(chi, dtype=numpy.float64))
 
@@ -263,6 +270,14 @@ class Kernel(object):
         self.cosmo.set_cosmology(cosmo_dict)
         self.window_function_a.set_cosmology_object(self.cosmo)
         self.window_function_b.set_cosmology_object(self.cosmo)
+
+    def write(self, output_file_name):
+        """kernel.py:765-781."""
+        with open(output_file_name, "w") as f:
+            f.write("#ttype1 = k*theta [h/Mpc*Radians]\n"
+                    "#ttype2 = kernel [(h/Mpc)^2]\n")
+            for ln_ktheta, kernel in zip(self._ln_ktheta_array, self._kernel_array):
+                f.write("%1.10g %1.10g\n" % (numpy.exp(ln_ktheta), kernel))
 
     def kernel(self, ln_ktheta):
         return self._dev().kernel_eval(numpy.asarray(ln_ktheta, dtype=numpy.float64))

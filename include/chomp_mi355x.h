@@ -77,6 +77,9 @@ typedef struct chomp_config {
 #define CHOMP_T_H_G 4u    /* Halo._initialize_h_g    halo.py:929-969   */
 #define CHOMP_T_PP_GM 8u  /* Halo._initialize_pp_gm  halo.py:1043-1086 */
 #define CHOMP_T_PP_GG 16u /* Halo._initialize_pp_gg  halo.py:996-1041  */
+/* OR-ed in: the object is a HaloExclusion (halo.py:1201-1233): h_m and h_g are built
+ * with the halo-exclusion mass window in their integrands. */
+#define CHOMP_T_EXCLUSION 64u
 #define CHOMP_FAM_MM (CHOMP_T_H_M | CHOMP_T_PP_MM)               /* power_mm */
 #define CHOMP_FAM_GM (CHOMP_T_H_M | CHOMP_T_H_G | CHOMP_T_PP_GM) /* power_gm */
 #define CHOMP_FAM_GG (CHOMP_T_H_G | CHOMP_T_PP_GG)               /* power_gg */
@@ -87,6 +90,10 @@ typedef struct chomp_config {
 #define CHOMP_P_GM 2  /* Halo.power_gm/mg   halo.py:322-389 */
 #define CHOMP_P_GG 3  /* Halo.power_gg      halo.py:391-439 */
 #define CHOMP_P_HALOFIT 16 /* OR-ed in: HaloFit.power_* halo.py:1325-1413 */
+/* OR-ed in: Halo(extrapolate=True) -- above k_max P_mm continues as a rescaled linear
+ * spectrum, P_gm / P_gg as power laws (halo.py:300-312, 341-367, 405-431); HaloFit
+ * ignores it, as in the reference. */
+#define CHOMP_P_EXTRAPOLATE 32
 
 void chomp_default_config(chomp_config* cfg);
 
@@ -316,6 +323,18 @@ int chomp_wtheta(chomp_ctx* ctx, int which, size_t epoch, double k_min,
 /* CorrelationFourier.correlation(l) (correlation.py:360-392): Limber C_l. */
 int chomp_cell(chomp_ctx* ctx, int which, size_t epoch, double D_z,
                const double* ell, size_t n, double* out, int mem);
+
+/* Correlation3d.raw_correlation(r) (correlation.py:470-499): xi(r) = int dlnk k^2/(2 pi)
+ * P(k) J0(k r) over [k_min, k_max] -- the cylindrical J0, as the reference has it.  One
+ * wavefront-group per r; P is `which` of halo epoch `epoch`. */
+int chomp_xi3d(chomp_ctx* ctx, int which, size_t epoch, double k_min, double k_max,
+               const double* r, size_t n, double* out, int mem);
+/* scipy InterpolatedUnivariateSpline(xk, yk)(x) (k = 3, not-a-knot), host buffers: the
+ * 50-knot xi(r) spline of Correlation3d.compute_correlation / correlation
+ * (correlation.py:459-468, 501-510).  x outside [xk[0], xk[nk-1]] extrapolates the end
+ * pieces, as FITPACK does. */
+int chomp_spline_eval(chomp_ctx* ctx, const double* xk, const double* yk, size_t nk,
+                      const double* x, size_t n, double* out);
 
 /* Arithmetic of the w(theta) integral (BASELINE.json configs[4]: "mixed fp32/fp64 with
  * tolerance sweep").  The reference computes everything in fp64; F64 is the

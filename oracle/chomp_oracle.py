@@ -407,16 +407,17 @@ def zheng_second(h, mass):
 # ---------------------------------------------------------------------------
 # L3: halo model (halo.py)
 # ---------------------------------------------------------------------------
-def halo_table(e=None, m=None, hod=None, halo_dict=None, families=("mm",)):
+def halo_table(e=None, m=None, hod=None, halo_dict=None, families=("mm",), exclusion=False):
     """halo.py:41-104 + the lazy initialisers.  ``families`` selects which of
     the 1-halo/2-halo knot tables to build: 'mm' (h_m, pp_mm), 'gm' (h_m, h_g,
-    pp_gm), 'gg' (h_g, pp_gg)."""
+    pp_gm), 'gg' (h_g, pp_gg).  ``exclusion``: HaloExclusion (halo.py:1201-1233), whose
+    two 2-halo integrands carry the halo-exclusion mass window."""
     e = epoch() if e is None else e
     hd = default_halo_dict if halo_dict is None else halo_dict
     m = mass_table(e, hd) if m is None else m
     hod = zheng(prec=e.prec) if hod is None else hod
     prec = e.prec
-    t = Table(e=e, m=m, hod=hod, halo_dict=hd)
+    t = Table(e=e, m=m, hod=hod, halo_dict=hd, exclusion=bool(exclusion))
     t.k_min, t.k_max = e.limits["k_min"], e.limits["k_max"]
     t.ln_k = numpy.linspace(numpy.log(t.k_min), numpy.log(t.k_max),
                             prec["halo_npoints"])             # :52-54
@@ -479,10 +480,22 @@ def y_nfw(t, ln_k, mass):
     return rho_km / mass_k
 
 
-def _h_m_integrand(ln_nu, t, ln_k, norm):                       # :922-927
+def _mass_window(t, mass, ln_k):
+    """HaloExclusion._mass_window, halo.py:1223-1233: transform of the window that cuts
+    halos within two virial radii of each other (1 for the plain Halo)."""
+    if not getattr(t, "exclusion", False):
+        return 1.0
+    k = numpy.exp(ln_k)
+    kR = k * 2.0 * numpy.exp(t.ln_r_v_spline(numpy.log(mass)))
+    return ((kR * numpy.cos(kR) + kR * kR * kR * special.sici(kR)[1] +
+             (2 - kR * kR) * numpy.sin(kR)) / (3.0 * kR))
+
+
+def _h_m_integrand(ln_nu, t, ln_k, norm):                       # :922-927, 1208-1213
     nu = numpy.exp(ln_nu)
     mass = mass_of_nu(t.m, nu)
-    return norm * nu * f_nu(t.m, nu) * bias_nu(t.m, nu) * y_nfw(t, ln_k, mass)
+    return (norm * nu * _mass_window(t, mass, ln_k) * f_nu(t.m, nu) * bias_nu(t.m, nu) *
+            y_nfw(t, ln_k, mass))
 
 
 def _pp_mm_integrand(ln_nu, t, ln_k, norm):                     # :989-994
@@ -492,10 +505,10 @@ def _pp_mm_integrand(ln_nu, t, ln_k, norm):                     # :989-994
     return norm * nu * f_nu(t.m, nu) * mass * y * y
 
 
-def _h_g_integrand(ln_nu, t, ln_k, norm):                       # :964-969
+def _h_g_integrand(ln_nu, t, ln_k, norm):                       # :964-969, 1215-1221
     nu = numpy.exp(ln_nu)
     mass = mass_of_nu(t.m, nu)
-    return (norm * nu * f_nu(t.m, nu) * bias_nu(t.m, nu) *
+    return (norm * nu * _mass_window(t, mass, ln_k) * f_nu(t.m, nu) * bias_nu(t.m, nu) *
             y_nfw(t, ln_k, mass) * zheng_first(t.hod, mass) / mass)
 
 
@@ -576,8 +589,11 @@ def _ranged(t, spline, k):
                            spline(numpy.log(k)), 0.0)
 
 
-def halo_power(t, which, k):
-    """halo.py:266-439 with extrapolate=False.  which: 'lin','mm','gm','gg'."""
+def halo_power(t, which, k, extrapolate=False):
+    """halo.py:266-439.  which: 'lin','mm','gm','gg'.  ``extrapolate`` follows
+    Halo(extrapolate=True): above k_max P_mm continues as a rescaled linear spectrum
+    (:300-312), P_gm / P_gg as power laws whose slope is the mean log-slope over knots
+    -7..-1 (:341-367, 405-431)."""
     k = numpy.asarray(k, dtype=float)
     e = t.e
     if which == "lin":
@@ -592,12 +608,38 @@ def halo_power(t, which, k):
         pp = t.pp_gg_spline
     else:
         raise KeyError(which)
-    kmin = t.k_min
+    kmin, kmax = t.k_min, t.k_max
     lo = linear_power(e, k) * (
         _ranged(t, ha, kmin) * _ranged(t, hb, kmin) +
         _ranged(t, pp, kmin) / linear_power(e, kmin))
     mid = linear_power(e, k) * _ranged(t, ha, k) * _ranged(t, hb, k) + _ranged(t, pp, k)
-    return numpy.where(k < t.k_min, lo, numpy.where(k <= t.k_max, mid, 0.0))
+    if not extrapolate:
+        return numpy.where(k < t.k_min, lo, numpy.where(k <= t.k_max, mid, 0.0))
+    if which == "mm":
+        hi = linear_power(e, k) * (
+            _ranged(t, ha, kmax) * _ranged(t, hb, kmax) +
+            _ranged(t, pp, kmax) / linear_power(e, kmax))
+    else:
+        k_array = numpy.exp(t.ln_k[-7:-1])
+        log_values = numpy.log(linear_power(e, k_array) * _ranged(t, ha, k_array) *
+                               _ranged(t, hb, k_array) + _ranged(t, pp, k_array))
+        slope = numpy.mean((log_values[1:] - log_values[:-1]) /
+                           (t.ln_k[-6:-1] - t.ln_k[-7:-2]))
+        with numpy.errstate(all="ignore"):
+            hi = numpy.power(k / kmax, slope) * (
+                linear_power(e, kmax) * _ranged(t, ha, kmax) * _ranged(t, hb, kmax) +
+                _ranged(t, pp, kmax))
+    return numpy.where(k < t.k_min, lo, numpy.where(k < t.k_max, mid, hi))
+
+
+def log_slope(t, which):
+    """Halo._log_slope_gm / _log_slope_gg (halo.py:343-352, 407-416)."""
+    ha, hb, pp = ((t.h_g_spline, t.h_m_spline, t.pp_gm_spline) if which == "gm" else
+                  (t.h_g_spline, t.h_g_spline, t.pp_gg_spline))
+    k_array = numpy.exp(t.ln_k[-7:-1])
+    log_values = numpy.log(linear_power(t.e, k_array) * _ranged(t, ha, k_array) *
+                           _ranged(t, hb, k_array) + _ranged(t, pp, k_array))
+    return numpy.mean((log_values[1:] - log_values[:-1]) / (t.ln_k[-6:-1] - t.ln_k[-7:-2]))
 
 
 def halofit_table(t):
@@ -862,6 +904,40 @@ def kernel_eval(kt, ln_ktheta):
 # ---------------------------------------------------------------------------
 # L5: observables (correlation.py)
 # ---------------------------------------------------------------------------
+def xi3d_raw(power, r, k_min, k_max, prec=None, levels=None):
+    """Correlation3d.raw_correlation (correlation.py:470-499): int dlnk k^2/(2 pi) P(k) J0(k r)
+    -- the cylindrical Bessel function, as the reference has it."""
+    prec = default_precision if prec is None else prec
+    out = []
+    for rv in numpy.atleast_1d(r):
+        def integrand(ln_k, rr):
+            k = numpy.exp(ln_k)
+            return k * k / (2.0 * numpy.pi) * power(k) * special.j0(k * rr)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", AccuracyWarning)
+            val, level = romberg(integrand, numpy.log(k_min), numpy.log(k_max),
+                                 args=(rv,), vec_func=True, tol=prec["global_precision"],
+                                 rtol=prec["corr_precision"], divmax=prec["divmax"],
+                                 return_level=True)
+        out.append(val)
+        if levels is not None:
+            levels.append(level)
+    return numpy.array(out)
+
+
+def xi3d(power, r_min, r_max, r, k_min, k_max, prec=None):
+    """Correlation3d.__init__/compute_correlation/correlation (correlation.py:414-510):
+    corr_npoints log-spaced r, spline in r, zero outside (r_min, r_max]."""
+    prec = default_precision if prec is None else prec
+    log_r_min, log_r_max = numpy.log10(r_min), numpy.log10(r_max)
+    r_array = numpy.logspace(log_r_min, log_r_max, prec["corr_npoints"])
+    xi_array = xi3d_raw(power, r_array, k_min, k_max, prec)
+    spline = InterpolatedUnivariateSpline(r_array, xi_array)
+    r = numpy.asarray(r, dtype=float)
+    return (numpy.where(numpy.logical_and(r <= 10.0 ** log_r_max, r > 10.0 ** log_r_min),
+                        spline(r), 0.0), r_array, xi_array)
+
+
 def theta_bins(theta_min_deg, theta_max_deg, bins_per_decade=5.0):
     """correlation.py:69-90."""
     d2r = numpy.pi / 180.0

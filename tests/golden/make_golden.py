@@ -4,7 +4,7 @@
 Development-container only: needs /root/reference (read as text at run time by
 ref_loader.py; nothing of it is stored here).  Fixtures are plain data: inputs,
 expected outputs and per-stage intermediate tables (SURVEY.md section 8(c),
-G1..G7).  Run from anywhere:  python tests/golden/make_golden.py [names...]
+G1..G7; G8, G9 for the section 8(f) rows).  Run from anywhere:  python tests/golden/make_golden.py [names...]
 
 All fixtures use the precision dictionary of defaults.py:62-92 unless they say
 otherwise ("prec": "unit_test" -> window_npoints 50, unit_test.py:17-46).
@@ -265,6 +265,45 @@ def g7(ns):
     save("g7_ggl_halofit", **out)
 
 
+def g8(ns):
+    """Halo(extrapolate=True) beyond k_max (halo.py:300-312, 341-367,
+    405-431) and HaloExclusion (halo.py:1201-1233)."""
+    k = numpy.concatenate([numpy.logspace(-4, 3, 36),
+                           [100.0 * (1 - 1e-9), 100.0, 100.0 * (1 + 1e-9), 250.0]])
+    out = {"k": k, "z": numpy.array([0.0, 0.5])}
+    for i, z in enumerate(out["z"]):
+        h = ns.halo.Halo(float(z), extrapolate=True)
+        out["ext_mm_%d" % i] = h.power_mm(k)
+        out["ext_gm_%d" % i] = h.power_gm(k)
+        out["ext_gg_%d" % i] = h.power_gg(k)
+        out["ext_slopes_%d" % i] = numpy.array([h._log_slope_gm, h._log_slope_gg])
+    kx = numpy.logspace(-3, 2, 40)
+    hx = ns.halo.HaloExclusion(0.0)
+    out.update(kx=kx, excl_mm=hx.power_mm(kx), excl_gm=hx.power_gm(kx),
+               excl_gg=hx.power_gg(kx), excl_ln_k=hx._ln_k_array,
+               excl_h_m=hx._h_m_spline(hx._ln_k_array),
+               excl_h_g=hx._h_g_spline(hx._ln_k_array))
+    save("g8_extrapolate_exclusion", **out)
+
+
+def g9(ns):
+    """Correlation3d xi(r) (correlation.py:408-510)."""
+    out = {}
+    r_test = numpy.concatenate([numpy.logspace(-1.2, 1.9, 16), [0.1, 50.0, 49.999]])
+    out["r_test"] = r_test
+    for tag, kw in (("mm", dict(powSpec="power_mm")), ("gg", dict(powSpec="power_gg")),
+                    ("mm_wide", dict(powSpec="power_mm", k_min=1e-4, k_max=1e3))):
+        c3 = ns.correlation.Correlation3d(0.1, 50.0, redshift=0.0, **kw)
+        t0 = time.time()
+        c3.compute_correlation()
+        out["t_" + tag] = time.time() - t0
+        out["r_array"] = c3.r_array
+        out["xi_" + tag] = numpy.array(c3.xi_array)
+        out["corr_" + tag] = c3.correlation(r_test)
+        out["extrap_" + tag] = numpy.array(c3.halo.get_extrapolation())
+    save("g9_correlation3d", **out)
+
+
 def pins():
     """Known-answer literals held by the reference's own tests (unit_test.py),
     restricted to the classes that pass against the shipped code."""
@@ -297,7 +336,7 @@ def pins():
 
 
 def main():
-    names = sys.argv[1:] or ["pins", "g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    names = sys.argv[1:] or ["pins", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     ns = ref_loader.load()
     cwd = os.getcwd()
     with tempfile.TemporaryDirectory() as tmp:

@@ -20,8 +20,9 @@ def test_scope_errors():
     from chomp_amd import cosmology, halo, kernel, _lib
     with pytest.raises(_lib.ChompScopeError):
         cosmology.SingleEpoch(0.0, with_bao=True)
-    with pytest.raises(_lib.ChompScopeError):
-        halo.Halo(0.0, extrapolate=True)
+    h = halo.Halo(0.0, extrapolate=True)          # accelerated since SURVEY 8(f) rank 2
+    assert h.get_extrapolation() and (h._power_code(_lib.P_GM) & _lib.P_EXTRAPOLATE)
+    assert h._power_code(_lib.P_LIN) == _lib.P_LIN
     with pytest.raises(_lib.ChompScopeError):
         halo.Halo(0.0, halo_dict=dict(stq=0.3, st_little_a=0.707, c0=9.0, beta=-0.13,
                                       alpha=-1.5, delta_v=-1.0))

@@ -1,0 +1,127 @@
+"""GPU parity of the SURVEY 8(f) "next" rows built so far: Halo(extrapolate=True) and
+HaloExclusion (rank 2), Correlation3d and the ASCII writers (rank 3), against vectors
+produced by running the reference (tests/golden/g8, g9)."""
+import os
+
+import numpy
+import pytest
+from scipy.interpolate import InterpolatedUnivariateSpline
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def test_extrapolation_above_k_max():
+    """halo.py:300-312, 341-367, 405-431."""
+    from chomp_amd import halo
+    g = load_golden("g8_extrapolate_exclusion")
+    for i, z in enumerate(g["z"]):
+        h = halo.Halo(float(z), extrapolate=True)
+        assert h.get_extrapolation() is True
+        assert rel_err(h.power_mm(g["k"]), g["ext_mm_%d" % i]) < RTOL
+        assert rel_err(h.power_gm(g["k"]), g["ext_gm_%d" % i]) < RTOL
+        assert rel_err(h.power_gg(g["k"]), g["ext_gg_%d" % i]) < RTOL
+    # switching it off restores the zero branch; on again (set_extrapolation, :113-121)
+    h.set_extrapolation(False)
+    assert h.power_gm(numpy.array([250.0]))[0] == 0.0
+    h.set_extrapolation(True)
+    assert abs(h.power_gm(numpy.array([250.0]))[0] / g["ext_gm_1"][-1] - 1) < RTOL
+    # a large device-resident grid reaching beyond k_max (streaming + per-lane passes)
+    import torch
+    kd = torch.logspace(-4, 3, 1 << 16, dtype=torch.float64, device="cuda")
+    ctx = h._sync(7)
+    big = ctx.power(h._power_code(1), kd, 0, 1)[0].cpu().numpy()
+    ref = numpy.exp(numpy.interp(numpy.log(g["k"][:36]), numpy.log(kd.cpu().numpy()), numpy.log(big)))
+    assert rel_err(ref, g["ext_mm_1"][:36]) < 2e-3          # (interpolation of the dense grid)
+    small = h.power_mm(kd.cpu().numpy()[::997])
+    assert numpy.array_equal(small, big[::997])
+
+
+def test_halo_exclusion():
+    """halo.py:1201-1233."""
+    from chomp_amd import halo
+    g = load_golden("g8_extrapolate_exclusion")
+    hx = halo.HaloExclusion(0.0)
+    assert rel_err(hx.power_mm(g["kx"]), g["excl_mm"]) < RTOL
+    assert rel_err(hx.power_gm(g["kx"]), g["excl_gm"]) < RTOL
+    assert rel_err(hx.power_gg(g["kx"]), g["excl_gg"]) < RTOL
+    k_knots = numpy.exp(g["excl_ln_k"])[:-1]
+    assert rel_err(hx._h_m(k_knots), g["excl_h_m"][:-1]) < RTOL
+    assert rel_err(hx._h_g(k_knots), g["excl_h_g"][:-1]) < RTOL
+    # the plain Halo differs visibly (the window suppresses the 2-halo term at high k)
+    h = halo.Halo(0.0)
+    assert rel_err(h.power_mm(g["kx"]), g["excl_mm"]) > 1e-2
+
+
+def test_correlation3d():
+    """correlation.py:408-510, all 50 separations of each case."""
+    from chomp_amd import correlation
+    g = load_golden("g9_correlation3d")
+    for tag, kw in (("mm", dict(powSpec="power_mm")), ("gg", dict(powSpec="power_gg")),
+                    ("mm_wide", dict(powSpec="power_mm", k_min=1e-4, k_max=1e3))):
+        c3 = correlation.Correlation3d(0.1, 50.0, redshift=0.0, **kw)
+        assert c3.halo.get_extrapolation() == bool(g["extrap_" + tag])
+        c3.compute_correlation()
+        assert numpy.allclose(c3.r_array, g["r_array"], rtol=1e-14)
+        scale = numpy.max(numpy.abs(g["xi_" + tag]))
+        # xi changes sign: relative to the local magnitude where it is not crossing zero
+        big = numpy.abs(g["xi_" + tag]) > 1e-3 * scale
+        assert rel_err(c3.xi_array[big], g["xi_" + tag][big]) < RTOL, tag
+        assert numpy.max(numpy.abs(c3.xi_array - g["xi_" + tag])) < RTOL * scale, tag
+        got = c3.correlation(g["r_test"])
+        assert numpy.max(numpy.abs(got - g["corr_" + tag])) < RTOL * scale, tag
+        assert got[g["r_test"] <= 0.1].tolist() == [0.0] * int(numpy.sum(g["r_test"] <= 0.1))
+
+
+def test_spline_eval_matches_fitpack():
+    from chomp_amd import cosmology
+    ctx = cosmology._context()
+    rng = numpy.random.default_rng(3)
+    xk = numpy.sort(rng.uniform(0.0, 10.0, 50))
+    yk = numpy.sin(xk) * numpy.exp(0.1 * xk)
+    x = numpy.concatenate([rng.uniform(xk[0], xk[-1], 500), xk, [xk[0] - 0.2, xk[-1] + 0.3]])
+    ref = InterpolatedUnivariateSpline(xk, yk)(x)
+    assert numpy.max(numpy.abs(ctx.spline_eval(xk, yk, x) - ref)) < 1e-12
+    with pytest.raises(ValueError):
+        ctx.spline_eval(xk[::-1].copy(), yk, x)
+
+
+def test_ascii_writers(tmp_path):
+    """halo.py:587-647, kernel.py:342-355, 765-781, correlation.py:277-289: same columns
+    and number formats as the reference's files."""
+    from chomp_amd import cosmology, correlation, halo, kernel
+    h = halo.Halo(0.0)
+    fn = str(tmp_path / "halo.txt")
+    h.write(fn)
+    rows = numpy.loadtxt(fn)
+    assert rows.shape == (50, 5)
+    k = rows[:, 0]
+    assert numpy.allclose(k, numpy.exp(h._ln_k_array), rtol=0, atol=1e-10)
+    assert numpy.allclose(rows[:-1, 2], h.power_mm(numpy.exp(h._ln_k_array))[:-1], rtol=1e-6, atol=1e-10)
+    assert rows[-1, 2] == 0.0            # exp(log(k_max)) > k_max: the reference's last row
+    open(fn).readline().startswith("#ttype1 = k [Mpc/h]")
+    h.write_power_components(str(tmp_path / "comp.txt"))
+    comp = numpy.loadtxt(str(tmp_path / "comp.txt"))
+    assert comp.shape == (50, 6) and numpy.all(comp[:-1, 1] > 0)
+    h.write_halo(str(tmp_path / "prof.txt"))
+    prof = numpy.loadtxt(str(tmp_path / "prof.txt"))
+    assert prof.shape == (50, 5) and numpy.all(prof[:, 2] > 0)
+    d2r = numpy.pi / 180.0
+    cm = cosmology.MultiEpoch(0.0, 5.0)
+    wa = kernel.WindowFunctionGalaxy(kernel.dNdzMagLim(0.0, 2.0, 2.0, 0.3, 2.0), cm)
+    wb = kernel.WindowFunctionGalaxy(kernel.dNdzMagLim(0.0, 2.0, 2.0, 0.3, 2.0), cm)
+    kern = kernel.Kernel(1e-6 * d2r, 100.0 * d2r, wa, wb, cm)
+    kern.write(str(tmp_path / "kern.txt"))
+    kt = numpy.loadtxt(str(tmp_path / "kern.txt"))
+    assert kt.shape == (50, 2) and numpy.allclose(kt[:, 1], kern._kernel_array, rtol=1e-9)
+    wa.write(str(tmp_path / "win.txt"))
+    wt = numpy.loadtxt(str(tmp_path / "win.txt"))
+    assert wt.shape[1] == 2 and wt.shape[0] == wa._chi_array.size
+    corr = correlation.Correlation(0.01, 1.0, kern, input_halo=h, power_spec="power_mm")
+    corr.compute_correlation()
+    corr.write(str(tmp_path / "w.txt"))
+    wt = numpy.loadtxt(str(tmp_path / "w.txt"))
+    assert numpy.allclose(wt[:, 0], corr.theta_array / d2r, rtol=1e-9)
+    assert numpy.allclose(wt[:, 1], corr.wtheta_array, rtol=1e-9)

@@ -197,3 +197,35 @@ def test_g7_ggl_halofit():
     assert rel_err(w, g["w_ggl"][::4]) < 1e-9
     c = o.cell(kt, power, g["ell"][::8], D_z)
     assert rel_err(c, g["cl_ggl"][::8]) < 1e-9
+
+
+def test_g8_extrapolation_and_exclusion():
+    """SURVEY 8(f) rank 2 against the reference: Halo(extrapolate=True) above k_max
+    (halo.py:300-312, 341-367, 405-431) and HaloExclusion (halo.py:1201-1233)."""
+    g = load_golden("g8_extrapolate_exclusion")
+    e = o.epoch(None, 0.0)
+    m = o.mass_table(e)
+    t = o.halo_table(e, m, families=("mm", "gm", "gg"))
+    for w in ("mm", "gm", "gg"):
+        assert rel_err(o.halo_power(t, w, g["k"], extrapolate=True), g["ext_%s_0" % w]) < 1e-12
+    assert abs(o.log_slope(t, "gm") - g["ext_slopes_0"][0]) < 1e-12
+    assert abs(o.log_slope(t, "gg") - g["ext_slopes_0"][1]) < 1e-12
+    tx = o.halo_table(e, m, families=("mm", "gm", "gg"), exclusion=True)
+    assert rel_err(tx.h_m, g["excl_h_m"]) < 1e-11 and rel_err(tx.h_g, g["excl_h_g"]) < 1e-11
+    for w in ("mm", "gm", "gg"):
+        assert rel_err(o.halo_power(tx, w, g["kx"]), g["excl_" + w]) < 1e-11
+
+
+def test_g9_correlation3d():
+    """Correlation3d xi(r) at a few of the reference's 50 separations
+    (the full table takes a minute on the CPU; the GPU test checks all of it)."""
+    g = load_golden("g9_correlation3d")
+    e = o.epoch(None, 0.0)
+    t = o.halo_table(e, o.mass_table(e), families=("mm",))
+    idx = [0, 12, 30, 49]
+    xi = o.xi3d_raw(lambda k: o.halo_power(t, "mm", k), g["r_array"][idx], 1e-3, 100.0)
+    assert rel_err(xi, g["xi_mm"][idx]) < 1e-11
+    xi = o.xi3d_raw(lambda k: o.halo_power(t, "mm", k, extrapolate=True), g["r_array"][idx],
+                    1e-4, 1e3)
+    assert rel_err(xi, g["xi_mm_wide"][idx]) < 1e-11
+    assert bool(g["extrap_mm_wide"]) and not bool(g["extrap_mm"])
