@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--workload", default="c2", choices=["c2", "c3"])
     ap.add_argument("--roofline-nk", type=int, default=1 << 20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="test-only: run the N > 1 path on ONE GPU (every rank on device 0, "
+                         "gloo all-gather through host memory); the numbers mean nothing")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -96,11 +99,16 @@ def main():
     import torch
     import torch.distributed as dist
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    if args.rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from chomp_amd import grid
     # weak scaling: every GPU carries configs[1]'s 64 redshift rows, so the global
@@ -131,7 +139,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device="cpu" if args.rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert out.shape == (nz, NK) and bool(torch.isfinite(out).all())
@@ -192,7 +201,8 @@ def main():
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic" + (" (REHEARSAL on one GPU: not a measurement)"
+                                                   if args.rehearse else ""),
             "config": {"workload": "configs[%d]: %s, WMAP7, %s mass function, %d k "
                                    "(logspace -3..2) x %d z (linspace 0..%.1f)"
                                    % (1 if args.workload == "c2" else 2, which,

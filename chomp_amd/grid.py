@@ -112,8 +112,15 @@ def gather_rows(local, n_all, world):
         return local[:n_all]
     rpr = rows_per_rank(n_all, world)
     assert local.shape[0] == rpr
-    full = torch.empty((world * rpr, local.shape[1]), dtype=local.dtype,
-                       device=local.device)
-    dist.all_gather_into_tensor(full, local.contiguous())
+    if local.is_cuda and dist.get_backend() == "gloo":
+        # rehearsal of the N > 1 path on a box with fewer GPUs than ranks
+        # (bench.py --rehearse): the same gather, staged through host memory
+        host = torch.empty((world * rpr, local.shape[1]), dtype=local.dtype)
+        dist.all_gather_into_tensor(host, local.cpu().contiguous())
+        full = host.to(local.device)
+    else:
+        full = torch.empty((world * rpr, local.shape[1]), dtype=local.dtype,
+                           device=local.device)
+        dist.all_gather_into_tensor(full, local.contiguous())
     order = torch.as_tensor(unshard_order(n_all, world), device=local.device)
     return full.index_select(0, order)
