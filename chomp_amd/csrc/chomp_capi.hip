@@ -43,6 +43,8 @@ struct chomp_ctx {
   double* d_z = nullptr;
   Epoch* d_epochs = nullptr;
   double* d_search = nullptr;
+  double* d_probe = nullptr;       // k_epoch_init: certifying probes of the mass-limit search
+  int* d_count = nullptr;          // k_epoch_init: arrivals per epoch (reset by the kernel)
   double* d_tab = nullptr;
   chomp_halo_par* d_mass_par = nullptr;
   chomp_halo_par* d_profile = nullptr;
@@ -184,7 +186,7 @@ int setup_constants(chomp_ctx* ctx) {
 
 int alloc_epochs(chomp_ctx* ctx, size_t n) {
   if (n <= ctx->cap_epoch) return CHOMP_OK;
-  void* old[] = {ctx->d_cosmo, ctx->d_z, ctx->d_epochs, ctx->d_search, ctx->d_tab,
+  void* old[] = {ctx->d_cosmo, ctx->d_z, ctx->d_epochs, ctx->d_search, ctx->d_probe, ctx->d_count, ctx->d_tab,
                  ctx->d_mass_par, ctx->d_profile, ctx->d_hod, ctx->d_nodes, ctx->d_snodes,
                  ctx->d_slot, ctx->d_first};
   for (void* p : old)
@@ -193,6 +195,9 @@ int alloc_epochs(chomp_ctx* ctx, size_t n) {
   HIPCHK(hipMalloc(&ctx->d_z, n * sizeof(double)));
   HIPCHK(hipMalloc(&ctx->d_epochs, n * sizeof(Epoch)));
   HIPCHK(hipMalloc(&ctx->d_search, n * 4 * sizeof(double)));
+  HIPCHK(hipMalloc(&ctx->d_probe, n * kProbeStride * sizeof(double)));
+  HIPCHK(hipMalloc(&ctx->d_count, n * sizeof(int)));
+  HIPCHK(hipMemsetAsync(ctx->d_count, 0, n * sizeof(int), ctx->stream));
   HIPCHK(hipMalloc(&ctx->d_tab, n * (size_t)ctx->L.stride * sizeof(double)));
   HIPCHK(hipMalloc(&ctx->d_mass_par, n * sizeof(chomp_halo_par)));
   HIPCHK(hipMalloc(&ctx->d_profile, n * sizeof(chomp_halo_par)));
@@ -273,7 +278,7 @@ void chomp_ctx_destroy(chomp_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   void* ptrs[] = {ctx->d_sici, ctx->d_j0, ctx->d_j2, ctx->d_tinker, ctx->d_gl16,
-                  ctx->d_cand, ctx->d_cosmo, ctx->d_z, ctx->d_epochs, ctx->d_search,
+                  ctx->d_cand, ctx->d_cosmo, ctx->d_z, ctx->d_epochs, ctx->d_search, ctx->d_probe, ctx->d_count,
                   ctx->d_tab, ctx->d_mass_par, ctx->d_profile, ctx->d_hod, ctx->d_nodes, ctx->d_snodes, ctx->d_slot, ctx->d_first,
                   ctx->d_stage_in, ctx->d_stage_in2, ctx->d_stage_out, ctx->d_work, ctx->d_slow,
                   ctx->d_winfo, ctx->d_ktab};
@@ -332,12 +337,14 @@ int chomp_epochs_set(chomp_ctx* ctx, size_t n_epoch, const chomp_cosmo* cosmo,
   if (rc) return rc;
   rc = upload(ctx, ctx->d_first, first.data(), n_epoch * sizeof(int), ctx->sh_first);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_sigma_nodes, dim3((kSigmaCount + 255) / 256 + 1, (unsigned)n_slots),
+  hipLaunchKernelGGL(k_sigma_nodes,
+                     dim3((kSigmaCount + 255) / 256 + 1 + kSGrid,
+                          (unsigned)(n_slots + (n_epoch + 255) / 256)),
                      dim3(256), 0, ctx->stream, ctx->cfg, ctx->d_cosmo, ctx->d_z, ctx->d_first,
-                     ctx->d_snodes);
-  hipLaunchKernelGGL(k_epoch_init, dim3((unsigned)n_epoch, 2), dim3(64 * kInitNW), 0, ctx->stream,
-                     ctx->cfg, ctx->d_cosmo, ctx->d_z, ctx->d_epochs, ctx->d_search,
-                     ctx->d_cand, ctx->d_snodes, ctx->d_slot);
+                     ctx->d_slot, (int)n_slots, (int)n_epoch, ctx->d_epochs, ctx->d_snodes);
+  hipLaunchKernelGGL(k_epoch_init, dim3((unsigned)n_epoch, 2 * kProbes), dim3(64 * kInitNW), 0,
+                     ctx->stream, ctx->cfg, ctx->d_epochs, ctx->d_search, ctx->d_cand,
+                     ctx->d_snodes, ctx->d_probe, ctx->d_count);
   HIPCHK(hipGetLastError());
   ctx->have_epochs = true;
   return CHOMP_OK;
