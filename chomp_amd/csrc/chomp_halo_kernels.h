@@ -239,7 +239,9 @@ struct SigmaTabIntegrand {
 
 // sigma^2(R) = int dlnk Delta^2 W^2 (cosmology.py:602-642) with the whole group on
 // one Romberg integral; `rtol` is cosmo_precision for reference-exact values.
-template <int NW>
+// UNROLL > 1 overlaps the table loads of several nodes (worth it where few blocks share a
+// CU, as in k_epoch_init; with many resident blocks the extra registers cost more).
+template <int NW, int UNROLL = 1>
 __device__ __forceinline__ double sigma2_block(const Epoch& E, const double* snode, double R,
                                                const chomp_config& cfg, double rtol,
                                                double* red) {
@@ -249,7 +251,7 @@ __device__ __forceinline__ double sigma2_block(const Epoch& E, const double* sno
   const double amp2 = E.amp * E.sigma_norm * E.sigma_norm;
   if (need_min > E.k_min && need_max < E.k_max) {          // fixed range: table path
     SigmaTabIntegrand f{&E, snode, R, 1.0 / amp2};
-    const RombergOut<1> r = romberg_group<NW, 1>(f, lo, hi, cfg.global_precision, rtol,
+    const RombergOut<1> r = romberg_group<NW, 1, SigmaTabIntegrand, UNROLL>(f, lo, hi, cfg.global_precision, rtol,
                                                  cfg.divmax, red);
     return amp2 * r.value[0];
   }
@@ -289,11 +291,11 @@ __device__ __forceinline__ void spline_build_pcr(const double* x, const double* 
 }
 
 // nu(M) = (delta_c / sigma(R(M)))^2, cosmology.py:662-699.
-template <int NW>
+template <int NW, int UNROLL = 1>
 __device__ __forceinline__ double nu_of_mass_block(const Epoch& E, const double* snode,
                                                    double mass, const chomp_config& cfg,
                                                    double rtol, double* red) {
-  const double s2 = sigma2_block<NW>(E, snode, scale_of_mass(E, mass), cfg, rtol, red);
+  const double s2 = sigma2_block<NW, UNROLL>(E, snode, scale_of_mass(E, mass), cfg, rtol, red);
   const double sq = E.delta_c / sqrt(s2);
   return sq * sq;
 }
@@ -338,10 +340,10 @@ __device__ __forceinline__ double nu_probe(const Epoch& E, const double* snode, 
                                            const chomp_config& cfg, double thr_lo,
                                            double thr_hi, double* red) {
   const double rtol_probe = 1e-6, kAmbiguous = 2e-5;
-  double nu = nu_of_mass_block<NW>(E, snode, m, cfg, rtol_probe, red);
+  double nu = nu_of_mass_block<NW, 4>(E, snode, m, cfg, rtol_probe, red);
   const double edge = fmin(fabs(log(nu / thr_lo)), fabs(log(nu / thr_hi)));
   if (edge < kAmbiguous && cfg.cosmo_precision < rtol_probe)
-    nu = nu_of_mass_block<NW>(E, snode, m, cfg, cfg.cosmo_precision, red);
+    nu = nu_of_mass_block<NW, 4>(E, snode, m, cfg, cfg.cosmo_precision, red);
   return nu;
 }
 

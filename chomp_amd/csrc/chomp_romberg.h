@@ -109,7 +109,9 @@ __device__ __forceinline__ void call_f(const F& f, double x, double (&o)[NF], in
 // points, one per thread) at once; the Romberg rows 0..L0 and their stopping tests
 // are then replayed from the per-level sums, so an integral that the reference
 // stops at level <= L0 still returns exactly that level's value.
-template <int NW, int NF, class F>
+// UNROLL: node evaluations issued together in the level loop (their table loads overlap);
+// the partial sums are still added in node order, so the result does not depend on it.
+template <int NW, int NF, class F, int UNROLL = 1>
 __device__ __forceinline__ RombergOut<NF> romberg_group(const F& f, double a, double b,
                                                         double tol, double rtol,
                                                         int divmax, double* red) {
@@ -269,7 +271,21 @@ __device__ __forceinline__ RombergOut<NF> romberg_group(const F& f, double a, do
     double part[NF];
 #pragma unroll
     for (int q = 0; q < NF; ++q) part[q] = 0.0;
-    for (long j = gt; j < numtosum; j += NT) {
+    long j = gt;
+    if (UNROLL > 1) {
+      for (; j + (UNROLL - 1) * (long)NT < numtosum; j += UNROLL * (long)NT) {
+        double v[UNROLL][NF];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+          detail::call_f<F, NF>(f, lox + h * (double)(j + u * (long)NT), v[u], i,
+                                j + u * (long)NT, 0);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+          for (int q = 0; q < NF; ++q) part[q] += v[u][q];
+      }
+    }
+    for (; j < numtosum; j += NT) {
       double v[NF];
       detail::call_f<F, NF>(f, lox + h * (double)j, v, i, j, 0);
 #pragma unroll
