@@ -441,13 +441,15 @@ struct SidePlan {
   bool ok;
   int dir, j;
   double nu_start;              // estimate at the starting mass
+  bool at_edge;                 // the starting mass sits on a band edge: dir is a guess, the
+                                // probes are candidates 0..3 (j = 2) and 0 decides exactly
 };
 __device__ __forceinline__ SidePlan plan_side(const Epoch& E, const double* lns, int side,
                                               const double* cand, int* sh) {
   const SideThresholds T = side_thresholds(side, cand);
   const SGrid G = make_sgrid(E.k_min, E.k_max);
   const double margin = 1e-2;             // estimate error ~1e-4; candidates are >= 0.4 % apart
-  SidePlan P{false, 0, 0, 0.0};
+  SidePlan P{false, 0, 0, 0.0, false};
   // ln nu = ln_nu_c - ln S(ln R); the candidates are M_0 * 1.05^(-+j), so ln R moves by
   // ln(1.05) / 3 per step (to the estimate's accuracy)
   const double ln_nu_c = log(E.delta_c * E.delta_c / (E.amp * E.sigma_norm * E.sigma_norm));
@@ -461,7 +463,11 @@ __device__ __forceinline__ SidePlan plan_side(const Epoch& E, const double* lns,
   else if (nu0 >= T.thr_lo * (1.0 + margin) && nu0 <= T.thr_hi * (1.0 - margin)) {
     P.ok = true;                          // inside the band with room to spare
     return P;
-  } else {
+  } else {                                // on an edge: probe the start and its neighbours
+    P.ok = true;
+    P.at_edge = true;
+    P.dir = nu0 > 0.5 * (T.thr_lo + T.thr_hi) ? -1 : +1;
+    P.j = 2;
     return P;
   }
   const double ln_thr = log(P.dir < 0 ? T.thr_hi : T.thr_lo);
@@ -547,7 +553,8 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_init(
     double nu_mine = NAN;
     if (plan.ok && plan.dir != 0) {
       const int c = plan.j - 2 + p;
-      if (c > 0 && c < kSearchJ) {   // (candidate 0 fails by the margin of the estimate)
+      // (away from an edge candidate 0 fails by the margin of the estimate)
+      if ((c > 0 || (c == 0 && plan.at_edge)) && c < kSearchJ) {
         const double* tab = plan.dir < 0 ? T.down : T.up;
         nu_mine = nu_probe<kInitNW>(E, snode, tab[c], cfg, T.thr_lo, T.thr_hi, red);
       }
@@ -556,8 +563,8 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_init(
       pr[role] = nu_mine;
       if (p == 0) {
         double* pl = pr + 2 * kProbes + 4 + 4 * side;
-        pl[0] = plan.ok ? 1.0 : 0.0; pl[1] = (double)plan.dir; pl[2] = (double)plan.j;
-        pl[3] = plan.nu_start;
+        pl[0] = plan.ok ? (plan.at_edge ? 2.0 : 1.0) : 0.0; pl[1] = (double)plan.dir;
+        pl[2] = (double)plan.j; pl[3] = plan.nu_start;
       }
     }
   }
@@ -575,16 +582,30 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_init(
   for (int sd = 0; sd < 2; ++sd) {
     __syncthreads();
     const double* pl = pr + 2 * kProbes + 4 + 4 * sd;
-    const bool ok = peek(pl) != 0.0;
-    const int dir = (int)peek(pl + 1), j = (int)peek(pl + 2);
-    const double nu_start = peek(pl + 3);
+    const double mode = peek(pl);
+    const bool ok = mode != 0.0, at_edge = mode == 2.0;
+    int dir = (int)peek(pl + 1);
+    const int j = (int)peek(pl + 2);
+    double nu_start = peek(pl + 3);
     const SideThresholds S = side_thresholds(sd, cand);
     double mass = S.down[0];
     int n_eval = 0;
     bool certified = ok;
     int seed_dir = 0, seed_jl = 0, seed_jh = -1;
     double nu_l = 0.0, nu_h = 0.0;
-    if (ok && dir != 0) {
+    bool walk = ok && dir != 0;
+    if (at_edge) {                 // the exact nu of the starting mass decides the direction
+      nu_start = peek(pr + kProbes * sd);
+      const int dir_exact = S.thr_hi < nu_start ? -1 : (S.thr_lo > nu_start ? +1 : 0);
+      n_eval = 1;
+      if (!(nu_start == nu_start)) { certified = false; walk = false; n_eval = 0; }
+      else if (dir_exact == 0) walk = false;                     // stays at the start: done
+      else if (dir_exact != dir) {                               // guessed the other way
+        certified = false; walk = false;
+        seed_dir = dir_exact; seed_jl = 0; nu_l = nu_start;
+      }
+    }
+    if (walk) {
       const double* tab = dir < 0 ? S.down : S.up;
       const double thr = dir < 0 ? S.thr_hi : S.thr_lo;
       // status of candidates j - 2 .. j + 1: 0 fails, 1 passes, -1 unknown
@@ -594,7 +615,7 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_init(
       for (int q = 0; q < kProbes; ++q) {
         const int c = j - 2 + q;
         nu[q] = peek(pr + kProbes * sd + q);
-        if (c <= 0) st[q] = 0;
+        if (c <= 0) st[q] = 0;     // (at an edge: candidate 0 fails exactly, see above)
         else if (!(nu[q] == nu[q])) st[q] = -1;
         else { st[q] = (dir < 0 ? !(thr < nu[q]) : !(thr > nu[q])) ? 1 : 0; ++n_eval; }
       }
