@@ -339,7 +339,10 @@ template <int NW>
 __device__ __forceinline__ double nu_probe(const Epoch& E, const double* snode, double m,
                                            const chomp_config& cfg, double thr_lo,
                                            double thr_hi, double* red) {
-  const double rtol_probe = 1e-6, kAmbiguous = 2e-5;
+  // (a cosmo_precision looser than the probe tolerance is used as it is: the reference's
+  // decision rests on exactly that integral)
+  const double kAmbiguous = 2e-5;
+  const double rtol_probe = cfg.cosmo_precision > 1e-6 ? cfg.cosmo_precision : 1e-6;
   double nu = nu_of_mass_block<NW, 4>(E, snode, m, cfg, rtol_probe, red);
   const double edge = fmin(fabs(log(nu / thr_lo)), fabs(log(nu / thr_hi)));
   if (edge < kAmbiguous && cfg.cosmo_precision < rtol_probe)

@@ -109,6 +109,45 @@ def test_stage_e_launch_shapes_agree(torch_mod, monkeypatch):
     assert torch.equal(part, full[2:5])
 
 
+def test_mass_limit_search_matches_the_walk():
+    """The aim-and-certify search of k_epoch_init must stop on exactly the step the
+    reference's 5 % walk stops at (mass_function.py:160-203), for cosmologies and redshifts
+    well away from the fixtures: the ln M limits are compared bit for bit with the
+    oracle's literal walk.
+
+    Not compared: walks that run below M = 1e3 M_sun/h (z ~ 1.7 with a low sigma_8; the
+    reference's search diverges near z ~ 1.9).  There R < 1e-5 Mpc/h, k R < 1e-1
+    over the whole integration range, and the top-hat window 3 (sin x - x cos x) / x^3 is
+    rounding noise of the libm in use: the step the reference stops at is then a property
+    of glibc's sin/cos, not of the algorithm (observed: 5 steps apart at M ~ 3e-8)."""
+    from chomp_amd import grid
+    from oracle import chomp_oracle as o
+    rng = numpy.random.default_rng(20)
+    base = o.default_cosmo_dict
+    cds, zs = [], []
+    for i in range(24):
+        om = rng.uniform(0.2, 0.4)
+        cds.append(dict(base, omega_m0=om - base["omega_r0"], omega_l0=1.0 - om,
+                        omega_b0=rng.uniform(0.035, 0.055), h=rng.uniform(0.6, 0.8),
+                        sigma_8=rng.uniform(0.65, 0.95), n_scalar=rng.uniform(0.9, 1.02)))
+        zs.append(float(rng.choice([0.0, 0.05, 0.3, 0.77, 1.1, 1.45, 1.7]) if i < 14
+                        else rng.uniform(0.0, 1.7)))
+    hg = grid.HaloGrid(numpy.array(zs), cosmo_dict=cds)
+    hg.setup("power_mm")
+    bad, n_checked = [], 0
+    for i in range(24):
+        e = o.epoch(cds[i], zs[i])
+        lo, hi, _ = o.mass_limits(e)
+        sc = hg.ctx.scalars(i)
+        assert numpy.isfinite(sc["ln_mass_min"]) and sc["ln_mass_max"] == hi, (i, zs[i])
+        if lo >= numpy.log(1e3):
+            n_checked += 1
+            if sc["ln_mass_min"] != lo:
+                bad.append((i, zs[i], float(sc["ln_mass_min"]), float(lo)))
+    assert not bad, bad
+    assert n_checked >= 18
+
+
 def test_range_branches_and_bad_inputs():
     """halo.py:314-320 semantics for every kind of k the reference accepts."""
     from chomp_amd import halo
