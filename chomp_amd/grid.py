@@ -93,23 +93,46 @@ class HaloGrid(object):
         """Stage K + E on this rank's shard, then all-gather (torch.distributed) and
         re-order to the caller's z order.  k: torch cuda tensor.  Returns the full
         [n_all, nk] tensor on every rank."""
+        return self.power_all_async(which, k).wait()
+
+    def power_all_async(self, which, k):
+        """As power_all, but the all-gather is only launched (RCCL runs it on its own
+        stream): the caller may queue the next set-up behind it and call .wait() on the
+        returned handle later -- the collective then overlaps that compute."""
         import torch
         rpr = rows_per_rank(self.n_all, self.world)
         local = torch.zeros((rpr, k.numel()), dtype=torch.float64, device=k.device)
         if len(self.idx):
             self.power(which, k, out=local[:len(self.idx)])
-        self.ctx.sync()
-        return gather_rows(local, self.n_all, self.world)
+        return gather_rows_async(local, self.n_all, self.world)
 
 
-def gather_rows(local, n_all, world):
-    """All-gather the per-rank row blocks ([rows_per_rank, nk], zero padded) and
-    put the rows back into epoch order.  RCCL on GPUs ("nccl" backend), gloo on CPU
-    tensors (used by the multi-process CPU tests)."""
+class PendingRows(object):
+    """Handle of an all-gather in flight; wait() returns the [n_all, nk] grid in epoch
+    order (stream-ordered: it does not block the host)."""
+
+    def __init__(self, full, work, n_all, world):
+        self._full, self._work, self._n_all, self._world = full, work, n_all, world
+
+    def wait(self):
+        import torch
+        if self._world == 1:
+            return self._full[:self._n_all]
+        if self._work is not None:
+            self._work.wait()
+        order = torch.as_tensor(unshard_order(self._n_all, self._world),
+                                device=self._full.device)
+        return self._full.index_select(0, order)
+
+
+def gather_rows_async(local, n_all, world):
+    """Launch the all-gather of the per-rank row blocks ([rows_per_rank, nk], zero
+    padded).  RCCL on GPUs ("nccl" backend), gloo on CPU tensors (multi-process CPU
+    tests); CUDA tensors under gloo are staged through host memory (rehearsal only)."""
     import torch
     import torch.distributed as dist
     if world == 1:
-        return local[:n_all]
+        return PendingRows(local, None, n_all, world)
     rpr = rows_per_rank(n_all, world)
     assert local.shape[0] == rpr
     if local.is_cuda and dist.get_backend() == "gloo":
@@ -117,10 +140,12 @@ def gather_rows(local, n_all, world):
         # (bench.py --rehearse): the same gather, staged through host memory
         host = torch.empty((world * rpr, local.shape[1]), dtype=local.dtype)
         dist.all_gather_into_tensor(host, local.cpu().contiguous())
-        full = host.to(local.device)
-    else:
-        full = torch.empty((world * rpr, local.shape[1]), dtype=local.dtype,
-                           device=local.device)
-        dist.all_gather_into_tensor(full, local.contiguous())
-    order = torch.as_tensor(unshard_order(n_all, world), device=local.device)
-    return full.index_select(0, order)
+        return PendingRows(host.to(local.device), None, n_all, world)
+    full = torch.empty((world * rpr, local.shape[1]), dtype=local.dtype, device=local.device)
+    work = dist.all_gather_into_tensor(full, local.contiguous(), async_op=True)
+    return PendingRows(full, work, n_all, world)
+
+
+def gather_rows(local, n_all, world):
+    """All-gather the per-rank row blocks and put the rows back into epoch order."""
+    return gather_rows_async(local, n_all, world).wait()
