@@ -65,6 +65,7 @@ class HaloGrid(object):
         self.z = self.z_all[self.idx]
         self.ctx = cosmology._context(stream=stream, device=device)
         self._tables = 0
+        self._bufs = {}
         n = len(self.idx)
         # parameter blocks packed once (ctypes), not per set-up call
         self._c_cosmo = self.ctx.pack_cosmo(self.cosmo, n) if n else None
@@ -98,13 +99,28 @@ class HaloGrid(object):
     def power_all_async(self, which, k):
         """As power_all, but the all-gather is only launched (RCCL runs it on its own
         stream): the caller may queue the next set-up behind it and call .wait() on the
-        returned handle later -- the collective then overlaps that compute."""
+        returned handle later -- the collective then overlaps that compute.
+
+        The row block this rank fills and the gathered grid live in two alternating
+        persistent buffers (no allocation or fill per call): a returned grid is valid
+        until the second call after the one that produced it."""
         import torch
         rpr = rows_per_rank(self.n_all, self.world)
-        local = torch.zeros((rpr, k.numel()), dtype=torch.float64, device=k.device)
+        key = (rpr, k.numel(), str(k.device))
+        if self._bufs.get("key") != key:
+            self._bufs = {"key": key, "turn": 0, "local": [], "full": []}
+            for _ in range(2):
+                self._bufs["local"].append(
+                    torch.zeros((rpr, k.numel()), dtype=torch.float64, device=k.device))
+                self._bufs["full"].append(
+                    torch.empty((self.world * rpr, k.numel()), dtype=torch.float64,
+                                device=k.device) if self.world > 1 else None)
+        turn = self._bufs["turn"]
+        self._bufs["turn"] = turn ^ 1
+        local = self._bufs["local"][turn]
         if len(self.idx):
             self.power(which, k, out=local[:len(self.idx)])
-        return gather_rows_async(local, self.n_all, self.world)
+        return gather_rows_async(local, self.n_all, self.world, out=self._bufs["full"][turn])
 
 
 class PendingRows(object):
@@ -125,10 +141,11 @@ class PendingRows(object):
         return self._full.index_select(0, order)
 
 
-def gather_rows_async(local, n_all, world):
+def gather_rows_async(local, n_all, world, out=None):
     """Launch the all-gather of the per-rank row blocks ([rows_per_rank, nk], zero
-    padded).  RCCL on GPUs ("nccl" backend), gloo on CPU tensors (multi-process CPU
-    tests); CUDA tensors under gloo are staged through host memory (rehearsal only)."""
+    padded) into `out` (allocated if None).  RCCL on GPUs ("nccl" backend), gloo on CPU
+    tensors (multi-process CPU tests); CUDA tensors under gloo are staged through host
+    memory (rehearsal only)."""
     import torch
     import torch.distributed as dist
     if world == 1:
@@ -141,7 +158,8 @@ def gather_rows_async(local, n_all, world):
         host = torch.empty((world * rpr, local.shape[1]), dtype=local.dtype)
         dist.all_gather_into_tensor(host, local.cpu().contiguous())
         return PendingRows(host.to(local.device), None, n_all, world)
-    full = torch.empty((world * rpr, local.shape[1]), dtype=local.dtype, device=local.device)
+    full = out if out is not None else torch.empty((world * rpr, local.shape[1]),
+                                                   dtype=local.dtype, device=local.device)
     work = dist.all_gather_into_tensor(full, local.contiguous(), async_op=True)
     return PendingRows(full, work, n_all, world)
 
