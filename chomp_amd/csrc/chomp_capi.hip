@@ -16,7 +16,7 @@
 #include <vector>
 
 #include "../../include/chomp_mi355x.h"
-#include "chomp_halo_kernels.h"
+#include "chomp_power_kernels.h"
 #include "chomp_proj_kernels.h"
 
 using namespace chomp;

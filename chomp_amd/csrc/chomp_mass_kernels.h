@@ -1,0 +1,829 @@
+// chomp_mass_kernels.h -- Stage K, first half (gfx950): everything up to the mass
+// function of an epoch (= one (cosmology, z) pair).
+//
+//   k_sigma_nodes   cosmology-only tables, once per distinct cosmology of the batch: the
+//                   sigma(R) node table, the sigma_8 integral (cosmology.py:118-119), the
+//                   coarse ln S(R) table that aims the mass-limit search, and the
+//                   closed-form part of every epoch record (cosmology.py:39-119)
+//   k_epoch_init    comoving distance + the mass-limit search of
+//                   MassFunction._set_mass_limits (mass_function.py:160-203)
+//   k_nu_table      MassFunction._initialize_splines nu_m loop (mass_function.py:205-210)
+//   k_mass_setup    splines, m_star, f/bias normalisation (mass_function.py:212-241,
+//                   Tinker 532-564)
+//
+// Also here: the layout of the per-epoch table block (TabLayout) and of the node tables,
+// shared by the other kernel headers.
+//
+// Execution shape: one integral (or a pair sharing nodes) per group of wavefronts;
+// tables are staged in LDS or read through L2; reductions are wavefront butterflies.
+// No MFMA: there is no dense contraction anywhere on this path.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/chomp_mi355x.h"
+#include "chomp_math.h"
+#include "chomp_romberg.h"
+
+namespace chomp {
+
+// Per-epoch table block (doubles), offsets fixed by the context's point counts.
+struct TabLayout {
+  int NM, NK;
+  int off_ln_mass, off_nu, off_nu_pp, off_lnm_pp;
+  int off_knot[5], off_kpp[5];
+  int off_levels, off_hf_lns2, off_misc;   // misc[0] = n_bar / rho_bar (raw integral)
+  int stride;
+};
+
+inline TabLayout make_layout(int NM, int NK) {
+  TabLayout L;
+  L.NM = NM;
+  L.NK = NK;
+  int o = 0;
+  L.off_ln_mass = o; o += NM;
+  L.off_nu = o; o += NM;
+  L.off_nu_pp = o; o += 4 * (NM - 1);
+  L.off_lnm_pp = o; o += 4 * (NM - 1);
+  for (int f = 0; f < 5; ++f) { L.off_knot[f] = o; o += NK; }
+  for (int f = 0; f < 5; ++f) { L.off_kpp[f] = o; o += 4 * (NK - 1); }
+  L.off_levels = o; o += 5 * NK;
+  L.off_hf_lns2 = o; o += NK;
+  L.off_misc = o; o += 8;
+  L.stride = (o + 7) & ~7;
+  return L;
+}
+
+// Families: index into off_knot / off_kpp.
+enum { F_HM = 0, F_PPMM = 1, F_HG = 2, F_PPGM = 3, F_PPGG = 4 };
+
+// Node tables of the halo integrals: every knot k of an epoch integrates over the
+// SAME ln(nu) nodes, so everything that does not depend on k (nu f(nu), b(nu), M(nu),
+// concentration, r_s, HOD moments) is tabulated once per (epoch, integration range)
+// on the level-kNodeLevel Romberg grid, stored level by level so a level's nodes are
+// contiguous.  Deeper levels fall back to direct evaluation.
+constexpr int kNodeLevel = 10;
+constexpr int kNodeCount = (1 << kNodeLevel) + 1;
+constexpr int kNodeFields = 7;   // wA, wB, ln_rs, con, ln_cp, inv_mass_k, flag
+constexpr int kNodeStride = kNodeFields * kNodeCount + 8;   // doubles per (epoch, group);
+                                                            // tail: integration limits a, b
+__host__ __device__ inline int node_index(int lev, long j) {
+  return lev == 0 ? (int)j : 1 + (1 << (lev - 1)) + (int)j;
+}
+
+constexpr int kKnotScratch = romberg_scratch<4, 2>();   // LDS doubles of a knot block
+constexpr int kSearchJ = 2048;        // candidates per walking direction
+constexpr int kEpochDoubles = (int)(sizeof(Epoch) / sizeof(double));
+static_assert(sizeof(Epoch) % sizeof(double) == 0, "Epoch must be 8-byte granular");
+
+__device__ __forceinline__ bool same_cosmology(const Epoch& a, const Epoch& b) {
+  return a.om0 == b.om0 && a.ob0 == b.ob0 && a.ol0 == b.ol0 && a.or0 == b.or0 &&
+         a.tcmb == b.tcmb && a.h == b.h && a.ns == b.ns;
+}
+
+// Cooperative copy of POD blocks as doubles.
+__device__ __forceinline__ void copy_doubles(double* dst, const double* src, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+
+// sigma(R) node table.  For 14.0662/k_max < R < 0.1/k_min (0.14 < R < 100 Mpc/h at
+// the default limits) SingleEpoch.sigma_r integrates over the fixed range
+// [ln k_min, ln k_max] (cosmology.py:611-632), so every such integral of an epoch
+// visits the same ln k nodes: k_j and the R-independent factor
+// (k_j/H0)^(3+n) T(k_j)^2 of Delta^2 are tabulated once per epoch on the
+// level-kSigmaLevel Romberg grid (level-major order) by k_sigma_nodes.
+constexpr int kSigmaLevel = 13;
+constexpr int kSigmaCount = (1 << kSigmaLevel) + 1;
+// Coarse table of ln S(R), S = int dlnk (k/H0)^(3+n) T^2 W(kR)^2 over sigma_r's own
+// limits, used only to AIM the mass-limit search (k_epoch_init).  S(R) has kinks where
+// sigma_r's integration limits switch (cosmology.py:611-632): at R = 14.0662 / k_max,
+// that / 100, 0.1 / k_min and that x 100.  The table is therefore four segments between
+// those radii, each uniform in ln R, and is never interpolated across a kink.
+constexpr int kSGrid = 48;
+// Segment s covers ln R in [b[s], b[s + 1]] with kSegN[s] points starting at kSegOff[s].
+// (Scalars and if-chains rather than arrays: dynamic indexing would put them in scratch.)
+struct SGrid {
+  double b0, b1, b2, b3, b4;
+  bool valid;
+  // segment of x: lo, hi, number of points, offset of its first point
+  __host__ __device__ void segment(double x, double* lo, double* hi, int* n, int* off) const {
+    if (x <= b1) { *lo = b0; *hi = b1; *n = 8; *off = 0; }
+    else if (x <= b2) { *lo = b1; *hi = b2; *n = 14; *off = 8; }
+    else if (x <= b3) { *lo = b2; *hi = b3; *n = 18; *off = 22; }
+    else { *lo = b3; *hi = b4; *n = 8; *off = 40; }
+  }
+  __host__ __device__ double ln_r(int i) const {
+    double lo, hi;
+    int n, off;
+    if (i < 8) { lo = b0; hi = b1; n = 8; off = 0; }
+    else if (i < 22) { lo = b1; hi = b2; n = 14; off = 8; }
+    else if (i < 40) { lo = b2; hi = b3; n = 18; off = 22; }
+    else { lo = b3; hi = b4; n = 8; off = 40; }
+    return lo + (hi - lo) * (double)(i - off) / (double)(n - 1);
+  }
+};
+__host__ __device__ inline SGrid make_sgrid(double k_min, double k_max) {
+  SGrid g;
+  const double a = log(14.0662 / k_max) - log(100.0), b = log(14.0662 / k_max),
+               c = log(0.1 / k_min);
+  g.b0 = a - log(20.0);                          // the walks of z <~ 1.5 end above R_a / 2
+  g.b1 = a; g.b2 = b; g.b3 = c;
+  g.b4 = c + log(3.0);
+  g.valid = b < c;
+  return g;
+}
+constexpr int kSigmaOffI8 = 2 * kSigmaCount, kSigmaOffLnS = 2 * kSigmaCount + 8;
+constexpr int kSigmaStride = 2 * kSigmaCount + 8 + kSGrid;  // doubles per cosmology: k[], d2[],
+                                                   // I8 = int dlnk d2 W(8k)^2 (sigma_8 norm.), ln S[]
+
+// Everything here depends on the cosmology only, not on z, so it is built once per
+// distinct cosmology of the batch ("slot"; the z-axis of a (k, z) grid is one slot).
+// grid (ceil(kSigmaCount / 256) + 1 + kSGrid, n_slots + ceil(n_epoch / 256)), block 256;
+// first[s] = an epoch that has cosmology s.  For y < n_slots: after the node-table
+// blocks, one x-block does the sigma_8 integral (cosmology.py:118-119) and kSGrid blocks
+// the coarse ln S(R) table, all by direct evaluation.  The rows y >= n_slots fill in the
+// closed-form part of every epoch record (SingleEpoch.__init__ minus its two integrals),
+// one epoch per thread, while the cosmology-only integrals run.
+__global__ __launch_bounds__(256) void k_sigma_nodes(chomp_config cfg,
+                                                     const chomp_cosmo* __restrict__ cosmo,
+                                                     const double* __restrict__ zin,
+                                                     const int* __restrict__ first,
+                                                     const int* __restrict__ slots, int n_slots,
+                                                     int n_epoch, Epoch* __restrict__ epochs,
+                                                     double* __restrict__ snodes) {
+  __shared__ Epoch E;
+  __shared__ double red[romberg_scratch<4, 1>()];
+  if ((int)blockIdx.y >= n_slots) {
+    const int e = ((int)blockIdx.y - n_slots) * 256 + (int)threadIdx.x;
+    if (blockIdx.x != 0 || e >= n_epoch) return;
+    Epoch B;
+    double* q = reinterpret_cast<double*>(&B);
+    for (int i = 0; i < kEpochDoubles; ++i) q[i] = 0.0;
+    const chomp_cosmo c = cosmo[e];
+    B.om0 = c.omega_m0; B.ob0 = c.omega_b0; B.ol0 = c.omega_l0; B.or0 = c.omega_r0;
+    B.tcmb = c.cmb_temp; B.h = c.h; B.sigma8 = c.sigma_8; B.ns = c.n_scalar;
+    B.z = zin[e];
+    epoch_background(B, cfg.cosmo_precision, cfg.k_min, cfg.k_max);
+    B.cosmo_slot = slots[e];
+    epochs[e] = B;
+    return;
+  }
+  const int slot = blockIdx.y, e = first[slot];
+  if (threadIdx.x == 0) {
+    const chomp_cosmo c = cosmo[e];
+    E.om0 = c.omega_m0; E.ob0 = c.omega_b0; E.ol0 = c.omega_l0; E.or0 = c.omega_r0;
+    E.tcmb = c.cmb_temp; E.h = c.h; E.sigma8 = c.sigma_8; E.ns = c.n_scalar;
+    E.z = zin[e];
+    epoch_background(E, cfg.cosmo_precision, cfg.k_min, cfg.k_max);
+  }
+  __syncthreads();
+  double* n = snodes + (size_t)slot * kSigmaStride;
+  const int nb = (int)gridDim.x - 1 - kSGrid;     // node-table blocks
+  if ((int)blockIdx.x >= nb) {
+    const int i = (int)blockIdx.x - nb - 1;       // -1: sigma_8 block, else ln S point
+    const double R = i < 0 ? 8.0 : exp(make_sgrid(cfg.k_min, cfg.k_max).ln_r(i));
+    double lo, hi;
+    sigma_limits(E, R, &lo, &hi);
+    SigmaIntegrand f{&E, R};                      // sigma_norm = 1: amp * integral
+    // (the ln S points only aim the search: 1e-5 and at most 2^12 panels are plenty)
+    const double s2 = romberg1<4>(f, lo, hi, cfg.global_precision,
+                                  i < 0 ? cfg.cosmo_precision : 1e-5,
+                                  i < 0 || cfg.divmax < 12 ? cfg.divmax : 12, red);
+    if (threadIdx.x == 0) {
+      if (i < 0) n[kSigmaOffI8] = s2 / E.amp;
+      else n[kSigmaOffLnS + i] = log(s2 / E.amp);
+    }
+    return;
+  }
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= kSigmaCount) return;
+  const double a = log(cfg.k_min), b = log(cfg.k_max);
+  double x;
+  if (idx < 2) {
+    x = idx == 0 ? a : b;
+  } else {
+    const int m = idx - 1;
+    const int lev = 32 - __builtin_clz((unsigned)m);
+    const long j = m - (1 << (lev - 1));
+    const double h = (b - a) / (double)(1L << (lev - 1));
+    x = (a + 0.5 * h) + h * (double)j;
+  }
+  const double k = exp(x);
+  const double T = eh_transfer(E, k);
+  n[idx] = k;
+  n[kSigmaCount + idx] = exp((3.0 + E.ns) * (x - E.ln_H0)) * T * T;
+}
+
+// Delta^2(k) W(kR)^2 / (amp sigma_norm^2) from the table (levels <= kSigmaLevel),
+// direct evaluation beyond.
+struct SigmaTabIntegrand {
+  const Epoch* e;
+  const double* node;      // this epoch's table
+  double scale, inv_amp;
+  __device__ __forceinline__ void operator()(double ln_k, double (&out)[1], int lev,
+                                             long j) const {
+    if (lev <= kSigmaLevel) {
+      const int idx = node_index(lev, j);
+      const double kR = scale * node[idx];
+      double s, c;
+      fast_sincos(kR, &s, &c);
+      const double W = 3.0 * (s - kR * c) / (kR * kR * kR);
+      out[0] = node[kSigmaCount + idx] * W * W;
+    } else {
+      SigmaIntegrand f{e, scale};
+      out[0] = f(ln_k) * inv_amp;
+    }
+  }
+};
+
+// sigma^2(R) = int dlnk Delta^2 W^2 (cosmology.py:602-642) with the whole group on
+// one Romberg integral; `rtol` is cosmo_precision for reference-exact values.
+// UNROLL > 1 overlaps the table loads of several nodes (worth it where few blocks share a
+// CU, as in k_epoch_init; with many resident blocks the extra registers cost more).
+template <int NW, int UNROLL = 1>
+__device__ __forceinline__ double sigma2_block(const Epoch& E, const double* snode, double R,
+                                               const chomp_config& cfg, double rtol,
+                                               double* red) {
+  double lo, hi;
+  sigma_limits(E, R, &lo, &hi);
+  const double need_min = 1.0 / R / 10.0, need_max = 1.0 / R * 14.0662;
+  const double amp2 = E.amp * E.sigma_norm * E.sigma_norm;
+  if (need_min > E.k_min && need_max < E.k_max) {          // fixed range: table path
+    SigmaTabIntegrand f{&E, snode, R, 1.0 / amp2};
+    const RombergOut<1> r = romberg_group<NW, 1, SigmaTabIntegrand, UNROLL>(f, lo, hi, cfg.global_precision, rtol,
+                                                 cfg.divmax, red);
+    return amp2 * r.value[0];
+  }
+  SigmaIntegrand f{&E, R};
+  return romberg1<NW>(f, lo, hi, cfg.global_precision, rtol, cfg.divmax, red);
+}
+
+// Not-a-knot spline build by parallel cyclic reduction.  Every thread of the block
+// must call it (it contains barriers); the threads with 0 <= tid < tps of an
+// `active` caller work on one system, rows strided by tps, so several systems can
+// be built in lockstep by disjoint thread ranges.  w: 9 n doubles of LDS per system.
+__device__ __forceinline__ void spline_build_pcr(const double* x, const double* y, int n,
+                                                 double* c, double* w, int tid, int tps,
+                                                 bool active) {
+  double *a0 = w, *b0 = w + n, *c0 = w + 2 * n, *d0 = w + 3 * n;
+  double *a1 = w + 4 * n, *b1 = w + 5 * n, *c1 = w + 6 * n, *d1 = w + 7 * n;
+  double* sl = w + 8 * n;
+  if (active)
+    for (int i = tid; i < n; i += tps) spline_row(x, y, n, i, &a0[i], &b0[i], &c0[i], &d0[i]);
+  __syncthreads();
+  for (int s = 1; s < n; s *= 2) {
+    if (active)
+      for (int i = tid; i < n; i += tps) pcr_step(n, i, s, a0, b0, c0, d0, a1, b1, c1, d1);
+    __syncthreads();
+    double* t;
+    t = a0; a0 = a1; a1 = t;
+    t = b0; b0 = b1; b1 = t;
+    t = c0; c0 = c1; c1 = t;
+    t = d0; d0 = d1; d1 = t;
+  }
+  if (active)
+    for (int i = tid; i < n; i += tps) sl[i] = d0[i] / b0[i];
+  __syncthreads();
+  if (active)
+    for (int i = tid; i < n - 1; i += tps) spline_coef(x, y, sl, i, c);
+  __syncthreads();
+}
+
+// nu(M) = (delta_c / sigma(R(M)))^2, cosmology.py:662-699.
+template <int NW, int UNROLL = 1>
+__device__ __forceinline__ double nu_of_mass_block(const Epoch& E, const double* snode,
+                                                   double mass, const chomp_config& cfg,
+                                                   double rtol, double* red) {
+  const double s2 = sigma2_block<NW, UNROLL>(E, snode, scale_of_mass(E, mass), cfg, rtol, red);
+  const double sq = E.delta_c / sqrt(s2);
+  return sq * sq;
+}
+
+// ---------------------------------------------------------------------------
+// Mass-limit search (mass_function.py:160-203).  The reference walks mass_min (from 1e9)
+// and mass_max (from 1e16) in 5 % steps until nu(M) lands in 0.1(1 +- 0.05) /
+// 50(1 +- 0.05), one sigma(R) Romberg per step (57 steps at z=0, 306 at z=1.5).  nu(M) is
+// monotone, so the step the walk stops at is the first index j of the (bit-identical,
+// host-tabulated) candidate sequence M_0 * 1.05^(-+j) whose nu passes a one-sided
+// threshold test.
+//
+// k_epoch_init AIMS with the coarse ln S(R) table of the cosmology (nu to ~1e-4) and
+// CERTIFIES with Romberg integrals at the four candidates around the crossing -- eight
+// independent integrals per epoch, one per block -- so the decision rests on the same
+// integrals the reference would have evaluated there.  Whatever cannot be certified
+// (estimate too close to a threshold, candidate outside the table, disagreement) falls
+// back to the bracketing secant search on exact integrals.
+// ---------------------------------------------------------------------------
+constexpr int kInitNW = 4;       // wavefronts per k_epoch_init block
+
+struct SideThresholds {
+  double thr_lo, thr_hi;
+  const double *down, *up;      // candidate masses; [0] is the starting mass of both
+};
+__device__ __forceinline__ SideThresholds side_thresholds(int side, const double* cand) {
+  // cand: [0] min-side divide, [1] min-side multiply, [2] max-side multiply,
+  //       [3] max-side divide; index 0 of each is the starting mass.
+  SideThresholds t;
+  t.thr_lo = (side == 0 ? 0.1 : 50.0) * (1.0 - 0.05);
+  t.thr_hi = (side == 0 ? 0.1 : 50.0) * (1.0 + 0.05);
+  t.down = cand + (side == 0 ? 0 : 3) * kSearchJ;
+  t.up = cand + (side == 0 ? 1 : 2) * kSearchJ;
+  return t;
+}
+
+// nu(M) at a probe: a looser Romberg tolerance first; a probe that lands within
+// kAmbiguous (in ln nu) of a band edge is redone at the reference's tolerance, so every
+// comparison that decides the stopping step is either clear of the edge or exact.
+template <int NW>
+__device__ __forceinline__ double nu_probe(const Epoch& E, const double* snode, double m,
+                                           const chomp_config& cfg, double thr_lo,
+                                           double thr_hi, double* red) {
+  // (a cosmo_precision looser than the probe tolerance is used as it is: the reference's
+  // decision rests on exactly that integral)
+  const double kAmbiguous = 2e-5;
+  const double rtol_probe = cfg.cosmo_precision > 1e-6 ? cfg.cosmo_precision : 1e-6;
+  double nu = nu_of_mass_block<NW, 4>(E, snode, m, cfg, rtol_probe, red);
+  const double edge = fmin(fabs(log(nu / thr_lo)), fabs(log(nu / thr_hi)));
+  if (edge < kAmbiguous && cfg.cosmo_precision < rtol_probe)
+    nu = nu_of_mass_block<NW, 4>(E, snode, m, cfg, cfg.cosmo_precision, red);
+  return nu;
+}
+
+// The bracketing secant search on exact integrals (whole block).  Returns the mass the
+// reference's walk stops at; *n_eval counts the sigma integrals.  Seeds (from probes that
+// did not certify the estimate): seed_dir != 0 fixes the walking direction; candidate
+// seed_jl is known to FAIL the threshold test (nu_l: its nu, exact or estimated -- it only
+// steers the secant); seed_jh >= 0 is known to PASS it with exact nu_h.
+template <int NW>
+__device__ double search_side_exact(const Epoch& E, const double* snode, int side,
+                                    const chomp_config& cfg, const double* cand, double* red,
+                                    int* n_eval, int seed_dir = 0, int seed_jl = 0,
+                                    double nu_l = 0.0, int seed_jh = -1, double nu_h = 0.0) {
+  const SideThresholds T = side_thresholds(side, cand);
+  double mass = T.down[0];
+  int dir = seed_dir;
+  double nu0 = nu_l;
+  if (seed_dir == 0) {
+    nu0 = nu_probe<NW>(E, snode, T.down[0], cfg, T.thr_lo, T.thr_hi, red);
+    ++*n_eval;
+    if (T.thr_hi < nu0) dir = -1; else if (T.thr_lo > nu0) dir = +1;
+  }
+  if (dir != 0) {
+    const double* tab = dir < 0 ? T.down : T.up;
+    const double thr = dir < 0 ? T.thr_hi : T.thr_lo;
+    int jl = seed_dir == 0 ? 0 : seed_jl, jh = seed_dir == 0 ? -1 : seed_jh;
+    double tl = dir < 0 ? log(nu0 / thr) : log(thr / nu0);
+    double th = jh < 0 ? 0.0 : (dir < 0 ? log(nu_h / thr) : log(thr / nu_h));
+    double d = (side == 0 ? 0.25 : 0.7) * 0.04879;     // guess of d ln(nu) per step
+    for (int it = 0; it < 4 * kSearchJ; ++it) {
+      int jp;
+      if (jh < 0) {
+        double want = ceil(tl / d);
+        if (!(want >= 1.0)) want = 1.0;
+        if (want > 256.0) want = 256.0;
+        jp = jl + (int)want;
+        if (jp > kSearchJ - 1) jp = kSearchJ - 1;
+      } else {
+        if (jh == jl + 1) break;
+        const double dd = (tl - th) / (double)(jh - jl);
+        double want = ceil(tl / dd);
+        if (!(want >= 1.0)) want = 1.0;
+        if (want > (double)(jh - jl - 1)) want = (double)(jh - jl - 1);
+        jp = jl + (int)want;
+      }
+      const double nu = nu_probe<NW>(E, snode, tab[jp], cfg, T.thr_lo, T.thr_hi, red);
+      ++*n_eval;
+      const bool pred = dir < 0 ? !(thr < nu) : !(thr > nu);
+      const double tp = dir < 0 ? log(nu / thr) : log(thr / nu);
+      if (pred) {
+        jh = jp;
+        th = tp;
+      } else {
+        if (jh < 0) {
+          const double dn = (tl - tp) / (double)(jp - jl);
+          d = dn > 1e-6 ? dn : 1e-6;
+        }
+        jl = jp;
+        tl = tp;
+        if (jh < 0 && jp == kSearchJ - 1) { jh = jp; break; }   // table exhausted
+      }
+    }
+    if (jh < 0) jh = jl;
+    mass = tab[jh];
+  }
+  return mass;
+}
+
+// ln S at ln R = x from the coarse table (6-point Lagrange inside one segment); NaN
+// outside the table.
+__device__ __forceinline__ double ln_s_estimate(const SGrid& G, const double* lns, double x) {
+  if (!G.valid || !(x >= G.b0 && x <= G.b4)) return NAN;
+  double lo, hi;
+  int n, off;
+  G.segment(x, &lo, &hi, &n, &off);
+  const double u = (x - lo) / (hi - lo) * (double)(n - 1);
+  int i0 = (int)floor(u) - 2;
+  i0 = i0 < 0 ? 0 : (i0 > n - 6 ? n - 6 : i0);
+  const double* f = lns + off + i0;
+  const double t = u - (double)i0;               // position among nodes 0..5
+  const double t0 = t, t1 = t - 1.0, t2 = t - 2.0, t3 = t - 3.0, t4 = t - 4.0, t5 = t - 5.0;
+  return f[0] * (t1 * t2 * t3 * t4 * t5) * (-1.0 / 120.0) +
+         f[1] * (t0 * t2 * t3 * t4 * t5) * (1.0 / 24.0) +
+         f[2] * (t0 * t1 * t3 * t4 * t5) * (-1.0 / 12.0) +
+         f[3] * (t0 * t1 * t2 * t4 * t5) * (1.0 / 12.0) +
+         f[4] * (t0 * t1 * t2 * t3 * t5) * (-1.0 / 24.0) +
+         f[5] * (t0 * t1 * t2 * t3 * t4) * (1.0 / 120.0);
+}
+
+// Where the estimate says the walk of `side` stops: dir (0: the starting mass already
+// passes), and the first index j of the candidate table whose estimate passes.  ok = false
+// when the estimate cannot be trusted to within one candidate.  The whole block calls it
+// (every candidate is tried at once); sh: one int of LDS.
+struct SidePlan {
+  bool ok;
+  int dir, j;
+  double nu_start;              // estimate at the starting mass
+  bool at_edge;                 // the starting mass sits on a band edge: dir is a guess, the
+                                // probes are candidates 0..3 (j = 2) and 0 decides exactly
+};
+__device__ __forceinline__ SidePlan plan_side(const Epoch& E, const double* lns, int side,
+                                              const double* cand, int* sh) {
+  const SideThresholds T = side_thresholds(side, cand);
+  const SGrid G = make_sgrid(E.k_min, E.k_max);
+  const double margin = 1e-2;             // estimate error ~1e-4; candidates are >= 0.4 % apart
+  SidePlan P{false, 0, 0, 0.0, false};
+  // ln nu = ln_nu_c - ln S(ln R); the candidates are M_0 * 1.05^(-+j), so ln R moves by
+  // ln(1.05) / 3 per step (to the estimate's accuracy)
+  const double ln_nu_c = log(E.delta_c * E.delta_c / (E.amp * E.sigma_norm * E.sigma_norm));
+  const double x0 = log(scale_of_mass(E, T.down[0]));
+  const double step = 0.016263388 /* ln(1.05) / 3 */;
+  const double nu0 = exp(ln_nu_c - ln_s_estimate(G, lns, x0));
+  P.nu_start = nu0;
+  if (!(nu0 == nu0)) return P;
+  if (nu0 > T.thr_hi * (1.0 + margin)) P.dir = -1;
+  else if (nu0 < T.thr_lo * (1.0 - margin)) P.dir = +1;
+  else if (nu0 >= T.thr_lo * (1.0 + margin) && nu0 <= T.thr_hi * (1.0 - margin)) {
+    P.ok = true;                          // inside the band with room to spare
+    return P;
+  } else {                                // on an edge: probe the start and its neighbours
+    P.ok = true;
+    P.at_edge = true;
+    P.dir = nu0 > 0.5 * (T.thr_lo + T.thr_hi) ? -1 : +1;
+    P.j = 2;
+    return P;
+  }
+  const double ln_thr = log(P.dir < 0 ? T.thr_hi : T.thr_lo);
+  __syncthreads();
+  if (threadIdx.x == 0) *sh = kSearchJ;
+  __syncthreads();
+  // nu is monotone along the table, so the first passing index is the minimum over the
+  // passing ones; a candidate outside the ln S table counts as passing, and is rejected
+  // below if it turns out to be the first.
+  int mine = kSearchJ;
+  for (int j = 1 + (int)threadIdx.x; j < kSearchJ; j += blockDim.x) {
+    const double ln_nu = ln_nu_c - ln_s_estimate(G, lns, x0 + (double)(P.dir * j) * step);
+    const bool pass = !(ln_nu == ln_nu) || (P.dir < 0 ? !(ln_thr < ln_nu) : !(ln_thr > ln_nu));
+    if (pass) { mine = j; break; }               // (ascending j: the first is the smallest)
+  }
+  if (mine < kSearchJ) atomicMin(sh, mine);
+  __syncthreads();
+  const int j = *sh;
+  if (j >= kSearchJ) return P;                   // nothing passes: exact search
+  const double lsj = ln_s_estimate(G, lns, x0 + (double)(P.dir * j) * step);
+  if (!(lsj == lsj)) return P;                   // the walk leaves the ln S table
+  P.j = j;
+  P.ok = true;
+  return P;
+}
+
+// grid (n_epoch, 2 * kProbes), block 64 * kInitNW.  blockIdx.y = kProbes * side + p
+// certifies candidate j - 2 + p of side 0 (mass_min) / 1 (mass_max); role kProbes also
+// does the comoving distance (or only that, with fixed mass limits).  The last block of
+// an epoch to finish combines the results (count[e], reset by it).  epochs[e] holds the closed-form part of
+// the record (k_sigma_nodes) on entry and the complete record on exit.
+constexpr int kProbes = 4;
+constexpr int kProbeStride = 24;   // doubles per epoch: nu[2][kProbes], chi, pad[3], plan[2][4]
+__global__ __launch_bounds__(64 * kInitNW) void k_epoch_init(
+    chomp_config cfg, Epoch* __restrict__ epochs, double* __restrict__ search,
+    const double* __restrict__ cand, const double* __restrict__ snodes,
+    double* __restrict__ probe, int* __restrict__ count) {
+  __shared__ Epoch E;
+  __shared__ double red[romberg_scratch<kInitNW, 1>()];
+  __shared__ double lns[kSGrid];   // the cosmology's coarse ln S(R) table
+  __shared__ int last, sh_j;
+  const int e = blockIdx.x, role = blockIdx.y;
+  const bool chi_role = role == kProbes;
+  const int side = role / kProbes, p = role % kProbes;
+  const bool fixed = cfg.mass_min > 0.0 && cfg.mass_max > 0.0;     // mass_function.py:163-170
+  if (fixed && !chi_role) return;
+  copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
+               kEpochDoubles);
+  __syncthreads();
+  const double* snode = snodes + (size_t)E.cosmo_slot * kSigmaStride;
+  copy_doubles(lns, snode + kSigmaOffLnS, kSGrid);
+  if (threadIdx.x == 0) {
+    // sigma_8 normalisation, cosmology.py:118-119: sigma_r(8)^2 = amp * I8 with the
+    // cosmology-only integral I8 from k_sigma_nodes
+    E.sigma_norm = E.sigma8 * E.growth / sqrt(E.amp * snode[kSigmaOffI8]);
+  }
+  __syncthreads();
+  double* pr = probe + (size_t)e * kProbeStride;
+  if (chi_role) {                  // comoving distance, cosmology.py:106-110
+    EIntegrand f{E.om0, E.ol0, E.or0, E.H0};
+    const double chi = romberg1<kInitNW>(f, 0.0, E.z, cfg.global_precision,
+                                         cfg.cosmo_precision, cfg.divmax, red);
+    __syncthreads();
+    if (threadIdx.x == 0) { E.chi = chi; pr[2 * kProbes] = chi; }
+    __syncthreads();
+    if (fixed) {
+      if (threadIdx.x == 0) {
+        search[(e * 2 + 0) * 2 + 0] = log(cfg.mass_min);
+        search[(e * 2 + 0) * 2 + 1] = 0.0;
+        search[(e * 2 + 1) * 2 + 0] = log(cfg.mass_max);
+        search[(e * 2 + 1) * 2 + 1] = 0.0;
+      }
+      __syncthreads();
+      copy_doubles(reinterpret_cast<double*>(&epochs[e]), reinterpret_cast<const double*>(&E),
+                   kEpochDoubles);
+      return;
+    }
+  }
+  {
+    // ---- this block's probe: candidate j - 2 + p of its side
+    const SidePlan plan = plan_side(E, lns, side, cand, &sh_j);
+    const SideThresholds T = side_thresholds(side, cand);
+    double nu_mine = NAN;
+    if (plan.ok && plan.dir != 0) {
+      const int c = plan.j - 2 + p;
+      // (away from an edge candidate 0 fails by the margin of the estimate)
+      if ((c > 0 || (c == 0 && plan.at_edge)) && c < kSearchJ) {
+        const double* tab = plan.dir < 0 ? T.down : T.up;
+        nu_mine = nu_probe<kInitNW>(E, snode, tab[c], cfg, T.thr_lo, T.thr_hi, red);
+      }
+    }
+    if (threadIdx.x == 0) {
+      pr[role] = nu_mine;
+      if (p == 0) {
+        double* pl = pr + 2 * kProbes + 4 + 4 * side;
+        pl[0] = plan.ok ? (plan.at_edge ? 2.0 : 1.0) : 0.0; pl[1] = (double)plan.dir;
+        pl[2] = (double)plan.j; pl[3] = plan.nu_start;
+      }
+    }
+  }
+  if (threadIdx.x == 0) {
+    __threadfence();               // results visible before the arrival is counted
+    last = atomicAdd(&count[e], 1) == 2 * kProbes - 1 ? 1 : 0;
+  }
+  __syncthreads();
+  if (!last) return;
+  // ---- last block of the epoch: certify both sides, exact search where that fails
+  __threadfence();
+  auto peek = [](const double* q) {
+    return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  for (int sd = 0; sd < 2; ++sd) {
+    __syncthreads();
+    const double* pl = pr + 2 * kProbes + 4 + 4 * sd;
+    const double mode = peek(pl);
+    const bool ok = mode != 0.0, at_edge = mode == 2.0;
+    int dir = (int)peek(pl + 1);
+    const int j = (int)peek(pl + 2);
+    double nu_start = peek(pl + 3);
+    const SideThresholds S = side_thresholds(sd, cand);
+    double mass = S.down[0];
+    int n_eval = 0;
+    bool certified = ok;
+    int seed_dir = 0, seed_jl = 0, seed_jh = -1;
+    double nu_l = 0.0, nu_h = 0.0;
+    bool walk = ok && dir != 0;
+    if (at_edge) {                 // the exact nu of the starting mass decides the direction
+      nu_start = peek(pr + kProbes * sd);
+      const int dir_exact = S.thr_hi < nu_start ? -1 : (S.thr_lo > nu_start ? +1 : 0);
+      n_eval = 1;
+      if (!(nu_start == nu_start)) { certified = false; walk = false; n_eval = 0; }
+      else if (dir_exact == 0) walk = false;                     // stays at the start: done
+      else if (dir_exact != dir) {                               // guessed the other way
+        certified = false; walk = false;
+        seed_dir = dir_exact; seed_jl = 0; nu_l = nu_start;
+      }
+    }
+    if (walk) {
+      const double* tab = dir < 0 ? S.down : S.up;
+      const double thr = dir < 0 ? S.thr_hi : S.thr_lo;
+      // status of candidates j - 2 .. j + 1: 0 fails, 1 passes, -1 unknown
+      int st[kProbes];
+      double nu[kProbes];
+#pragma unroll
+      for (int q = 0; q < kProbes; ++q) {
+        const int c = j - 2 + q;
+        nu[q] = peek(pr + kProbes * sd + q);
+        if (c <= 0) st[q] = 0;     // (at an edge: candidate 0 fails exactly, see above)
+        else if (!(nu[q] == nu[q])) st[q] = -1;
+        else { st[q] = (dir < 0 ? !(thr < nu[q]) : !(thr > nu[q])) ? 1 : 0; ++n_eval; }
+      }
+      certified = false;
+      int first_pass = -1, before = -1;          // status of the candidate before it
+      double nu_first = 0.0;
+#pragma unroll
+      for (int q = kProbes - 1; q >= 0; --q)
+        if (st[q] == 1) { first_pass = q; nu_first = nu[q]; before = q > 0 ? st[q - 1] : -1; }
+      if (first_pass > 0 && before == 0) {                       // fails at c - 1, passes at c
+        certified = true;
+        mass = tab[j - 2 + first_pass];
+      } else if (first_pass == 0 && j - 2 == 1) {                // passes at 1, 0 fails
+        certified = true;
+        mass = tab[1];
+      }
+      if (!certified) {            // the estimate was off by more than the probes cover:
+        seed_dir = dir;            // the exact search starts from what they established
+        seed_jl = 0; nu_l = nu_start;
+#pragma unroll
+        for (int q = 0; q < kProbes; ++q)
+          if (st[q] == 0 && j - 2 + q > 0) { seed_jl = j - 2 + q; nu_l = nu[q]; }
+        if (first_pass >= 0 && j - 2 + first_pass > seed_jl) {
+          seed_jh = j - 2 + first_pass; nu_h = nu_first;
+        }
+      }
+    }
+    if (!certified)                // block-uniform: every thread read the same values
+      mass = search_side_exact<kInitNW>(E, snode, sd, cfg, cand, red, &n_eval, seed_dir, seed_jl,
+                                        nu_l, seed_jh, nu_h);
+    if (threadIdx.x == 0) {
+      search[(e * 2 + sd) * 2 + 0] = log(mass);
+      search[(e * 2 + sd) * 2 + 1] = (double)n_eval;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    E.chi = peek(pr + 2 * kProbes);
+    count[e] = 0;
+  }
+  __syncthreads();
+  copy_doubles(reinterpret_cast<double*>(&epochs[e]), reinterpret_cast<const double*>(&E),
+               kEpochDoubles);
+}
+
+// ---------------------------------------------------------------------------
+// k_nu_table: grid (NM, n_epoch), block 256: nu_i = nu_m(exp(ln_mass_i)).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_nu_table(chomp_config cfg, TabLayout L,
+                                                  const Epoch* __restrict__ epochs,
+                                                  const double* __restrict__ search,
+                                                  const double* __restrict__ snodes,
+                                                  double* __restrict__ tab) {
+  __shared__ Epoch E;
+  __shared__ double red[romberg_scratch<4, 2>()];
+  const int i = blockIdx.x, e = blockIdx.y;
+  copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
+               kEpochDoubles);
+  __syncthreads();
+  const double ln_lo = search[(e * 2 + 0) * 2], ln_hi = search[(e * 2 + 1) * 2];
+  const double lnm = linspace_at(ln_lo, ln_hi, L.NM, i);
+  const double nu = nu_of_mass_block<4>(E, snodes + (size_t)E.cosmo_slot * kSigmaStride, exp(lnm), cfg,
+                                        cfg.cosmo_precision, red);
+  if (threadIdx.x == 0) {
+    double* t = tab + (size_t)e * L.stride;
+    t[L.off_ln_mass + i] = lnm;
+    t[L.off_nu + i] = nu;
+  }
+}
+
+// Tinker10 parameter splines (mass_function.py:450-470): x[9] then 5 x 32 pp
+// coefficients (alpha, beta, gamma, phi, eta), built on the host at context
+// creation with the same spline_build.
+struct TinkerTab {
+  double x[9];
+  double c[5][32];
+};
+
+struct FnuLn {          // f(nu) d nu = f(e^t) e^t dt
+  const Epoch* e;
+  __device__ __forceinline__ double operator()(double t) const {
+    const double nu = exp(t);
+    return f_nu(*e, nu) * nu;
+  }
+};
+struct FnuLin {         // mass_function.py:227-231, as the reference integrates it
+  const Epoch* e;
+  __device__ __forceinline__ double operator()(double nu) const { return f_nu(*e, nu); }
+};
+struct FnuBiasLin {     // mass_function.py:235-240
+  const Epoch* e;
+  __device__ __forceinline__ double operator()(double nu) const {
+    return f_nu(*e, nu) * bias_nu(*e, nu);
+  }
+};
+constexpr int kNormLiteralDivmax = 18;
+struct FnuBiasLn {
+  const Epoch* e;
+  __device__ __forceinline__ double operator()(double t) const {
+    const double nu = exp(t);
+    return f_nu(*e, nu) * bias_nu(*e, nu) * nu;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// k_mass_setup: grid n_epoch, block 256.  Dynamic LDS: see carve-up below.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mass_setup(
+    chomp_config cfg, TabLayout L, Epoch* __restrict__ epochs,
+    const double* __restrict__ search, double* __restrict__ tab,
+    const chomp_halo_par* __restrict__ par, int mf_kind,
+    const TinkerTab* __restrict__ tinker, const double* __restrict__ gl16) {
+  extern __shared__ __align__(16) double sm[];
+  __shared__ Epoch E;
+  const int NM = L.NM;
+  double* x_lnm = sm;                    // [NM]
+  double* y_nu = x_lnm + NM;             // [NM]
+  double* c_nu = y_nu + NM;              // [4(NM-1)]
+  double* c_lnm = c_nu + 4 * (NM - 1);   // [4(NM-1)]
+  double* work = c_lnm + 4 * (NM - 1);   // [18 NM]
+  double* gl = work + 18 * NM;           // [32]
+  double* red = gl + 32;                 // [romberg_scratch<4, 1>()]
+  const int e = blockIdx.x;
+  double* t = tab + (size_t)e * L.stride;
+  copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
+               kEpochDoubles);
+  copy_doubles(x_lnm, t + L.off_ln_mass, NM);
+  copy_doubles(y_nu, t + L.off_nu, NM);
+  copy_doubles(gl, gl16, 32);
+  __syncthreads();
+  {   // nu(ln M) on threads 0..127, ln M(nu) on threads 128..255, in lockstep
+    const int sys = threadIdx.x >> 7, tid = threadIdx.x & 127;
+    spline_build_pcr(sys == 0 ? x_lnm : y_nu, sys == 0 ? y_nu : x_lnm, NM,
+                     sys == 0 ? c_nu : c_lnm, work + sys * 9 * NM, tid, 128, true);
+  }
+  if (threadIdx.x == 0) {
+    const chomp_halo_par hp = par[e];
+    E.ln_mass_min = search[(e * 2 + 0) * 2];
+    E.ln_mass_max = search[(e * 2 + 1) * 2];
+    E.n_search = (int)(search[(e * 2 + 0) * 2 + 1] + search[(e * 2 + 1) * 2 + 1]);
+    E.nu_min = 1.001 * y_nu[0];                       // mass_function.py:212-213
+    E.nu_max = 0.999 * y_nu[NM - 1];
+    E.m_star = exp(spline_eval(y_nu, c_lnm, NM, 1.0));   // :223
+    E.stq = hp.stq;
+    E.st_a = hp.st_little_a;
+    E.mf_delta_v = (hp.delta_v == -1.0) ? E.delta_v : hp.delta_v;
+    E.mf_kind = mf_kind;
+    E.f_norm = 1.0;
+    E.bias_norm = 1.0;
+    E.ln_st_a = log(hp.st_little_a);
+    E.ln_t_beta = 0.0;
+    if (mf_kind == CHOMP_MF_TINKER) {                 // mass_function.py:547-564
+      const double ld = log(E.mf_delta_v);
+      const double opz = 1.0 + E.z;
+      E.t_alpha = spline_eval(tinker->x, tinker->c[0], 9, ld);
+      E.t_beta = spline_eval(tinker->x, tinker->c[1], 9, ld) * pow(opz, 0.20);
+      E.t_gamma = spline_eval(tinker->x, tinker->c[2], 9, ld) * pow(opz, -0.01);
+      E.t_phi = spline_eval(tinker->x, tinker->c[3], 9, ld) * pow(opz, -0.08);
+      E.t_eta = spline_eval(tinker->x, tinker->c[4], 9, ld) * pow(opz, 0.27);
+      E.ln_t_beta = log(E.t_beta);
+      tinker_bias_constants(E);
+    }
+  }
+  __syncthreads();
+  // Normalisations (mass_function.py:225-241; Tinker: bias only, :532-545).  The
+  // reference integrates in linear nu with Romberg to rtol 1.48e-8 (8193 nodes);
+  // the integrand is analytic, so 8 x 16 Gauss-Legendre nodes in ln nu give the
+  // same number to ~4e-11.
+  // With a shallow divmax the reference's Romberg cannot converge and returns its last
+  // row; that (not the true integral) is then the reference's number, so the literal
+  // Romberg in linear nu is run instead (at most 2^17 cheap nodes).
+  int flip = 0;
+  const bool literal = cfg.divmax < kNormLiteralDivmax;
+  const double a = log(E.nu_min), b = log(E.nu_max);
+  if (mf_kind == CHOMP_MF_ST) {
+    double norm;
+    if (literal) {
+      FnuLin f{&E};
+      norm = romberg1<4>(f, E.nu_min, E.nu_max, cfg.global_precision, cfg.mass_precision,
+                         cfg.divmax, red);
+    } else {
+      FnuLn f{&E};
+      norm = gauss_panels<4>(f, a, b, 8, gl, red, flip);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) E.f_norm = 1.0 / norm;
+    __syncthreads();
+  }
+  {
+    double norm;
+    if (literal) {
+      FnuBiasLin f{&E};
+      norm = romberg1<4>(f, E.nu_min, E.nu_max, cfg.global_precision, cfg.mass_precision,
+                         cfg.divmax, red);
+    } else {
+      FnuBiasLn f{&E};
+      norm = gauss_panels<4>(f, a, b, 8, gl, red, flip);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) E.bias_norm = 1.0 / norm;
+    __syncthreads();
+  }
+  copy_doubles(reinterpret_cast<double*>(&epochs[e]), reinterpret_cast<const double*>(&E),
+               kEpochDoubles);
+  copy_doubles(t + L.off_nu_pp, c_nu, 4 * (NM - 1));
+  copy_doubles(t + L.off_lnm_pp, c_lnm, 4 * (NM - 1));
+}
+
+}  // namespace chomp

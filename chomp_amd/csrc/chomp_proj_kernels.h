@@ -22,7 +22,7 @@
 
 #include <hip/hip_runtime.h>
 
-#include "chomp_halo_kernels.h"
+#include "chomp_power_kernels.h"
 
 namespace chomp {
 
