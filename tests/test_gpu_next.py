@@ -125,3 +125,36 @@ def test_ascii_writers(tmp_path):
     wt = numpy.loadtxt(str(tmp_path / "w.txt"))
     assert numpy.allclose(wt[:, 0], corr.theta_array / d2r, rtol=1e-9)
     assert numpy.allclose(wt[:, 1], corr.wtheta_array, rtol=1e-9)
+
+
+def test_simulation_design_batched_equals_loop():
+    """simulation_design.py:116-155: the design points of a
+    SimulationDesign are one batch of epochs; the batch must give what the reference-shaped
+    point-by-point loop gives, and what the oracle gives for a point."""
+    from chomp_amd import halo, simulation_design as sd
+    from oracle import chomp_oracle as o
+    numpy.random.seed(12)
+    k = numpy.logspace(-3, 2, 24)
+    params = {"omega_m0": [0.27, 0.22, 0.35], "sigma_8": [0.8, 0.7, 0.9],
+              "log_M_min": [12.1, 11.8, 12.6]}
+    des = sd.SimulationDesignFlatUniverse(halo.Halo(0.3), "power_gm", params, n_design=6,
+                                          independent_var=k)
+    batched = des.run_design()
+    assert des._batched() and batched.shape == (24, 6)
+    points = des.points.copy()
+    loop = sd.SimulationDesignFlatUniverse(halo.Halo(0.3), "power_gm", params, n_design=6,
+                                           independent_var=k)
+    loop._init_design_points()
+    loop.points = points
+    looped = loop.run_design(batched=False)
+    assert rel_err(batched.values, looped.values) < 1e-12
+    # one point against the oracle
+    i = 4
+    pt = points.iloc[i]
+    cd = dict(o.default_cosmo_dict, omega_m0=pt["omega_m0"], sigma_8=pt["sigma_8"])
+    cd["omega_l0"] = 1.0 - cd["omega_m0"] - cd["omega_r0"]
+    hd = dict(o.default_hod_dict, log_M_min=pt["log_M_min"])
+    e = o.epoch(cd, 0.3)
+    t = o.halo_table(e, o.mass_table(e), o.zheng(hd), families=("gm",))
+    assert rel_err(batched.values[:, i], o.halo_power(t, "gm", k)) < RTOL
+    des.write("/dev/null")
