@@ -45,6 +45,7 @@ struct chomp_ctx {
   double* d_search = nullptr;
   double* d_probe = nullptr;       // k_epoch_init: certifying probes of the mass-limit search
   int* d_count = nullptr;          // k_epoch_init: arrivals per epoch (reset by the kernel)
+  int* d_pending = nullptr;        // work list of k_halo_knots_deep (cleared by k_halo_finalize)
   double* d_tab = nullptr;
   chomp_halo_par* d_mass_par = nullptr;
   chomp_halo_par* d_profile = nullptr;
@@ -186,7 +187,7 @@ int setup_constants(chomp_ctx* ctx) {
 
 int alloc_epochs(chomp_ctx* ctx, size_t n) {
   if (n <= ctx->cap_epoch) return CHOMP_OK;
-  void* old[] = {ctx->d_cosmo, ctx->d_z, ctx->d_epochs, ctx->d_search, ctx->d_probe, ctx->d_count, ctx->d_tab,
+  void* old[] = {ctx->d_cosmo, ctx->d_z, ctx->d_epochs, ctx->d_search, ctx->d_probe, ctx->d_count, ctx->d_pending, ctx->d_tab,
                  ctx->d_mass_par, ctx->d_profile, ctx->d_hod, ctx->d_nodes, ctx->d_snodes,
                  ctx->d_slot, ctx->d_first};
   for (void* p : old)
@@ -198,6 +199,8 @@ int alloc_epochs(chomp_ctx* ctx, size_t n) {
   HIPCHK(hipMalloc(&ctx->d_probe, n * kProbeStride * sizeof(double)));
   HIPCHK(hipMalloc(&ctx->d_count, n * sizeof(int)));
   HIPCHK(hipMemsetAsync(ctx->d_count, 0, n * sizeof(int), ctx->stream));
+  HIPCHK(hipMalloc(&ctx->d_pending, (2 + 3 * n * (size_t)ctx->L.NK) * sizeof(int)));
+  HIPCHK(hipMemsetAsync(ctx->d_pending, 0, 2 * sizeof(int), ctx->stream));
   HIPCHK(hipMalloc(&ctx->d_tab, n * (size_t)ctx->L.stride * sizeof(double)));
   HIPCHK(hipMalloc(&ctx->d_mass_par, n * sizeof(chomp_halo_par)));
   HIPCHK(hipMalloc(&ctx->d_profile, n * sizeof(chomp_halo_par)));
@@ -278,7 +281,7 @@ void chomp_ctx_destroy(chomp_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   void* ptrs[] = {ctx->d_sici, ctx->d_j0, ctx->d_j2, ctx->d_tinker, ctx->d_gl16,
-                  ctx->d_cand, ctx->d_cosmo, ctx->d_z, ctx->d_epochs, ctx->d_search, ctx->d_probe, ctx->d_count,
+                  ctx->d_cand, ctx->d_cosmo, ctx->d_z, ctx->d_epochs, ctx->d_search, ctx->d_probe, ctx->d_count, ctx->d_pending,
                   ctx->d_tab, ctx->d_mass_par, ctx->d_profile, ctx->d_hod, ctx->d_nodes, ctx->d_snodes, ctx->d_slot, ctx->d_first,
                   ctx->d_stage_in, ctx->d_stage_in2, ctx->d_stage_out, ctx->d_work, ctx->d_slow,
                   ctx->d_winfo, ctx->d_ktab};
@@ -420,14 +423,19 @@ int chomp_halo_setup(chomp_ctx* ctx, const chomp_halo_par* profile,
   if (groups[0] != 3)
   hipLaunchKernelGGL(k_halo_knots, dim3(L.NK, (unsigned)n, ng), dim3(256), 0, ctx->stream,
                      ctx->cfg, L, ctx->d_tab, ctx->d_sici, ctx->d_nodes, groups[0], groups[1],
-                     groups[2], kmask);
-  if (ctx->cfg.divmax > kNodeLevel && groups[0] != 3)
-    hipLaunchKernelGGL(k_halo_knots_deep, dim3(L.NK, (unsigned)n, ng), dim3(256), sh, ctx->stream,
-                       ctx->cfg, L, ctx->d_epochs, ctx->d_tab, ctx->d_profile, ctx->d_hod,
-                       ctx->d_sici, groups[0], groups[1], groups[2], kmask);
+                     groups[2], kmask, ctx->d_pending);
+  if (ctx->cfg.divmax > kNodeLevel && groups[0] != 3) {
+    // blocks draw knots from the list k_halo_knots left: enough of them to fill the chip
+    // when the list is long, cheap to launch when it is empty
+    unsigned gd = (unsigned)(L.NK * n * ng);
+    if (gd > 2048) gd = 2048;
+    hipLaunchKernelGGL(k_halo_knots_deep, dim3(gd), dim3(256), sh, ctx->stream, ctx->cfg, L,
+                       ctx->d_epochs, ctx->d_tab, ctx->d_profile, ctx->d_hod, ctx->d_sici,
+                       groups[0], groups[1], groups[2], kmask, (int)n, ctx->d_pending);
+  }
   const size_t sh2 = (size_t)(51 * L.NK) * sizeof(double);
   hipLaunchKernelGGL(k_halo_finalize, dim3((unsigned)n), dim3(384), sh2, ctx->stream, ctx->cfg,
-                     L, ctx->d_epochs, ctx->d_tab, ctx->d_profile, ctx->d_hod, fam);
+                     L, ctx->d_epochs, ctx->d_tab, ctx->d_profile, ctx->d_hod, fam, ctx->d_pending);
   HIPCHK(hipGetLastError());
   ctx->have_halo = true;
   ctx->fam_mask |= fam;

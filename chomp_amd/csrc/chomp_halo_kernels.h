@@ -271,7 +271,7 @@ constexpr unsigned kMaskExclusion = 1u << 8;   // bit of the kernels' family mas
 __global__ __launch_bounds__(256) void k_halo_knots(
     chomp_config cfg, TabLayout L, double* __restrict__ tab,
     const SiCiTab* __restrict__ sici_g, const double* __restrict__ nodes, int g0, int g1,
-    int g2, unsigned mask) {
+    int g2, unsigned mask, int* __restrict__ pending) {
   __shared__ SiCiTab S;
   __shared__ double red[kKnotScratch];
   const int NK = L.NK;
@@ -297,38 +297,52 @@ __global__ __launch_bounds__(256) void k_halo_knots(
       t[L.off_knot[fa] + ik] = r.value[0];
       lev[fa * NK + ik] = (!r.converged[0] && more) ? kPendingLevel : (double)r.level[0];
     }
+    bool any = false;
+    if (group != 2 && (mask & (1u << fa))) any = any || (!r.converged[0] && more);
     if (mask & (1u << fb)) {
       t[L.off_knot[fb] + ik] = r.value[1];
       lev[fb * NK + ik] = (!r.converged[1] && more) ? kPendingLevel : (double)r.level[1];
+      any = any || (!r.converged[1] && more);
     }
+    // work list of k_halo_knots_deep: [0] items, [1] next item to hand out, [2...] items
+    if (any) pending[2 + atomicAdd(&pending[0], 1)] = (int)((blockIdx.z * gridDim.y + e) * NK + ik);
   }
 }
 
 // ---------------------------------------------------------------------------
-// k_halo_knots_deep: same grid as k_halo_knots (without the n_bar column).  A block
-// whose knot is not marked pending exits at once; otherwise it redoes the Romberg
-// integral by direct evaluation up to divmax (the discontinuous HOD integrands run
-// to 2^18..2^20 nodes, halo.py:1038-1041, 1084-1086) and stores the pending
-// families.
+// k_halo_knots_deep: the knots k_halo_knots listed as not converged at the depth of the
+// node tables, redone by direct evaluation up to divmax (the discontinuous HOD integrands
+// run to 2^18..2^20 nodes, halo.py:1038-1041, 1084-1086).  1-D grid of any size; blocks
+// draw items from the list until it is empty (an empty list costs one load per block).
+// k_halo_finalize clears the list.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_halo_knots_deep(
     chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs,
     double* __restrict__ tab, const chomp_halo_par* __restrict__ profile,
     const HodDev* __restrict__ hod, const SiCiTab* __restrict__ sici_g, int g0, int g1,
-    int g2, unsigned mask) {
+    int g2, unsigned mask, int n_epoch, int* __restrict__ pending) {
   extern __shared__ __align__(16) double sm[];
   __shared__ Epoch E;
   __shared__ SiCiTab S;
+  __shared__ int item_sh;
   const int NK = L.NK;
-  const int ik = blockIdx.x, e = blockIdx.y;
-  const int group = blockIdx.z == 0 ? g0 : (blockIdx.z == 1 ? g1 : g2);
-  if (group < 0 || group > 2) return;
+  const int count = pending[0];
+  if (count == 0) return;          // nothing listed: no traffic on the queue head
+  for (;;) {
+  __syncthreads();                 // (previous item done with E, S, sm)
+  if (threadIdx.x == 0) item_sh = atomicAdd(&pending[1], 1);
+  __syncthreads();
+  if (item_sh >= count) return;    // block-uniform
+  const int item = pending[2 + item_sh];
+  const int ik = item % NK, e = (item / NK) % n_epoch, zg = item / (NK * n_epoch);
+  const int group = zg == 0 ? g0 : (zg == 1 ? g1 : g2);
+  if (group < 0 || group > 2) continue;
   double* t = tab + (size_t)e * L.stride;
   double* lev = t + L.off_levels;
   const int fa = group_fa(group), fb = group_fb(group);
   const bool pa = group != 2 && (mask & (1u << fa)) && lev[fa * NK + ik] == kPendingLevel;
   const bool pb = (mask & (1u << fb)) && lev[fb * NK + ik] == kPendingLevel;
-  if (!pa && !pb) return;
+  if (!pa && !pb) continue;
   HaloLds H;
   H.stage(L, E, S, epochs, e, t, profile, hod, sici_g, sm);
   double* red = H.rest;
@@ -360,6 +374,7 @@ __global__ __launch_bounds__(256) void k_halo_knots_deep(
     if (pa) { t[L.off_knot[fa] + ik] = va; lev[fa * NK + ik] = (double)la; }
     if (pb) { t[L.off_knot[fb] + ik] = vb; lev[fb * NK + ik] = (double)lb; }
   }
+  }   // next item
 }
 
 // ---------------------------------------------------------------------------
@@ -371,9 +386,10 @@ __global__ __launch_bounds__(256) void k_halo_knots_deep(
 __global__ __launch_bounds__(384) void k_halo_finalize(
     chomp_config cfg, TabLayout L, Epoch* __restrict__ epochs, double* __restrict__ tab,
     const chomp_halo_par* __restrict__ profile, const HodDev* __restrict__ hod,
-    unsigned fam_mask) {
+    unsigned fam_mask, int* __restrict__ pending) {
   extern __shared__ __align__(16) double sm[];
   const int NK = L.NK;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { pending[0] = 0; pending[1] = 0; }
   double* xk = sm;                      // [NK]
   double* yk = xk + NK;                 // [5][NK]
   double* work = yk + 5 * NK;           // [5][9 NK]

@@ -91,7 +91,8 @@ __device__ __forceinline__ void copy_doubles(double* dst, const double* src, int
 // [ln k_min, ln k_max] (cosmology.py:611-632), so every such integral of an epoch
 // visits the same ln k nodes: k_j and the R-independent factor
 // (k_j/H0)^(3+n) T(k_j)^2 of Delta^2 are tabulated once per epoch on the
-// level-kSigmaLevel Romberg grid (level-major order) by k_sigma_nodes.
+// level-kSigmaLevel Romberg grid (level-major order) by k_sigma_nodes (the factor is
+// stored divided by k_j^6, see SigmaTabIntegrand).
 constexpr int kSigmaLevel = 13;
 constexpr int kSigmaCount = (1 << kSigmaLevel) + 1;
 // Coarse table of ln S(R), S = int dlnk (k/H0)^(3+n) T^2 W(kR)^2 over sigma_r's own
@@ -211,15 +212,18 @@ __global__ __launch_bounds__(256) void k_sigma_nodes(chomp_config cfg,
   const double k = exp(x);
   const double T = eh_transfer(E, k);
   n[idx] = k;
-  n[kSigmaCount + idx] = exp((3.0 + E.ns) * (x - E.ln_H0)) * T * T;
+  // Delta^2 shape over k^6: W(kR)^2 = 9 (sin y - y cos y)^2 / (k R)^6 then needs no division
+  const double k3 = k * k * k;
+  n[kSigmaCount + idx] = exp((3.0 + E.ns) * (x - E.ln_H0)) * T * T / (k3 * k3);
 }
 
 // Delta^2(k) W(kR)^2 / (amp sigma_norm^2) from the table (levels <= kSigmaLevel),
 // direct evaluation beyond.
 struct SigmaTabIntegrand {
   const Epoch* e;
-  const double* node;      // this epoch's table
+  const double* node;      // this cosmology's table: k_j, then (k_j/H0)^(3+n) T^2 / k_j^6
   double scale, inv_amp;
+  double nine_over_r6;     // 9 / R^6
   __device__ __forceinline__ void operator()(double ln_k, double (&out)[1], int lev,
                                              long j) const {
     if (lev <= kSigmaLevel) {
@@ -227,8 +231,8 @@ struct SigmaTabIntegrand {
       const double kR = scale * node[idx];
       double s, c;
       fast_sincos(kR, &s, &c);
-      const double W = 3.0 * (s - kR * c) / (kR * kR * kR);
-      out[0] = node[kSigmaCount + idx] * W * W;
+      const double t = s - kR * c;
+      out[0] = node[kSigmaCount + idx] * nine_over_r6 * (t * t);
     } else {
       SigmaIntegrand f{e, scale};
       out[0] = f(ln_k) * inv_amp;
@@ -249,7 +253,8 @@ __device__ __forceinline__ double sigma2_block(const Epoch& E, const double* sno
   const double need_min = 1.0 / R / 10.0, need_max = 1.0 / R * 14.0662;
   const double amp2 = E.amp * E.sigma_norm * E.sigma_norm;
   if (need_min > E.k_min && need_max < E.k_max) {          // fixed range: table path
-    SigmaTabIntegrand f{&E, snode, R, 1.0 / amp2};
+    const double r3 = R * R * R;
+    SigmaTabIntegrand f{&E, snode, R, 1.0 / amp2, 9.0 / (r3 * r3)};
     const RombergOut<1> r = romberg_group<NW, 1, SigmaTabIntegrand, UNROLL>(f, lo, hi, cfg.global_precision, rtol,
                                                  cfg.divmax, red);
     return amp2 * r.value[0];
