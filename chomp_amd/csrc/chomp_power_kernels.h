@@ -298,6 +298,7 @@ __global__ __launch_bounds__(256) void k_power_grid(chomp_config cfg, TabLayout 
   slow_list_begin(slow, parity);
   const int k_group = (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
   const PowerFam F = power_families(w);
+  const bool same_ab = F.fa == F.fb;
   const int NK = L.NK;
   const KLanes s = load_k_lanes(cfg, NK, k, nk, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
   const int idxu = __builtin_amdgcn_readfirstlane(s.idx0);
@@ -354,11 +355,14 @@ __global__ __launch_bounds__(256) void k_power_grid(chomp_config cfg, TabLayout 
       shape1 = power_shape(E, s.lk1, k1);
     }
     double ha0 = fma(fma(fma(c.a3, d0, c.a2), d0, c.a1), d0, c.a0);
-    double hb0 = fma(fma(fma(c.b3, d0, c.b2), d0, c.b1), d0, c.b0);
     double pp0 = fma(fma(fma(c.p3, d0, c.p2), d0, c.p1), d0, c.p0);
     double ha1 = fma(fma(fma(c.a3, d1, c.a2), d1, c.a1), d1, c.a0);
-    double hb1 = fma(fma(fma(c.b3, d1, c.b2), d1, c.b1), d1, c.b0);
     double pp1 = fma(fma(fma(c.p3, d1, c.p2), d1, c.p1), d1, c.p0);
+    double hb0 = ha0, hb1 = ha1;   // P_mm and P_gg multiply a 2-halo factor by itself
+    if (!same_ab) {                // wave-uniform
+      hb0 = fma(fma(fma(c.b3, d0, c.b2), d0, c.b1), d0, c.b0);
+      hb1 = fma(fma(fma(c.b3, d1, c.b2), d1, c.b1), d1, c.b0);
+    }
     if (two) {       // the wavefront straddles a knot: lanes above it use the next piece
       const double* t = tab + (size_t)(epoch0 + qc) * L.stride;
       const double A0 = t[oa + 4], A1 = t[oa + 5], A2 = t[oa + 6], A3 = t[oa + 7];
@@ -457,6 +461,7 @@ __global__ __launch_bounds__(256) void k_power_stream(TabLayout L, const double*
   const int idxu = info & kWaveIdxMask;
   const bool two = (info & kWaveTwo) != 0;
   const PowerFam F = power_families(w);
+  const bool same_ab = F.fa == F.fb;
   const int oa = L.off_kpp[F.fa] + 4 * idxu, ob = L.off_kpp[F.fb] + 4 * idxu,
             op = L.off_kpp[F.fp] + 4 * idxu;
   const int q_lo = blockIdx.y * PER;
@@ -478,11 +483,14 @@ __global__ __launch_bounds__(256) void k_power_stream(TabLayout L, const double*
   for (int j = 0; j < PER; ++j) {
     const Row& c = r[j];
     double ha0 = fma(fma(fma(c.a3, d0, c.a2), d0, c.a1), d0, c.a0);
-    double hb0 = fma(fma(fma(c.b3, d0, c.b2), d0, c.b1), d0, c.b0);
     double pp0 = fma(fma(fma(c.p3, d0, c.p2), d0, c.p1), d0, c.p0);
     double ha1 = fma(fma(fma(c.a3, d1, c.a2), d1, c.a1), d1, c.a0);
-    double hb1 = fma(fma(fma(c.b3, d1, c.b2), d1, c.b1), d1, c.b0);
     double pp1 = fma(fma(fma(c.p3, d1, c.p2), d1, c.p1), d1, c.p0);
+    double hb0 = ha0, hb1 = ha1;   // P_mm and P_gg multiply a 2-halo factor by itself
+    if (!same_ab) {                // wave-uniform
+      hb0 = fma(fma(fma(c.b3, d0, c.b2), d0, c.b1), d0, c.b0);
+      hb1 = fma(fma(fma(c.b3, d1, c.b2), d1, c.b1), d1, c.b0);
+    }
     if (two) {       // the wavefront straddles a knot: lanes above it use the next piece
       const double* t = tab + (size_t)(epoch0 + q_lo + j) * L.stride;
       const double A0 = t[oa + 4], A1 = t[oa + 5], A2 = t[oa + 6], A3 = t[oa + 7];

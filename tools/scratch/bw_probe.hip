@@ -119,6 +119,23 @@ int main() {
         snprintf(nm, 96, "rows_u sc1 U=4 rot=%d block=%d", rot, bs); rep(nm, timeit([&] { hipLaunchKernelGGL((k_rows_u<2, 4>), dim3(nk / 2 / bs / 4), dim3(bs), 0, 0, out, nk, nz, rot); }), bytes);
         snprintf(nm, 96, "rows_u sc1 U=8 rot=%d block=%d", rot, bs); rep(nm, timeit([&] { hipLaunchKernelGGL((k_rows_u<2, 8>), dim3(nk / 2 / bs / 8), dim3(bs), 0, 0, out, nk, nz, rot); }), bytes);
       }
+
+    {   // sustained behaviour: 30 batches of 10 launches of the row-major pattern (per = 2)
+      const unsigned gx = (unsigned)(nk / 2 / 256);
+      hipEvent_t ev[31];
+      for (int i = 0; i < 31; ++i) hipEventCreate(&ev[i]);
+      hipDeviceSynchronize();
+      hipEventRecord(ev[0], 0);
+      for (int b = 0; b < 30; ++b) {
+        for (int r = 0; r < 10; ++r)
+          hipLaunchKernelGGL(k_tab<2>, dim3(gx, nz / 2), dim3(256), 0, 0, tbl, out, nk, 2);
+        hipEventRecord(ev[b + 1], 0);
+      }
+      hipDeviceSynchronize();
+      printf("sustained tab sc1 per=2, us per launch in batches of 10:");
+      for (int b = 0; b < 30; ++b) { float ms; hipEventElapsedTime(&ms, ev[b], ev[b + 1]); printf(" %.0f", ms * 100.0f); }
+      printf("\n");
+    }
     for (int gy : {16, 32, 64}) {
       snprintf(nm, 96, "rows sc1 gy=%d block=256", gy); rep(nm, timeit([&] { hipLaunchKernelGGL(k_rows_y<2>, dim3(nk / 512, gy), dim3(256), 0, 0, out, nk, nz, nk); }), bytes);
     }
