@@ -3,7 +3,8 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one full pass of the hot path over BASELINE.json's configs[1]:
+Default workload (the headline): a "step" is one full pass of the hot path over
+BASELINE.json's configs[1]:
 Stage K (every table of the 64 redshifts: sigma_8 normalisation, mass-limit search,
 nu table, splines, normalisations, n_bar, the 50-knot 2-halo / 1-halo integrals)
 followed by Stage E (P_mm on the 4096 x 64 (k, z) grid), with k resident in HBM
@@ -12,6 +13,9 @@ prints ONE JSON line (contract in the task description) carrying `roofline`
 (Stage-E kernel, HIP events on the kernel's own stream) and `cpu_baseline` (the
 NumPy oracle = a port of the reference's algorithm, timed on this box's host
 cores on a bounded sample of the same workload).
+
+--workload c3 is configs[2] (same grid, Tinker10 + Zheng07 P_gm); c4 / c5 are the
+projection configs (w(theta) at 1024 theta + C_l at 2048 l, see projection_bench).
 """
 import argparse
 import json
@@ -68,12 +72,164 @@ def cpu_baseline(which, mass_function, sample_z, pool_z):
             "host_cores_available": os.cpu_count()}
 
 
+N_THETA, N_ELL = 1024, 2048
+
+
+def projection_baseline(ggl):
+    """The oracle on a bounded sample of the projection workload (one thread): the set-up
+    (MultiEpoch, windows, 50-knot kernel, halo tables at z_bar) and a few theta / l."""
+    from oracle import chomp_oracle as o
+    d2r = numpy.pi / 180.0
+    t0 = time.perf_counter()
+    me = o.multi_epoch(0.0, 5.0)
+    wa = o.window_table("galaxy", o.dndz_maglim(0.0, 2.0, 2.0, 0.3, 2.0), me)
+    wb = (o.window_table("convergence", o.dndz_gaussian(0.0, 2.0, 1.0, 0.2), me) if ggl else
+          o.window_table("galaxy", o.dndz_maglim(0.0, 2.0, 2.0, 0.3, 2.0), me))
+    kt = o.kernel_table(1e-6 * d2r, 100.0 * d2r, wa, wb, me, bessel_order=2 if ggl else 0)
+    e = o.epoch(None, float(kt.z_bar))
+    fam = ("gm",) if ggl else ("gg",)
+    t = o.halo_table(e, o.mass_table(e), o.zheng(), families=fam)
+    if ggl:
+        o.halofit_table(t)
+    D_z = float(o.me_growth(me, kt.z_bar))
+    t_setup = time.perf_counter() - t0
+    power = ((lambda k: o.halofit_power(t, "gm", k)) if ggl else
+             (lambda k: o.halo_power(t, "gg", k)))
+    theta = numpy.logspace(-3, 0, N_THETA)[::128] * d2r
+    ell = numpy.logspace(1, 4, N_ELL)[::128]
+    t0 = time.perf_counter()
+    o.wtheta(kt, power, theta, t.k_min, t.k_max, D_z)
+    o.cell(kt, power, ell, D_z)
+    t_eval = time.perf_counter() - t0
+    n = theta.size + ell.size
+    full = t_setup + t_eval * (N_THETA + N_ELL) / n      # what the whole workload would take
+    return {"value": (N_THETA + N_ELL) / full, "unit": "samples/s", "cores": 1, "kind": "port",
+            "sample": "oracle set-up (%.1f s) + %d of %d theta and %d of %d l (%.1f s), the "
+                      "evaluation time scaled to the full grid" % (
+                          t_setup, theta.size, N_THETA, ell.size, N_ELL, t_eval),
+            "host_cores_available": os.cpu_count()}
+
+
+def projection_bench(args, world, rank, local):
+    """configs[3] (c4: gal-gal clustering, J0, P_gg) and configs[4] (c5: galaxy-galaxy
+    lensing, J2, HaloFit P_gm): a step = the whole projection path -- MultiEpoch chi(z),
+    both windows, the 50-knot Bessel kernel and z_bar, the halo tables at z_bar, then
+    w(theta) at 1024 theta and C_l at 2048 l -- with theta / l sharded over the ranks
+    (set-up replicated, as SURVEY 8(e) prescribes) and one all-gather each."""
+    ggl = args.workload == "c5"
+    baseline = None
+    if world == 1 and not args.no_cpu_baseline:
+        baseline = projection_baseline(ggl)
+    import torch
+    import torch.distributed as dist
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    if args.rehearse:
+        local = 0
+        os.environ["CHOMP_DEVICE"] = "0"      # the mirror classes pick their device from here
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo" if args.rehearse else "nccl",
+                                **({} if args.rehearse else {"device_id": dev}))
+    from chomp_amd import cosmology, correlation, halo, kernel
+    d2r = numpy.pi / 180.0
+    cm = cosmology.MultiEpoch(0.0, 5.0)
+    wa = kernel.WindowFunctionGalaxy(kernel.dNdzMagLim(0.0, 2.0, 2.0, 0.3, 2.0), cm)
+    if ggl:
+        wb = kernel.WindowFunctionConvergence(kernel.dNdzGaussian(0.0, 2.0, 1.0, 0.2), cm)
+        kern = kernel.GalaxyGalaxyLensingKernel(1e-6 * d2r, 100.0 * d2r, wa, wb, cm)
+        h = halo.HaloFit(0.0)
+        spec = "power_gm"
+    else:
+        wb = kernel.WindowFunctionGalaxy(kernel.dNdzMagLim(0.0, 2.0, 2.0, 0.3, 2.0), cm)
+        kern = kernel.Kernel(1e-6 * d2r, 100.0 * d2r, wa, wb, cm)
+        h = halo.Halo(0.0)
+        spec = "power_gg"
+    corr = correlation.Correlation(0.001, 1.0, kern, input_halo=h, power_spec=spec)
+    theta = torch.logspace(-3, 0, N_THETA, dtype=torch.float64, device=dev) * d2r
+    ell = torch.logspace(1, 4, N_ELL, dtype=torch.float64, device=dev)
+    my_theta = theta[rank::world].contiguous()
+    my_ell = ell[rank::world].contiguous()
+
+    def step():
+        # forget every table: the step rebuilds the projection and the halo model
+        kern._done.clear()
+        h._epoch_sig = None
+        h._nbar_valid = False
+        h._reset_flags(all_tables=True)
+        if ggl:
+            h._initialized_sigma_spline = False
+        ctx, code = corr._prepare()
+        w = ctx.wtheta(code, 0, corr._k_lim[0], corr._k_lim[1], corr.D_z, my_theta)
+        c = ctx.cell(code, 0, corr.D_z, my_ell)
+        if world > 1:
+            wf = torch.empty(world * w.numel(), dtype=torch.float64, device=w.device)
+            cf = torch.empty(world * c.numel(), dtype=torch.float64, device=c.device)
+            if args.rehearse:
+                wh, ch = wf.cpu(), cf.cpu()
+                dist.all_gather_into_tensor(wh, w.cpu())
+                dist.all_gather_into_tensor(ch, c.cpu())
+                wf, cf = wh.to(dev), ch.to(dev)
+            else:
+                dist.all_gather_into_tensor(wf, w)
+                dist.all_gather_into_tensor(cf, c)
+            w = wf.view(world, -1).t().reshape(-1)       # undo the interleaved sharding
+            c = cf.view(world, -1).t().reshape(-1)
+        return w, c
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        w, c = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        w, c = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse else dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert w.numel() == N_THETA and c.numel() == N_ELL
+    assert bool(torch.isfinite(w).all()) and bool((c > 0).all())
+    if rank == 0:
+        res = {"metric": "Limber w(theta) + C_l samples/sec (projection and halo set-up included)",
+               "value": (N_THETA + N_ELL) * args.steps / elapsed, "unit": "samples/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+               "data": "synthetic" + (" (REHEARSAL on one GPU: not a measurement)"
+                                      if args.rehearse else ""),
+               "config": {"workload": "configs[%d]: %s, %d theta (logspace -3..0 deg) + %d l "
+                                      "(logspace 1..4), WMAP7, halo at z_bar" % (
+                                          4 if ggl else 3,
+                                          "galaxy-galaxy lensing J2 kernel + HaloFit power_gm" if ggl
+                                          else "gal-gal clustering J0 kernel + power_gg",
+                                          N_THETA, N_ELL),
+                          "n_theta": N_THETA, "n_ell": N_ELL,
+                          "sharding": "theta and l interleaved over %d rank(s), set-up "
+                                      "replicated, one all-gather each" % world},
+               "roofline": None}
+        if baseline is not None:
+            res["cpu_baseline"] = baseline
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--roofline-nk", type=int, default=1 << 20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse", action="store_true",
@@ -85,6 +241,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node N"
+    if args.workload in ("c4", "c5"):
+        return projection_bench(args, world, rank, local)
     which = "power_mm" if args.workload == "c2" else "power_gm"
     mf = "st" if args.workload == "c2" else "tinker"
     baseline = None
