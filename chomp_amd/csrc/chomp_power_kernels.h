@@ -48,6 +48,24 @@ __device__ __forceinline__ double halofit_mm(const Epoch& E, double k) {
   return 2.0 * kPi * kPi / (k * k * k) * (d2q + d2h);
 }
 
+// halofit_mm for a caller that holds ln k as well: every power becomes one exp of a
+// linear form in ln k, the linear spectrum comes from power_shape (halo.py:1339-1360).
+__device__ __forceinline__ double halofit_mm_ln(const Epoch& E, double amp2, double lk, double k) {
+  const double k3 = k * k * k;
+  const double dk = amp2 * power_shape(E, lk, k) * k3 * (1.0 / (2.0 * kPi * kPi));
+  const double ln_y = lk - log(E.hf_k_s);               // (log of a per-epoch constant)
+  const double y = exp(ln_y);
+  const double d2q = dk * exp(E.hf_beta_n * fast_log(1.0 + dk) - (y * 0.25 + y * y * 0.125)) /
+                     (1.0 + E.hf_alpha_n * dk);
+  const double t_b = exp(E.hf_f2 * ln_y);
+  const double t_c = exp((3.0 - E.hf_gamma_n) * (log(E.hf_c_n * E.hf_f3) + ln_y));
+  const double inv_y = 1.0 / y;
+  const double d2h = E.hf_a_n * exp(3.0 * E.hf_f1 * ln_y) /
+                     ((1.0 + E.hf_b_n * t_b + t_c) *
+                      (1.0 + E.hf_mu_n * inv_y + E.hf_nu_n * inv_y * inv_y));
+  return 2.0 * kPi * kPi / k3 * (d2q + d2h);
+}
+
 // P(k) of one epoch from tables staged in LDS: shared by k_power and by the
 // projection integrands (correlation.py:270-275, 387-392 call halo.power_*).
 struct PowerEval {
@@ -56,7 +74,7 @@ struct PowerEval {
   int NK, w;
   bool halofit, extrap;
   const double* tail;             // misc[3..7] of the epoch (k_power_extrap)
-  double x0, dx, k_min, k_max, c_lo;
+  double x0, dx, inv_dx, amp2, k_min, k_max, c_lo;
 
   // Stage the coefficient sets of spectrum `which` of epoch table `t` into `sm`
   // (needs 12 (NK-1) doubles) and set the evaluator up.  All threads call it;
@@ -86,6 +104,8 @@ struct PowerEval {
     k_max = cfg.k_max;
     x0 = log(cfg.k_min);
     dx = (log(cfg.k_max) - x0) / (double)(NK - 1);
+    inv_dx = 1.0 / dx;
+    amp2 = Els->amp * Els->sigma_norm * Els->sigma_norm;
     c_lo = 0.0;
   }
   __device__ __forceinline__ bool needs_tables() const {
@@ -123,6 +143,29 @@ struct PowerEval {
     }
     if (extrap) return power_tail(*E, tail, w, kv, k_max);
     return 0.0;                                           // k > k_max (or NaN)
+  }
+  // The same spectrum for callers that integrate over ln k (w(theta), xi(r)) and so hold
+  // both ln k and k: no logarithm is retaken, the three splines share one interval
+  // lookup, and the linear spectrum uses the two-division arrangement of Stage E
+  // (power_shape).  Agrees with operator() to rounding.
+  __device__ __forceinline__ double at_ln(double lk, double kv) const {
+    const bool in = kv >= k_min && kv <= k_max;
+    if (halofit) {
+      const double pmm = halofit_mm_ln(*E, amp2, lk, kv);
+      if (w == CHOMP_P_MM) return pmm;
+      if (!in) return 0.0;                                // halo.py:649-672 range rule
+      int i = (int)floor((lk - x0) * inv_dx);
+      i = i < 0 ? 0 : (i > NK - 2 ? NK - 2 : i);
+      const double d = lk - (x0 + dx * (double)i);
+      return pmm * pp_poly(ca, i, d) * pp_poly(cb, i, d) + pp_poly(cp, i, d);
+    }
+    if (w == CHOMP_P_LIN || !in || (extrap && !(kv < k_max)))
+      return (*this)(kv);                                 // the rarely taken branches
+    int i = (int)floor((lk - x0) * inv_dx);
+    i = i < 0 ? 0 : (i > NK - 2 ? NK - 2 : i);
+    const double d = lk - (x0 + dx * (double)i);
+    const double ha = pp_poly(ca, i, d), hb = pp_poly(cb, i, d), pp = pp_poly(cp, i, d);
+    return amp2 * power_shape(*E, lk, kv) * ha * hb + pp;
   }
 };
 

@@ -449,8 +449,13 @@ struct KernelView {
   double lo, hi;
   __device__ __forceinline__ double operator()(double x) const {
     const double dx = (hi - lo) / (double)(N - 1);
+    const double inv_dx = (double)(N - 1) / (hi - lo);    // (both loop-invariant for a caller)
     if (x < lo) return pp_poly(pp, 0, 0.0);
-    if (x <= hi) return spline_eval_uniform(lo, dx, pp, N, x);
+    if (x <= hi) {
+      int i = (int)floor((x - lo) * inv_dx);
+      i = i < 0 ? 0 : (i > N - 2 ? N - 2 : i);
+      return pp_poly(pp, i, x - (lo + dx * (double)i));
+    }
     return 0.0;
   }
 };
@@ -486,15 +491,18 @@ __global__ void k_window_eval(ProjLayout L, const ProjDev* __restrict__ pd,
 struct WthetaIntegrand {
   const PowerEval* P;
   const KernelView* K;
-  double theta, inv_D2;
+  double theta, inv_D2, ln_theta;
   __device__ __forceinline__ double operator()(double ln_k) const {
     const double k = exp(ln_k);
-    return k * k / (2.0 * kPi) * (*P)(k) * inv_D2 * (*K)(log(k * theta));
+    return k * k / (2.0 * kPi) * P->at_ln(ln_k, k) * inv_D2 * (*K)(ln_k + ln_theta);
   }
 };
 
-// grid n_theta, block 256: one theta per workgroup.
-__global__ __launch_bounds__(256) void k_wtheta(chomp_config cfg, TabLayout HL, ProjLayout L,
+// grid n_theta, block 64 * kWthetaNW: one theta per workgroup.  The integrals of large
+// theta run to 2^18..2^20 nodes (the kernel oscillates in ln k theta) and set the launch's
+// duration, hence the wide group.
+constexpr int kWthetaNW = 16;
+__global__ __launch_bounds__(64 * kWthetaNW) void k_wtheta(chomp_config cfg, TabLayout HL, ProjLayout L,
                                                 const Epoch* __restrict__ epochs, int e,
                                                 const double* __restrict__ htab, int which,
                                                 const ProjDev* __restrict__ pd,
@@ -504,7 +512,7 @@ __global__ __launch_bounds__(256) void k_wtheta(chomp_config cfg, TabLayout HL, 
                                                 double* __restrict__ out) {
   extern __shared__ __align__(16) double sm[];
   __shared__ Epoch E;
-  __shared__ double red[romberg_scratch<4, 2>()];
+  __shared__ double red[romberg_scratch<kWthetaNW, 2>()];
   copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
                kEpochDoubles);
   PowerEval P;
@@ -514,8 +522,8 @@ __global__ __launch_bounds__(256) void k_wtheta(chomp_config cfg, TabLayout HL, 
   __syncthreads();
   P.finish();
   const KernelView K{kpp, L.NKT, pd->ln_kt_min, pd->ln_kt_max};
-  WthetaIntegrand f{&P, &K, theta[blockIdx.x], 1.0 / (D_z * D_z)};
-  const double v = romberg1<4>(f, log(k_min), log(k_max), cfg.global_precision,
+  WthetaIntegrand f{&P, &K, theta[blockIdx.x], 1.0 / (D_z * D_z), log(theta[blockIdx.x])};
+  const double v = romberg1<kWthetaNW>(f, log(k_min), log(k_max), cfg.global_precision,
                                cfg.corr_precision, cfg.divmax, red);
   if (threadIdx.x == 0) out[blockIdx.x] = v;
 }
@@ -697,7 +705,7 @@ __global__ __launch_bounds__(256) void k_wtheta_mixed(chomp_config cfg, TabLayou
   const KernelView K{kpp, L.NKT, pd->ln_kt_min, pd->ln_kt_max};
   double v;
   if (MODE == CHOMP_PREC_F32_TABLES) {
-    WthetaIntegrand f{&P, &K, theta[blockIdx.x], 1.0 / (D_z * D_z)};
+    WthetaIntegrand f{&P, &K, theta[blockIdx.x], 1.0 / (D_z * D_z), log(theta[blockIdx.x])};
     v = romberg1<4>(f, log(k_min), log(k_max), cfg.global_precision, cfg.corr_precision,
                     cfg.divmax, red);
   } else {
@@ -723,7 +731,7 @@ struct Xi3dIntegrand {
   double r;
   __device__ __forceinline__ double operator()(double ln_k) const {
     const double k = exp(ln_k);
-    return k * k / (2.0 * kPi) * (*P)(k) * bessel_j<0>(k * r, *B);
+    return k * k / (2.0 * kPi) * P->at_ln(ln_k, k) * bessel_j<0>(k * r, *B);
   }
 };
 
