@@ -148,9 +148,11 @@ struct PowerEval {
   // both ln k and k: no logarithm is retaken, the three splines share one interval
   // lookup, and the linear spectrum uses the two-division arrangement of Stage E
   // (power_shape).  Agrees with operator() to rounding.
+  // HF: compile-time copy of `halofit`, so that each instance carries one formula only.
+  template <bool HF>
   __device__ __forceinline__ double at_ln(double lk, double kv) const {
     const bool in = kv >= k_min && kv <= k_max;
-    if (halofit) {
+    if (HF) {
       const double pmm = halofit_mm_ln(*E, amp2, lk, kv);
       if (w == CHOMP_P_MM) return pmm;
       if (!in) return 0.0;                                // halo.py:649-672 range rule

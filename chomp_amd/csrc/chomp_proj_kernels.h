@@ -488,13 +488,14 @@ __global__ void k_window_eval(ProjLayout L, const ProjDev* __restrict__ pd,
 }
 
 // correlation.py:270-275
+template <bool HF>               // HF: the spectrum is a HaloFit one
 struct WthetaIntegrand {
   const PowerEval* P;
   const KernelView* K;
   double theta, inv_D2, ln_theta;
   __device__ __forceinline__ double operator()(double ln_k) const {
     const double k = exp(ln_k);
-    return k * k / (2.0 * kPi) * P->at_ln(ln_k, k) * inv_D2 * (*K)(ln_k + ln_theta);
+    return k * k / (2.0 * kPi) * P->template at_ln<HF>(ln_k, k) * inv_D2 * (*K)(ln_k + ln_theta);
   }
 };
 
@@ -502,6 +503,7 @@ struct WthetaIntegrand {
 // theta run to 2^18..2^20 nodes (the kernel oscillates in ln k theta) and set the launch's
 // duration, hence the wide group.
 constexpr int kWthetaNW = 16;
+template <bool HF>
 __global__ __launch_bounds__(64 * kWthetaNW) void k_wtheta(chomp_config cfg, TabLayout HL, ProjLayout L,
                                                 const Epoch* __restrict__ epochs, int e,
                                                 const double* __restrict__ htab, int which,
@@ -522,7 +524,7 @@ __global__ __launch_bounds__(64 * kWthetaNW) void k_wtheta(chomp_config cfg, Tab
   __syncthreads();
   P.finish();
   const KernelView K{kpp, L.NKT, pd->ln_kt_min, pd->ln_kt_max};
-  WthetaIntegrand f{&P, &K, theta[blockIdx.x], 1.0 / (D_z * D_z), log(theta[blockIdx.x])};
+  WthetaIntegrand<HF> f{&P, &K, theta[blockIdx.x], 1.0 / (D_z * D_z), log(theta[blockIdx.x])};
   const double v = romberg1<kWthetaNW>(f, log(k_min), log(k_max), cfg.global_precision,
                                cfg.corr_precision, cfg.divmax, red);
   if (threadIdx.x == 0) out[blockIdx.x] = v;
@@ -705,9 +707,15 @@ __global__ __launch_bounds__(256) void k_wtheta_mixed(chomp_config cfg, TabLayou
   const KernelView K{kpp, L.NKT, pd->ln_kt_min, pd->ln_kt_max};
   double v;
   if (MODE == CHOMP_PREC_F32_TABLES) {
-    WthetaIntegrand f{&P, &K, theta[blockIdx.x], 1.0 / (D_z * D_z), log(theta[blockIdx.x])};
-    v = romberg1<4>(f, log(k_min), log(k_max), cfg.global_precision, cfg.corr_precision,
-                    cfg.divmax, red);
+    if (P.halofit) {
+      WthetaIntegrand<true> f{&P, &K, theta[blockIdx.x], 1.0 / (D_z * D_z), log(theta[blockIdx.x])};
+      v = romberg1<4>(f, log(k_min), log(k_max), cfg.global_precision, cfg.corr_precision,
+                      cfg.divmax, red);
+    } else {
+      WthetaIntegrand<false> f{&P, &K, theta[blockIdx.x], 1.0 / (D_z * D_z), log(theta[blockIdx.x])};
+      v = romberg1<4>(f, log(k_min), log(k_max), cfg.global_precision, cfg.corr_precision,
+                      cfg.divmax, red);
+    }
   } else {
     f32::Eval f;
     f.init(&P, &K, theta[blockIdx.x], 1.0 / (D_z * D_z));
@@ -731,7 +739,8 @@ struct Xi3dIntegrand {
   double r;
   __device__ __forceinline__ double operator()(double ln_k) const {
     const double k = exp(ln_k);
-    return k * k / (2.0 * kPi) * P->at_ln(ln_k, k) * bessel_j<0>(k * r, *B);
+    const double p = P->halofit ? P->template at_ln<true>(ln_k, k) : P->template at_ln<false>(ln_k, k);
+    return k * k / (2.0 * kPi) * p * bessel_j<0>(k * r, *B);
   }
 };
 
