@@ -429,9 +429,16 @@ int chomp_halo_setup(chomp_ctx* ctx, const chomp_halo_par* profile,
     // when the list is long, cheap to launch when it is empty
     unsigned gd = (unsigned)(L.NK * n * ng);
     if (gd > 2048) gd = 2048;
-    hipLaunchKernelGGL(k_halo_knots_deep, dim3(gd), dim3(256), sh, ctx->stream, ctx->cfg, L,
-                       ctx->d_epochs, ctx->d_tab, ctx->d_profile, ctx->d_hod, ctx->d_sici,
-                       groups[0], groups[1], groups[2], kmask, (int)n, ctx->d_pending);
+    if (n * ng <= 4) {             // few epochs: wide groups, the deep knots set the duration
+      const size_t shw = (size_t)(L.NM + 8 * (L.NM - 1) + romberg_scratch<8, 2>()) * sizeof(double);
+      hipLaunchKernelGGL(k_halo_knots_deep<8>, dim3(gd), dim3(512), shw, ctx->stream, ctx->cfg,
+                         L, ctx->d_epochs, ctx->d_tab, ctx->d_profile, ctx->d_hod, ctx->d_sici,
+                         groups[0], groups[1], groups[2], kmask, (int)n, ctx->d_pending);
+    } else {
+      hipLaunchKernelGGL(k_halo_knots_deep<4>, dim3(gd), dim3(256), sh, ctx->stream, ctx->cfg, L,
+                         ctx->d_epochs, ctx->d_tab, ctx->d_profile, ctx->d_hod, ctx->d_sici,
+                         groups[0], groups[1], groups[2], kmask, (int)n, ctx->d_pending);
+    }
   }
   const size_t sh2 = (size_t)(51 * L.NK) * sizeof(double);
   hipLaunchKernelGGL(k_halo_finalize, dim3((unsigned)n), dim3(384), sh2, ctx->stream, ctx->cfg,

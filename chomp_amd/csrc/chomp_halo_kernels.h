@@ -316,7 +316,11 @@ __global__ __launch_bounds__(256) void k_halo_knots(
 // draw items from the list until it is empty (an empty list costs one load per block).
 // k_halo_finalize clears the list.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_halo_knots_deep(
+// NW wavefronts per integral: 4 when the list can be long (a batch of epochs keeps the chip
+// busy with one block per knot), 8 for a single epoch (at most 150 knots: the deep
+// integrals set the duration; 16 would cap the registers at 128 and spill).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_halo_knots_deep(
     chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs,
     double* __restrict__ tab, const chomp_halo_par* __restrict__ profile,
     const HodDev* __restrict__ hod, const SiCiTab* __restrict__ sici_g, int g0, int g1,
@@ -353,19 +357,19 @@ __global__ __launch_bounds__(256) void k_halo_knots_deep(
   int la = 0, lb = 0;
   if (group == 0) {
     IntegrandMM f{c};
-    const RombergOut<2> r = romberg_group<4, 2>(f, group_lower(E, 0), ln_nu_max,
+    const RombergOut<2> r = romberg_group<NW, 2>(f, group_lower(E, 0), ln_nu_max,
                                                 cfg.global_precision, cfg.halo_precision,
                                                 cfg.divmax, red);
     va = r.value[0]; vb = r.value[1]; la = r.level[0]; lb = r.level[1];
   } else if (group == 1) {
     IntegrandGM f{c, pa};
-    const RombergOut<2> r = romberg_group<4, 2>(f, group_lower(E, 1), ln_nu_max,
+    const RombergOut<2> r = romberg_group<NW, 2>(f, group_lower(E, 1), ln_nu_max,
                                                 cfg.global_precision, cfg.halo_precision,
                                                 cfg.divmax, red);
     va = r.value[0]; vb = r.value[1]; la = r.level[0]; lb = r.level[1];
   } else {
     IntegrandGG f{c};
-    const RombergOut<1> r = romberg_group<4, 1>(f, group_lower(E, 2), ln_nu_max,
+    const RombergOut<1> r = romberg_group<NW, 1>(f, group_lower(E, 2), ln_nu_max,
                                                 cfg.global_precision, cfg.halo_precision,
                                                 cfg.divmax, red);
     vb = r.value[0]; lb = r.level[0];
