@@ -521,6 +521,7 @@ int chomp_power_range(chomp_ctx* ctx, int which, size_t epoch0, size_t n, const 
     for (size_t i = 1; i < n; ++i) one_cosmology &= ctx->slot[epoch0 + i] == ctx->slot[epoch0];
     const int w = which & 15;
     size_t stream_min = (size_t)1 << 22;           // samples; below this the launches dominate
+    // (test hook: tests/test_gpu_properties.py forces either launch shape on small grids)
     if (const char* ev = getenv("CHOMP_E_STREAM_MIN")) stream_min = (size_t)atoll(ev);
     if (one_cosmology && w != CHOMP_P_LIN && nk % 2 == 0 && nk * n >= stream_min) {
       const unsigned gx8 = (gx + 7) / 8 * 8;
@@ -532,6 +533,7 @@ int chomp_power_range(chomp_ctx* ctx, int which, size_t epoch0, size_t n, const 
                          ctx->d_epochs, (int)epoch0, w, dk, nk, ctx->d_ktab, ctx->d_winfo,
                          ctx->d_slow, parity);
       int per = n % 2 == 0 ? 2 : 1;
+      // (tuning hook: rows per block of the streaming kernel; 2 measured best on MI355X)
       if (const char* ev = getenv("CHOMP_E_PER")) { int v = atoi(ev); if ((v == 1 || v == 2 || v == 4) && n % v == 0) per = v; }
       const unsigned gy = (unsigned)(n / per);
 #define CHOMP_STREAM(P)                                                                   \
