@@ -69,3 +69,39 @@ def test_theta_bins_match_oracle():
         except AttributeError:
             pass            # stops at the kernel access, after theta_array is built
         assert numpy.allclose(c.theta_array, o.theta_bins(*args), rtol=1e-15)
+
+
+def test_simulation_design_host_logic():
+    """simulation_design.py:17-114: Latin-hypercube sampling and the design frame (no GPU)."""
+    from chomp_amd import halo, simulation_design as sd
+    numpy.random.seed(3)
+    P = sd.random_lhs(16, 3)
+    assert P.shape == (16, 3) and numpy.all((P >= 0) & (P < 1))
+    for j in range(3):                      # one point per stratum in every dimension
+        assert sorted(numpy.floor(P[:, j] * 16).astype(int).tolist()) == list(range(16))
+    params = {"omega_m0": [0.27, 0.2, 0.4], "log_M_min": [12.1, 11.5, 12.8], "c0": [9, 7, 11]}
+    des = sd.SimulationDesign(halo.Halo(0.0), "power_gm", params, n_design=5,
+                              independent_var=numpy.logspace(-2, 1, 4))
+    assert des._param_types == ["cosmo_dict", "hod_dict", "halo_dict"]
+    assert des._vary_cosmology and des._vary_hod and des._vary_halo
+    assert not des._batched()               # halo parameters vary: point-by-point loop
+    des._init_design_points()
+    assert des.points.shape == (5, 3)
+    for key, (_, lo, hi) in params.items():
+        assert numpy.all((des.points[key] >= lo) & (des.points[key] <= hi))
+    des2 = sd.SimulationDesign(halo.Halo(0.0), "power_gm", {"sigma_8": [0.8, 0.7, 0.9]},
+                               n_design=4, independent_var=numpy.logspace(-2, 1, 4))
+    assert des2._batched()
+
+
+def test_correlation3d_host_logic():
+    """correlation.py:414-456: r grid, extrapolation switch, power-spectrum fallback."""
+    from chomp_amd import correlation, halo
+    c3 = correlation.Correlation3d(0.1, 50.0, powSpec="power_mm")
+    assert c3.r_array.size == 50 and abs(c3.r_array[0] - 0.1) < 1e-15
+    assert not c3.halo.get_extrapolation()
+    c3w = correlation.Correlation3d(0.1, 50.0, powSpec="power_mm", k_min=1e-4, k_max=1e3)
+    assert c3w.halo.get_extrapolation() and c3w._k_lim == (1e-4, 1e3)
+    one = correlation.Correlation3d(2.0, 2.0)
+    assert one.r_array.tolist() == [2.0] and one._power_name == "linear_power"
+    assert isinstance(halo.HaloExclusion(0.2), halo.Halo)
