@@ -148,6 +148,48 @@ def test_mass_limit_search_matches_the_walk():
     assert n_checked >= 18
 
 
+def test_abi_error_codes_and_call_order():
+    """The C ABI reports misuse instead of computing garbage: stages called before their
+    prerequisites (CHOMP_ERR_STATE), bad arguments (CHOMP_ERR_ARG -> ValueError), features
+    outside the scope (CHOMP_ERR_SCOPE), each with a message from chomp_last_error."""
+    from chomp_amd import _lib, cosmology, defaults
+    ctx = cosmology._context()
+    k = numpy.logspace(-2, 1, 8)
+    with pytest.raises(_lib.ChompError, match="epochs_set"):
+        ctx.power(_lib.P_MM, k, 0, 1)
+    ctx.epochs_set(defaults.default_cosmo_dict, [0.2])
+    with pytest.raises(_lib.ChompError, match="mass_setup"):
+        ctx.halo_setup(defaults.default_halo_dict, __import__("chomp_amd").hod.HODZheng(), _lib.FAM_MM)
+    ctx.mass_setup(defaults.default_halo_dict, _lib.MF_ST)
+    with pytest.raises(_lib.ChompError, match="not built"):
+        ctx.power(_lib.P_MM, k, 0, 1)                       # knot tables missing
+    assert ctx.power(_lib.P_LIN, k, 0, 1).shape == (1, 8)   # needs no tables
+    from chomp_amd import hod
+    ctx.halo_setup(defaults.default_halo_dict, hod.HODZheng(), _lib.FAM_MM)
+    assert numpy.all(ctx.power(_lib.P_MM, k, 0, 1) > 0)
+    with pytest.raises(_lib.ChompError, match="not built"):
+        ctx.power(_lib.P_GG, k, 0, 1)
+    with pytest.raises(ValueError):
+        ctx.power(7, k, 0, 1)                               # unknown spectrum
+    with pytest.raises(ValueError):
+        ctx.power(_lib.P_MM, k, 0, 2)                       # epoch range
+    with pytest.raises(_lib.ChompError, match="halofit_setup"):
+        ctx.power(_lib.P_MM | _lib.P_HALOFIT, k, 0, 1)
+    with pytest.raises(_lib.ChompError, match="kernel_setup"):
+        ctx.wtheta(_lib.P_MM, 0, 1e-3, 1e2, 1.0, numpy.array([1e-3]))
+    with pytest.raises(ValueError):
+        ctx.xi3d(_lib.P_MM, 0, 1.0, 0.5, numpy.array([1.0]))    # k_max < k_min
+    with pytest.raises(_lib.ChompScopeError):
+        ctx.epochs_set(dict(defaults.default_cosmo_dict, w0=-0.9), [0.2])
+    with pytest.raises(_lib.ChompScopeError):
+        ctx.halo_setup(dict(defaults.default_halo_dict, alpha=-1.5), hod.HODZheng(), _lib.FAM_MM)
+    # the context stays usable after every one of them
+    ctx.epochs_set(defaults.default_cosmo_dict, [0.2])
+    ctx.mass_setup(defaults.default_halo_dict, _lib.MF_ST)
+    ctx.halo_setup(defaults.default_halo_dict, hod.HODZheng(), _lib.FAM_MM)
+    assert numpy.all(numpy.isfinite(ctx.power(_lib.P_MM, k, 0, 1)))
+
+
 def test_range_branches_and_bad_inputs():
     """halo.py:314-320 semantics for every kind of k the reference accepts."""
     from chomp_amd import halo

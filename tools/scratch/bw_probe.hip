@@ -59,6 +59,18 @@ template <int MODE> __global__ void k_tab(const double* __restrict__ tbl, double
     st<MODE>(out + (size_t)e * nk + i, d2{fma(a.x, c, a.y), fma(b.x, c, b.y)});
   }
 }
+
+// as k_tab, with NF dependent fp64 FMAs per sample (the arithmetic density of Stage E)
+template <int NF> __global__ void k_tab_fma(const double* __restrict__ tbl, double* out, size_t nk, int per) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+  const d2 a = *(const d2*)(tbl + 2 * i), b = *(const d2*)(tbl + 2 * i + 2);
+  for (int e = blockIdx.y * per; e < (int)(blockIdx.y + 1) * per; ++e) {
+    double x = (double)e + a.x, y = (double)e + b.x;
+#pragma unroll
+    for (int q = 0; q < NF; ++q) { x = fma(x, a.y + 0.5, 1e-3); y = fma(y, b.y + 0.5, 1e-3); }
+    st<2>(out + (size_t)e * nk + i, d2{x, y});
+  }
+}
 __global__ void k_copy(const double* __restrict__ in, double* __restrict__ out, size_t n2) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -133,6 +145,23 @@ int main() {
       }
       hipDeviceSynchronize();
       printf("sustained tab sc1 per=2, us per launch in batches of 10:");
+      for (int b = 0; b < 30; ++b) { float ms; hipEventElapsedTime(&ms, ev[b], ev[b + 1]); printf(" %.0f", ms * 100.0f); }
+      printf("\n");
+    }
+
+    {   // sustained, with Stage E's arithmetic density
+      const unsigned gx = (unsigned)(nk / 2 / 256);
+      hipEvent_t ev[31];
+      for (int i = 0; i < 31; ++i) hipEventCreate(&ev[i]);
+      hipDeviceSynchronize();
+      hipEventRecord(ev[0], 0);
+      for (int b = 0; b < 30; ++b) {
+        for (int r = 0; r < 10; ++r)
+          hipLaunchKernelGGL(k_tab_fma<14>, dim3(gx, nz / 2), dim3(256), 0, 0, tbl, out, nk, 2);
+        hipEventRecord(ev[b + 1], 0);
+      }
+      hipDeviceSynchronize();
+      printf("sustained tab sc1 per=2 + 14 FMA/sample, us per launch in batches of 10:");
       for (int b = 0; b < 30; ++b) { float ms; hipEventElapsedTime(&ms, ev[b], ev[b + 1]); printf(" %.0f", ms * 100.0f); }
       printf("\n");
     }
