@@ -205,7 +205,7 @@ def lib():
         L.chomp_cell.argtypes = [vp, i, sz, d, vp, sz, vp, i]
         L.chomp_set_precision.argtypes = [vp, i]
         L.chomp_xi3d.argtypes = [vp, i, sz, d, d, vp, sz, vp, i]
-        L.chomp_spline_eval.argtypes = [vp, c_double_p, c_double_p, sz, c_double_p, sz,
+        L.chomp_spline_eval.argtypes = [vp, c_double_p, c_double_p, sz, c_double_p, sz, i,
                                         c_double_p]
         for name in EXPORTS:
             if name not in ("chomp_default_config", "chomp_ctx_destroy",
@@ -498,8 +498,9 @@ class Context(object):
     def xi3d(self, which, epoch, k_min, k_max, r):
         return self._map1(self._L.chomp_xi3d, r, int(which), epoch, float(k_min), float(k_max))
 
-    def spline_eval(self, xk, yk, x):
-        """Not-a-knot cubic spline through (xk, yk) at x (FITPACK k=3, s=0)."""
+    def spline_eval(self, xk, yk, x, deriv=0):
+        """Not-a-knot cubic spline through (xk, yk) at x (FITPACK k=3, s=0); deriv=1: its
+        first derivative."""
         xk = numpy.ascontiguousarray(xk, dtype=numpy.float64)
         yk = numpy.ascontiguousarray(yk, dtype=numpy.float64)
         xa = numpy.ascontiguousarray(numpy.atleast_1d(x), dtype=numpy.float64).ravel()
@@ -507,7 +508,8 @@ class Context(object):
         if xa.size:
             self._check(self._L.chomp_spline_eval(
                 self._h, xk.ctypes.data_as(c_double_p), yk.ctypes.data_as(c_double_p), xk.size,
-                xa.ctypes.data_as(c_double_p), xa.size, out.ctypes.data_as(c_double_p)))
+                xa.ctypes.data_as(c_double_p), xa.size, int(deriv),
+                out.ctypes.data_as(c_double_p)))
         return out
 
     def set_precision(self, mode):

@@ -152,6 +152,47 @@ class SingleEpoch(object):
         sqrt_nu = self.delta_c() / self.sigma_m(mass)
         return sqrt_nu * sqrt_nu
 
+    def growth_factor_eval(self, a):
+        """cosmology.py:305-326: always the Carroll et al. approximation (the return of
+        _growth_approx, :215-231, with its Omega_m * (4/7) term)."""
+        a = numpy.asarray(a, dtype=numpy.float64)
+        om = self._omega_m0 / (a * a * a)
+        denom = self._omega_l0 + om
+        Omega_m, Omega_L = om / denom, self._omega_l0 / denom
+        coeff = 5.0 * Omega_m / (2.0 / a)
+        return coeff / (Omega_m * (4.0 / 7.0) - Omega_L +
+                        (1.0 + 0.5 * Omega_m) * (1.0 + Omega_L / 70.0))
+
+    def transfer_function(self, k):
+        """cosmology.py:540-572 (the no-wiggle E&H fit as the reference evaluates it), from
+        the device's Delta^2(k) = delta_H^2 (k/H0)^(3+n) T^2 / h * D^2 sigma_norm^2."""
+        ka = numpy.asarray(k, dtype=numpy.float64)
+        d2 = self.delta_k(ka)
+        amp = (self.delta_H ** 2 * numpy.power(ka / self.H0, 3.0 + self._n) / self._h *
+               self._growth ** 2 * self._sigma_norm ** 2)
+        return numpy.sqrt(d2 / amp)
+
+    def write(self, output_power_file_name=None):
+        """cosmology.py:700-728."""
+        print("z = %1.4f" % self._redshift)
+        print("Comoving distance = %1.4f" % self._chi)
+        print("Growth factor = %1.4f" % self._growth)
+        print("Omega_m(z) = %1.4f" % self.omega_m())
+        print("Omega_l(z) = %1.4f" % self.omega_l())
+        print("DE w(z)    = %1.4f" % self.w(self._redshift))
+        print("Delta_V(z) = %1.4f" % self.delta_v())
+        print("delta_c(z) = %1.4f" % self.delta_c())
+        print("sigma_8(z) = %1.4f" % self.sigma_r(8.0))
+        if output_power_file_name is not None:
+            dln_k = (numpy.log(self._k_max) - numpy.log(self._k_min)) / 200
+            ln_k = numpy.arange(numpy.log(self._k_min) - dln_k,
+                                numpy.log(self._k_max) + dln_k + dln_k, dln_k)
+            k = numpy.exp(ln_k)
+            with open(output_power_file_name, "w") as f:
+                f.write("#ttype1 = k [Mpc/h]\n#ttype2 = P(k) [(Mpc/h)^3]\n")
+                for row in zip(k, self.linear_power(k)):
+                    f.write("%1.10f %1.10f\n" % row)
+
 
 class MultiEpoch(object):
     """cosmology.MultiEpoch (cosmology.py:731-1164): chi(z), z(chi), D(z) on a
@@ -245,3 +286,77 @@ class MultiEpoch(object):
         if redshift is not None:
             sigma = sigma * self.growth_factor(redshift)
         return sigma
+
+    # -- cosmology.py:977-1110: redshift-argument versions of the SingleEpoch scalars ----
+    def _flags(self):
+        p = defaults.default_precision["cosmo_precision"]
+        tot = self._omega_m0 + self._omega_l0 + self._omega_r0
+        return (tot <= 1.0 + p and tot >= 1.0 - p), tot <= 1.0 - p      # flat, open
+
+    def delta_c(self, redshift=None):
+        flat, open_ = self._flags()
+        delta_c = 0.15 * (12.0 * numpy.pi) ** (2.0 / 3.0)
+        if open_:
+            delta_c *= self.omega_m(redshift) ** 0.0185
+        if flat and self._omega_m0 < 1.0001:
+            delta_c *= self.omega_m(redshift) ** 0.0055
+        if redshift is None:
+            return delta_c
+        return delta_c / self.growth_factor(redshift)
+
+    def delta_v(self, redshift=None):
+        flat, open_ = self._flags()
+        delta_v = 178.0
+        if open_:
+            delta_v /= self.omega_m(redshift) ** 0.7
+        if flat and self._omega_m0 < 1.0001:
+            delta_v /= self.omega_m(redshift) ** 0.55
+        if redshift is None:
+            return delta_v
+        return delta_v / self.growth_factor(redshift)
+
+    def rho_crit(self, redshift=None):
+        if redshift is None:
+            redshift = 0.0
+        return 1.879 / (1.989) * 3.086 ** 3 * 1e10 * self.epoch0.E0(redshift)
+
+    def rho_bar(self, redshift=None):
+        return self.rho_crit(redshift) * self.omega_m(redshift)
+
+    def delta_k(self, k, redshift=None):
+        delta_k = self.epoch0.delta_k(k)
+        if redshift is not None:
+            delta_k = delta_k * self.growth_factor(redshift) ** 2
+        return delta_k
+
+    def sigma_m(self, mass, redshift=None):
+        scale = (3.0 * numpy.asarray(mass, dtype=numpy.float64) /
+                 (4.0 * numpy.pi * self.rho_bar(redshift))) ** (1.0 / 3.0)
+        return self.sigma_r(scale, redshift)
+
+    def nu_r(self, scale, redshift=None):
+        sqrt_nu = self.delta_c(redshift) / self.sigma_r(scale, redshift)
+        return sqrt_nu * sqrt_nu
+
+    def nu_m(self, mass, redshift=None):
+        sqrt_nu = self.delta_c(redshift) / self.sigma_m(mass, redshift)
+        return sqrt_nu * sqrt_nu
+
+    def write(self, output_file_name, output_power_file_name=None):
+        """cosmology.py:1112-1164."""
+        with open(output_file_name, "w") as f:
+            f.write("#ttype1 = z\n#ttype2 = chi [Mpc/h]\n#ttype3 = growth\n"
+                    "#ttype4 = omega_m\n#ttype5 = omega_l\n#ttype6 = delta_c\n"
+                    "#ttype7 = delta_v\n#ttype8 = sigma_8\n")
+            for z, chi, growth in zip(self._z_array, self._chi_array, self._growth_array):
+                if z <= self.z_max:
+                    f.write("%1.10f %1.10f %1.10f %1.10f %1.10f %1.10f %1.10f %1.10f\n" % (
+                        z, chi, growth, self.omega_m(z), self.omega_l(z), self.delta_c(z),
+                        self.delta_v(z), self.sigma_r(8.0, z)))
+        if output_power_file_name is not None:
+            ln_k_array = numpy.linspace(numpy.log(self._k_min), numpy.log(self._k_max), 100)
+            k = numpy.exp(ln_k_array)
+            with open(output_power_file_name, "w") as f:
+                f.write("#ttype1 = k [Mpc/h]\n#ttype2 = linear_power [Mpc/h]^3\n")
+                for row in zip(k, self.linear_power(k)):
+                    f.write("%1.10f %1.10f\n" % row)

@@ -774,11 +774,25 @@ __global__ __launch_bounds__(256) void k_xi3d(chomp_config cfg, TabLayout HL,
 // doubles, w: 2 nk doubles of scratch.
 __global__ void k_spline_eval(const double* __restrict__ xk, const double* __restrict__ yk, int nk,
                               double* __restrict__ c, double* __restrict__ w,
-                              const double* __restrict__ x, int n, double* __restrict__ out) {
+                              const double* __restrict__ x, int n, int deriv,
+                              double* __restrict__ out) {
   if (threadIdx.x == 0) spline_build(xk, yk, nk, c, w);
   __threadfence_block();
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = spline_eval(xk, c, nk, x[i]);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    if (deriv == 0) {
+      out[i] = spline_eval(xk, c, nk, x[i]);
+    } else {                       // derivative of the piece that holds x
+      int lo = 0, hi = nk - 2;
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (x[i] >= xk[mid]) lo = mid; else hi = mid - 1;
+      }
+      const double* q = c + 4 * lo;
+      const double d = x[i] - xk[lo];
+      out[i] = fma(fma(3.0 * q[3], d, 2.0 * q[2]), d, q[1]);
+    }
+  }
 }
 
 // correlation.py:387-392

@@ -18,6 +18,29 @@ class HOD(object):
         self.second_moment_zero = -1
         self._safe_norm = -1
 
+    def first_moment(self, mass, z=None):
+        """hod.py:40-52 (base class: one galaxy per halo)."""
+        return 1.0
+
+    def second_moment(self, mass, z=None):
+        """hod.py:54-66."""
+        return 1.0
+
+    def nth_moment(self, mass, n=3, z=None):
+        """hod.py:68-92: <N(N-1)...(N-n+1)> from the first two moments."""
+        if n == 1:
+            return self.first_moment(mass, z)
+        if n == 2:
+            return self.second_moment(mass, z)
+        first_mom = self.first_moment(mass, z)
+        exp_nth = first_mom ** n
+        with numpy.errstate(all="ignore"):
+            alpha_m2 = numpy.where(first_mom != 0.0,
+                                   self.second_moment(mass, z) / first_mom ** 2, 0.0)
+        for j in range(n):
+            exp_nth = exp_nth * (j * alpha_m2 - j + 1)
+        return exp_nth
+
     def get_hod(self):
         return self.hod_dict
 
@@ -26,6 +49,20 @@ class HOD(object):
 
     def set_halo(self, halo_dict):
         pass
+
+    def write(self, output_file_name):
+        """hod.py:112-129 (the reference passes (mass, None, 3) to nth_moment, i.e. n = None:
+        written here as the third moment it means)."""
+        mass_max, mass_min = 1.0e16, 1.0e9
+        dln_mass = (numpy.log(mass_max) - numpy.log(mass_min)) / 200
+        ln_mass_array = numpy.arange(numpy.log(mass_min) - dln_mass,
+                                     numpy.log(mass_max) + dln_mass + dln_mass, dln_mass)
+        with open(output_file_name, "w") as f:
+            for ln_mass in ln_mass_array:
+                mass = numpy.exp(ln_mass)
+                f.write("%1.10f %1.10f %1.10f %1.10f\n" % (
+                    mass, self.first_moment(mass), self.second_moment(mass),
+                    self.nth_moment(mass, 3)))
 
 
 def _erfinv(y):

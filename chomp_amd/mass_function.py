@@ -114,6 +114,26 @@ class MassFunction(object):
     def mass(self, nu):
         return numpy.exp(self.ln_mass(nu))
 
+    def dndm(self, mass):
+        """mass_function.py:268-287: 0.5 rho_bar / M^2 f(nu(M)) dnu/dlnM, the derivative
+        taken from the nu(ln M) spline."""
+        m = numpy.atleast_1d(numpy.asarray(mass, dtype=numpy.float64))
+        dev = self._dev()
+        dnu = dev.spline_eval(self._ln_mass_array, self._nu_array, numpy.log(m), deriv=1)
+        out = 0.5 * (self.cosmo.rho_bar() / (m * m) * self.f_m(m) * dnu)
+        return out if numpy.ndim(mass) else float(out[0])
+
+    def write(self, output_file_name):
+        """mass_function.py:289-302."""
+        print("M* = 10^%1.4f M_sun" % numpy.log10(self.m_star))
+        nu = self._nu_array
+        cols = (numpy.exp(self._ln_mass_array), nu, self.f_nu(nu), self.bias_nu(nu))
+        with open(output_file_name, "w") as f:
+            f.write("#ttype1 = mass [M_solar/h]\n#ttype2 = nu\n"
+                    "#ttype3 = f(nu)\n#ttype4 = bias(nu)\n")
+            for row in zip(*cols):
+                f.write("%1.10f %1.10f %1.10f %1.10f\n" % row)
+
 
 class TinkerMassFunction(MassFunction):
     """Tinker et al. 2010 (mass_function.py:436-564)."""

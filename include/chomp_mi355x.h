@@ -332,9 +332,11 @@ int chomp_xi3d(chomp_ctx* ctx, int which, size_t epoch, double k_min, double k_m
 /* scipy InterpolatedUnivariateSpline(xk, yk)(x) (k = 3, not-a-knot), host buffers: the
  * 50-knot xi(r) spline of Correlation3d.compute_correlation / correlation
  * (correlation.py:459-468, 501-510).  x outside [xk[0], xk[nk-1]] extrapolates the end
- * pieces, as FITPACK does. */
+ * pieces, as FITPACK does.  deriv = 0: values; 1: first derivative (the
+ * InterpolatedUnivariateSpline.derivatives(x)[1] of MassFunction.dndm,
+ * mass_function.py:268-287). */
 int chomp_spline_eval(chomp_ctx* ctx, const double* xk, const double* yk, size_t nk,
-                      const double* x, size_t n, double* out);
+                      const double* x, size_t n, int deriv, double* out);
 
 /* Arithmetic of the w(theta) integral (BASELINE.json configs[4]: "mixed fp32/fp64 with
  * tolerance sweep").  The reference computes everything in fp64; F64 is the

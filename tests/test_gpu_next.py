@@ -84,6 +84,10 @@ def test_spline_eval_matches_fitpack():
     x = numpy.concatenate([rng.uniform(xk[0], xk[-1], 500), xk, [xk[0] - 0.2, xk[-1] + 0.3]])
     ref = InterpolatedUnivariateSpline(xk, yk)(x)
     assert numpy.max(numpy.abs(ctx.spline_eval(xk, yk, x) - ref)) < 1e-12
+    sp = InterpolatedUnivariateSpline(xk, yk)
+    inside = x[(x > xk[0]) & (x < xk[-1])]
+    dref = numpy.array([sp.derivatives(v)[1] for v in inside])
+    assert numpy.max(numpy.abs(ctx.spline_eval(xk, yk, inside, deriv=1) - dref)) < 1e-11
     with pytest.raises(ValueError):
         ctx.spline_eval(xk[::-1].copy(), yk, x)
 
@@ -158,3 +162,42 @@ def test_simulation_design_batched_equals_loop():
     t = o.halo_table(e, o.mass_table(e), o.zheng(hd), families=("gm",))
     assert rel_err(batched.values[:, i], o.halo_power(t, "gm", k)) < RTOL
     des.write("/dev/null")
+
+
+def test_convenience_methods_vs_oracle(tmp_path):
+    """Methods of the reference's classes that sit beside the hot path: MassFunction.dndm /
+    write (mass_function.py:268-302), MultiEpoch's redshift-argument scalars
+    (cosmology.py:977-1110), SingleEpoch.growth_factor_eval / transfer_function."""
+    from chomp_amd import cosmology, mass_function
+    from oracle import chomp_oracle as o
+    e = o.epoch(None, 0.4)
+    m = o.mass_table(e)
+    mf = mass_function.MassFunction(0.4)
+    mass = numpy.logspace(10, 15, 12)
+    sp = m.nu_spline
+    ref = numpy.array([0.5 * o.rho_bar(e) / (x * x) * o.f_nu(m, o.nu_of_mass(m, x)) *
+                       sp.derivatives(numpy.log(x))[1] for x in mass])
+    assert rel_err(mf.dndm(mass), ref) < 1e-6
+    mf.write(str(tmp_path / "mf.txt"))
+    rows = numpy.loadtxt(str(tmp_path / "mf.txt"))
+    assert rows.shape == (50, 4) and rel_err(rows[:, 1], m.nu_arr) < 1e-6
+    se = cosmology.SingleEpoch(0.4)
+    k = numpy.logspace(-3, 2, 20)
+    assert rel_err(se.transfer_function(k), o.eh_transfer(e, k)) < 1e-12
+    a = numpy.array([0.3, 0.7, 1.0])
+    assert rel_err(se.growth_factor_eval(a), o.growth_approx(e, a)) < 1e-14
+    se.write(str(tmp_path / "pk.txt"))
+    pk = numpy.loadtxt(str(tmp_path / "pk.txt"))
+    assert pk.shape[1] == 2 and pk.shape[0] >= 202
+    me = cosmology.MultiEpoch(0.0, 2.0)
+    z = 0.4
+    D = float(me.growth_factor(z))
+    assert abs(me.delta_c(z) * D / o.delta_c(e) - 1) < 1e-12
+    assert abs(me.delta_v(z) * D / (178.0 / o.omega_m(e) ** 0.55) - 1) < 1e-12
+    assert abs(me.rho_bar(z) / o.rho_bar(e) - 1) < 1e-12
+    e0 = o.epoch(None, 0.0)
+    assert rel_err(me.delta_k(k, z), o.delta_k(e0, k) * D * D) < 1e-12
+    assert abs(me.nu_r(8.0, z) / (me.delta_c(z) / (o.sigma_r(e0, 8.0) * D)) ** 2 - 1) < 1e-7
+    me.write(str(tmp_path / "me.txt"), str(tmp_path / "me_pk.txt"))
+    assert numpy.loadtxt(str(tmp_path / "me.txt")).shape == (50, 8)
+    assert numpy.loadtxt(str(tmp_path / "me_pk.txt")).shape == (100, 2)
