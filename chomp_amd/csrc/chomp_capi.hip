@@ -421,7 +421,7 @@ int chomp_halo_setup(chomp_ctx* ctx, const chomp_halo_par* profile,
                      ctx->d_hod, ctx->d_sici, ctx->d_nodes, ctx->d_tab, groups[0], groups[1],
                      groups[2]);
   if (groups[0] != 3)
-  hipLaunchKernelGGL(k_halo_knots, dim3(L.NK, (unsigned)n, ng), dim3(256), 0, ctx->stream,
+  hipLaunchKernelGGL(k_halo_knots, dim3(L.NK, (unsigned)n, ng), dim3(64 * kKnotNW), 0, ctx->stream,
                      ctx->cfg, L, ctx->d_tab, ctx->d_sici, ctx->d_nodes, groups[0], groups[1],
                      groups[2], kmask, ctx->d_pending);
   if (ctx->cfg.divmax > kNodeLevel && groups[0] != 3) {

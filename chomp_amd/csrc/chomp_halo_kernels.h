@@ -268,7 +268,8 @@ constexpr unsigned kMaskExclusion = 1u << 8;   // bit of the kernels' family mas
 // converged by then are marked for k_halo_knots_deep.  A block only stages the Si/Ci
 // tables: everything else it needs is in the (epoch, group) node table.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_halo_knots(
+constexpr int kKnotNW = 2;
+__global__ __launch_bounds__(64 * kKnotNW) void k_halo_knots(
     chomp_config cfg, TabLayout L, double* __restrict__ tab,
     const SiCiTab* __restrict__ sici_g, const double* __restrict__ nodes, int g0, int g1,
     int g2, unsigned mask, int* __restrict__ pending) {
@@ -287,8 +288,8 @@ __global__ __launch_bounds__(256) void k_halo_knots(
   const double ln_k = linspace_at(log(cfg.k_min), log(cfg.k_max), NK, ik);   // halo.py:52-54
   NodeIntegrand f{&S, node, ln_k, (mask & kMaskExclusion) != 0};
   const int dmax = cfg.divmax < kNodeLevel ? cfg.divmax : kNodeLevel;
-  const RombergOut<2> r = romberg_group<4, 2>(f, a, b, cfg.global_precision,
-                                              cfg.halo_precision, dmax, red);
+  const RombergOut<2> r = romberg_group<kKnotNW, 2>(f, a, b, cfg.global_precision,
+                                                    cfg.halo_precision, dmax, red);
   if (threadIdx.x == 0) {
     double* lev = t + L.off_levels;
     const int fa = group_fa(group), fb = group_fb(group);
