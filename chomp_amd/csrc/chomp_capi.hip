@@ -363,7 +363,7 @@ int chomp_mass_setup(chomp_ctx* ctx, const chomp_halo_par* par, int mf_kind) {
   const TabLayout& L = ctx->L;
   int rcu = upload(ctx, ctx->d_mass_par, par, n * sizeof(chomp_halo_par), ctx->sh_mass);
   if (rcu) return rcu;
-  hipLaunchKernelGGL(k_nu_table, dim3(L.NM, (unsigned)n), dim3(256), 0, ctx->stream, ctx->cfg,
+  hipLaunchKernelGGL(k_nu_table, dim3(L.NM, (unsigned)n), dim3(64 * kNuNW), 0, ctx->stream, ctx->cfg,
                      L, ctx->d_epochs, ctx->d_search, ctx->d_snodes, ctx->d_tab);
   const size_t sh = (size_t)(2 * L.NM + 8 * (L.NM - 1) + 18 * L.NM + 32 + romberg_scratch<4, 1>()) *
                     sizeof(double);

@@ -669,9 +669,10 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_init(
 }
 
 // ---------------------------------------------------------------------------
-// k_nu_table: grid (NM, n_epoch), block 256: nu_i = nu_m(exp(ln_mass_i)).
+// k_nu_table: grid (NM, n_epoch), block 64 * kNuNW: nu_i = nu_m(exp(ln_mass_i)).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_nu_table(chomp_config cfg, TabLayout L,
+constexpr int kNuNW = 2;         // wavefronts per sigma(R) integral of k_nu_table
+__global__ __launch_bounds__(64 * kNuNW) void k_nu_table(chomp_config cfg, TabLayout L,
                                                   const Epoch* __restrict__ epochs,
                                                   const double* __restrict__ search,
                                                   const double* __restrict__ snodes,
@@ -684,8 +685,8 @@ __global__ __launch_bounds__(256) void k_nu_table(chomp_config cfg, TabLayout L,
   __syncthreads();
   const double ln_lo = search[(e * 2 + 0) * 2], ln_hi = search[(e * 2 + 1) * 2];
   const double lnm = linspace_at(ln_lo, ln_hi, L.NM, i);
-  const double nu = nu_of_mass_block<4>(E, snodes + (size_t)E.cosmo_slot * kSigmaStride, exp(lnm), cfg,
-                                        cfg.cosmo_precision, red);
+  const double nu = nu_of_mass_block<kNuNW>(E, snodes + (size_t)E.cosmo_slot * kSigmaStride, exp(lnm), cfg,
+                                            cfg.cosmo_precision, red);
   if (threadIdx.x == 0) {
     double* t = tab + (size_t)e * L.stride;
     t[L.off_ln_mass + i] = lnm;
