@@ -671,7 +671,7 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_init(
 // ---------------------------------------------------------------------------
 // k_nu_table: grid (NM, n_epoch), block 64 * kNuNW: nu_i = nu_m(exp(ln_mass_i)).
 // ---------------------------------------------------------------------------
-constexpr int kNuNW = 2;         // wavefronts per sigma(R) integral of k_nu_table
+constexpr int kNuNW = 1;         // wavefronts per sigma(R) integral of k_nu_table
 __global__ __launch_bounds__(64 * kNuNW) void k_nu_table(chomp_config cfg, TabLayout L,
                                                   const Epoch* __restrict__ epochs,
                                                   const double* __restrict__ search,
