@@ -105,7 +105,7 @@ struct PowerEval {
     x0 = log(cfg.k_min);
     dx = (log(cfg.k_max) - x0) / (double)(NK - 1);
     inv_dx = 1.0 / dx;
-    amp2 = Els->amp * Els->sigma_norm * Els->sigma_norm;
+    amp2 = 0.0;                     // set by finish(): *Els may still be being staged
     c_lo = 0.0;
   }
   __device__ __forceinline__ bool needs_tables() const {
@@ -113,6 +113,7 @@ struct PowerEval {
   }
   // after the barrier: k < k_min constant (halo.py:314-317)
   __device__ __forceinline__ void finish() {
+    amp2 = E->amp * E->sigma_norm * E->sigma_norm;
     if (w != CHOMP_P_LIN && !halofit) {
       const double ha = pp_poly(ca, 0, 0.0), hb = pp_poly(cb, 0, 0.0), p0 = pp_poly(cp, 0, 0.0);
       c_lo = ha * hb + p0 / linear_power(*E, k_min);
