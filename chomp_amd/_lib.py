@@ -96,7 +96,7 @@ EXPORTS = [
     "chomp_multi_epoch_setup", "chomp_me_eval",
     "chomp_kernel_setup", "chomp_kernel_info", "chomp_kernel_table",
     "chomp_kernel_eval", "chomp_window_eval", "chomp_wtheta", "chomp_cell",
-    "chomp_set_precision", "chomp_xi3d", "chomp_spline_eval",
+    "chomp_set_precision", "chomp_xi3d", "chomp_spline_eval", "chomp_hod_stats",
 ]
 
 
@@ -204,6 +204,7 @@ def lib():
         L.chomp_wtheta.argtypes = [vp, i, sz, d, d, d, vp, sz, vp, i]
         L.chomp_cell.argtypes = [vp, i, sz, d, vp, sz, vp, i]
         L.chomp_set_precision.argtypes = [vp, i]
+        L.chomp_hod_stats.argtypes = [vp, sz, sz, c_double_p]
         L.chomp_xi3d.argtypes = [vp, i, sz, d, d, vp, sz, vp, i]
         L.chomp_spline_eval.argtypes = [vp, c_double_p, c_double_p, sz, c_double_p, sz, i,
                                         c_double_p]
@@ -494,6 +495,13 @@ class Context(object):
     def wtheta(self, which, epoch, k_min, k_max, D_z, theta):
         return self._map1(self._L.chomp_wtheta, theta, int(which), epoch,
                           float(k_min), float(k_max), float(D_z))
+
+    def hod_stats(self, epoch0=0, n=None):
+        """[n, 3]: effective bias, effective halo mass, satellite fraction."""
+        n = self.n_epoch - epoch0 if n is None else n
+        out = numpy.empty((n, 3))
+        self._check(self._L.chomp_hod_stats(self._h, epoch0, n, out.ctypes.data_as(c_double_p)))
+        return out
 
     def xi3d(self, which, epoch, k_min, k_max, r):
         return self._map1(self._L.chomp_xi3d, r, int(which), epoch, float(k_min), float(k_max))

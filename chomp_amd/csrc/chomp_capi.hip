@@ -449,6 +449,25 @@ int chomp_halo_setup(chomp_ctx* ctx, const chomp_halo_par* profile,
   return CHOMP_OK;
 }
 
+int chomp_hod_stats(chomp_ctx* ctx, size_t epoch0, size_t n, double* out) {
+  if (!ctx || !out || n == 0) return fail(ctx, CHOMP_ERR_ARG, "hod_stats: bad args");
+  if (!ctx->have_halo) return fail(ctx, CHOMP_ERR_STATE, "hod_stats before halo_setup");
+  if (epoch0 + n > ctx->n_epoch) return fail(ctx, CHOMP_ERR_ARG, "hod_stats: epoch range");
+  HIPCHK(hipSetDevice(ctx->device));
+  int rc = ensure(ctx, &ctx->d_stage_out, &ctx->cap_out, 3 * n);
+  if (rc) return rc;
+  const TabLayout& L = ctx->L;
+  const size_t sh = (size_t)(L.NM + 8 * (L.NM - 1) + kKnotScratch) * sizeof(double);
+  hipLaunchKernelGGL(k_hod_stats, dim3(3, (unsigned)n), dim3(256), sh, ctx->stream, ctx->cfg, L,
+                     ctx->d_epochs, (int)epoch0, ctx->d_tab, ctx->d_profile, ctx->d_hod,
+                     ctx->d_sici, ctx->d_stage_out);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, ctx->d_stage_out, 3 * n * sizeof(double), hipMemcpyDeviceToHost,
+                        ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return CHOMP_OK;
+}
+
 static int check_power(chomp_ctx* ctx, int which, size_t epoch0, size_t n) {
   if (!ctx) return CHOMP_ERR_ARG;
   if (!ctx->have_epochs) return fail(ctx, CHOMP_ERR_STATE, "power before epochs_set");

@@ -90,6 +90,21 @@ struct IntegrandNbar {     // halo.py:702-707
   }
 };
 
+struct IntegrandHodStat {  // halo.py:745-750 (bias), 786-790 (m_eff), 833-838 (f_sat)
+  HaloCtx c;
+  int kind;                // 0: nu <N> f b / M, 1: nu <N> f, 2: nu N_sat f / M
+  __device__ __forceinline__ double operator()(double ln_nu) const {
+    const double nu = exp(ln_nu);
+    const double lnm = spline_eval(c.nu_knots, c.lnm_pp, c.NM, nu);
+    const double mass = exp(lnm);
+    double nf, b = 1.0, n1, n2;
+    mf_node(*c.e, nu, ln_nu, kind == 0, &nf, &b);
+    if (kind == 2) return nf * zheng_satellite(*c.e, mass) / mass;
+    zheng_node(*c.e, mass, lnm, &n1, &n2);
+    return kind == 0 ? nf * b * n1 / mass : nf * n1;
+  }
+};
+
 // HOD-derived constants (hod.py:172-186) are computed on the host (erfinv) and
 // passed in; the lower limits of the HOD integrals follow halo.py:935-939,
 // 1002-1006.
@@ -234,6 +249,27 @@ __global__ __launch_bounds__(256) void k_halo_nodes(
   n[4 * kNodeCount] = ln_cp;
   n[5 * kNodeCount] = 1.0 / (ln_cp - con / cp);
   n[6 * kNodeCount] = flag;
+}
+
+// Halo.calculate_bias / calculate_m_eff / calculate_f_sat (halo.py:709-838): grid (3, n),
+// block 256, out[3 e + kind]; needs n_bar (chomp_halo_setup).
+__global__ __launch_bounds__(256) void k_hod_stats(
+    chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs, int epoch0,
+    const double* __restrict__ tab, const chomp_halo_par* __restrict__ profile,
+    const HodDev* __restrict__ hod, const SiCiTab* __restrict__ sici_g,
+    double* __restrict__ out) {
+  extern __shared__ __align__(16) double sm[];
+  __shared__ Epoch E;
+  __shared__ SiCiTab S;
+  const int kind = blockIdx.x, e = epoch0 + blockIdx.y;
+  HaloLds H;
+  H.stage(L, E, S, epochs, e, tab + (size_t)e * L.stride, profile, hod, sici_g, sm);
+  HaloCtx c{&E, &S, H.nu_knots, H.lnm_pp, L.NM, 0.0, false};
+  IntegrandHodStat f{c, kind};
+  const double lo = kind == 2 ? E.ln_nu_lo_second : E.ln_nu_lo_first;
+  const double v = romberg1<4>(f, lo, log(E.nu_max), cfg.global_precision, cfg.halo_precision,
+                               cfg.divmax, H.rest);
+  if (threadIdx.x == 0) out[3 * blockIdx.y + kind] = v / E.n_bar_over_rho_bar;
 }
 
 // out[0] = wA y, out[1] = wB (flag ? y : y^2) from the node table; group 2 uses

@@ -274,6 +274,29 @@ class Halo(object):
         return numpy.where(ok, knots[idx], 0.0)
 
 
+    # -- HOD summary integrals (halo.py:709-838) -----------------------------------
+    def calculate_bias(self):
+        self.bias = float(self._sync(0).hod_stats(0, 1)[0, 0])
+        return self.bias
+
+    def calculate_m_eff(self):
+        self.m_eff = float(self._sync(0).hod_stats(0, 1)[0, 1])
+        return self.m_eff
+
+    def calculate_f_sat(self):
+        """halo.py:792-838.  The reference hands the redshift to
+        satellite_first_moment(mass, z=...) (:836); HODZheng's takes none, so with the shipped
+        Zheng HOD the reference raises TypeError -- as does this -- and the integral is only
+        reachable with an HOD whose satellite_first_moment accepts z."""
+        import inspect
+        fn = getattr(self.local_hod, "satellite_first_moment", None)
+        if fn is None:
+            raise AttributeError("the HOD object has no satellite_first_moment")
+        if "z" not in inspect.signature(fn).parameters:
+            raise TypeError("satellite_first_moment() got an unexpected keyword argument 'z'")
+        self.f_sat = float(self._sync(0).hod_stats(0, 1)[0, 2])
+        return self.f_sat
+
     # -- ASCII writers (halo.py:587-647) -----------------------------------------
     def write(self, output_file_name):
         """halo.py:587-603.  The last knot is exp(ln k_max) = 100.00000000000004 > k_max,

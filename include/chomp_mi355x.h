@@ -324,6 +324,11 @@ int chomp_wtheta(chomp_ctx* ctx, int which, size_t epoch, double k_min,
 int chomp_cell(chomp_ctx* ctx, int which, size_t epoch, double D_z,
                const double* ell, size_t n, double* out, int mem);
 
+/* Halo.calculate_bias / calculate_m_eff / calculate_f_sat (halo.py:709-838) of epochs
+ * [epoch0, epoch0 + n): out[3 i + {0, 1, 2}] = effective bias, effective halo mass,
+ * satellite fraction (host buffer).  Needs chomp_halo_setup (n_bar). */
+int chomp_hod_stats(chomp_ctx* ctx, size_t epoch0, size_t n, double* out);
+
 /* Correlation3d.raw_correlation(r) (correlation.py:470-499): xi(r) = int dlnk k^2/(2 pi)
  * P(k) J0(k r) over [k_min, k_max] -- the cylindrical J0, as the reference has it.  One
  * wavefront-group per r; P is `which` of halo epoch `epoch`. */

@@ -552,6 +552,44 @@ def _n_bar(t):
     t.n_bar = t.n_bar_over_rho_bar * t.rho_bar
 
 
+def hod_stats(t):
+    """Halo.calculate_bias / calculate_m_eff / calculate_f_sat (halo.py:709-838): HOD-weighted
+    integrals over ln nu divided by n_bar / rho_bar.  Returns (bias, m_eff, f_sat)."""
+    m, hod, prec = t.m, t.hod, t.e.prec
+
+    def stat(integrand, zero, norm_inside_only):
+        nu_min = _nu_lo(t, zero)
+        norm = 1.0
+        ok = hod.safe_norm != -1
+        if norm_inside_only:
+            ok = ok and (hod.safe_norm > numpy.exp(m.ln_mass_min) and
+                         hod.safe_norm < numpy.exp(m.ln_mass_max))
+        if ok:
+            inv = integrand(numpy.log(nu_of_mass(m, hod.safe_norm)), 1.0)
+            norm = 1.0 / inv if inv > 1e-16 else 1.0
+        val = _rom(integrand, numpy.log(nu_min), numpy.log(m.nu_max), prec["halo_precision"],
+                   prec, args=(norm,))
+        return val / (norm * t.n_bar_over_rho_bar)
+
+    def bias_i(ln_nu, norm):                                     # :745-750
+        nu = numpy.exp(ln_nu)
+        mass = mass_of_nu(m, nu)
+        return norm * nu * zheng_first(hod, mass) * f_nu(m, nu) * bias_nu(m, nu) / mass
+
+    def m_eff_i(ln_nu, norm):                                    # :786-790
+        nu = numpy.exp(ln_nu)
+        mass = mass_of_nu(m, nu)
+        return norm * nu * zheng_first(hod, mass) * f_nu(m, nu)
+
+    def f_sat_i(ln_nu, norm):                                    # :833-838
+        nu = numpy.exp(ln_nu)
+        mass = mass_of_nu(m, nu)
+        return norm * nu * zheng_satellite(hod, mass) * f_nu(m, nu) / mass
+
+    return (stat(bias_i, hod.first_moment_zero, True), stat(m_eff_i, hod.first_moment_zero, True),
+            stat(f_sat_i, hod.second_moment_zero, False))
+
+
 def _knots(t, integrand, ln_nu_lo, safe_norm):
     """The 50-knot loops of halo.py:904-927, 929-969, 971-994, 996-1041,
     1043-1086.  ``safe_norm`` None -> normalise by the integrand at ln nu = 0

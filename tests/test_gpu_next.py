@@ -201,3 +201,29 @@ def test_convenience_methods_vs_oracle(tmp_path):
     me.write(str(tmp_path / "me.txt"), str(tmp_path / "me_pk.txt"))
     assert numpy.loadtxt(str(tmp_path / "me.txt")).shape == (50, 8)
     assert numpy.loadtxt(str(tmp_path / "me_pk.txt")).shape == (100, 2)
+
+
+def test_hod_summary_integrals():
+    """halo.py:709-838 against the reference (G10) and, for the satellite fraction the
+    reference cannot reach with its own Zheng HOD, against the oracle."""
+    from chomp_amd import cosmology, halo, mass_function
+    from oracle import chomp_oracle as o
+    g = load_golden("g10_hod_stats")
+    for i, z in enumerate(g["z"]):
+        for tag in ("st", "tinker"):
+            kw = {}
+            if tag == "tinker":
+                cosmo = cosmology.SingleEpoch(float(z))
+                kw = dict(cosmo_single_epoch=cosmo,
+                          mass_func=mass_function.TinkerMassFunction(float(z), cosmo))
+            h = halo.Halo(float(z), **kw)
+            ref = g["%s_%d" % (tag, i)]
+            assert abs(h.calculate_bias() / ref[0] - 1) < RTOL
+            assert abs(h.calculate_m_eff() / ref[1] - 1) < RTOL
+            assert abs(h.n_bar / ref[2] - 1) < RTOL
+            with pytest.raises(TypeError):
+                h.calculate_f_sat()
+            e = o.epoch(None, float(z))
+            t = o.halo_table(e, o.mass_table(e, kind=tag), families=())
+            got = h._sync(0).hod_stats(0, 1)[0]
+            assert numpy.allclose(got, o.hod_stats(t), rtol=RTOL)

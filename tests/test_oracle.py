@@ -229,3 +229,15 @@ def test_g9_correlation3d():
                     1e-4, 1e3)
     assert rel_err(xi, g["xi_mm_wide"][idx]) < 1e-11
     assert bool(g["extrap_mm_wide"]) and not bool(g["extrap_mm"])
+
+
+def test_g10_hod_stats():
+    """Halo.calculate_bias / calculate_m_eff (halo.py:709-790) against the reference."""
+    g = load_golden("g10_hod_stats")
+    for i, z in enumerate(g["z"]):
+        for tag in ("st", "tinker"):
+            e = o.epoch(None, float(z))
+            t = o.halo_table(e, o.mass_table(e, kind=tag), families=())
+            bias, m_eff, f_sat = o.hod_stats(t)
+            assert numpy.allclose([bias, m_eff, t.n_bar], g["%s_%d" % (tag, i)], rtol=1e-12)
+            assert 0.05 < f_sat < 0.5
