@@ -97,6 +97,7 @@ EXPORTS = [
     "chomp_kernel_setup", "chomp_kernel_info", "chomp_kernel_table",
     "chomp_kernel_eval", "chomp_window_eval", "chomp_wtheta", "chomp_cell",
     "chomp_set_precision", "chomp_xi3d", "chomp_spline_eval", "chomp_hod_stats",
+    "chomp_set_transfer",
 ]
 
 
@@ -205,6 +206,7 @@ def lib():
         L.chomp_cell.argtypes = [vp, i, sz, d, vp, sz, vp, i]
         L.chomp_set_precision.argtypes = [vp, i]
         L.chomp_hod_stats.argtypes = [vp, sz, sz, c_double_p]
+        L.chomp_set_transfer.argtypes = [vp, i]
         L.chomp_xi3d.argtypes = [vp, i, sz, d, d, vp, sz, vp, i]
         L.chomp_spline_eval.argtypes = [vp, c_double_p, c_double_p, sz, c_double_p, sz, i,
                                         c_double_p]
@@ -328,7 +330,9 @@ class Context(object):
             hods = [hods] * n
         return (HodPar * n)(*[hod_struct(h) for h in hods])
 
-    def epochs_set(self, cosmo, z):
+    def epochs_set(self, cosmo, z, with_bao=False):
+        """with_bao: SingleEpoch(with_bao=True), the E&H transfer function with wiggles."""
+        self._check(self._L.chomp_set_transfer(self._h, 1 if with_bao else 0))
         z = numpy.ascontiguousarray(numpy.atleast_1d(z), dtype=numpy.float64)
         n = z.size
         arr = cosmo if isinstance(cosmo, ctypes.Array) else self.pack_cosmo(cosmo, n)

@@ -21,8 +21,8 @@ def _context(stream=None, device=None):
 
 
 class SingleEpoch(object):
-    """cosmology.py:25-728.  ``with_bao=True`` (the E&H wiggle transfer function,
-    cosmology.py:474-538) and w0/wa != -1/0 are outside the accelerated scope."""
+    """cosmology.py:25-728.  w0/wa != -1/0 are outside the accelerated scope.  As in the
+    reference, set_cosmology() re-runs __init__ without with_bao, i.e. switches it off."""
 
     def __init__(self, redshift, cosmo_dict=None, with_bao=False, **kws):
         if redshift < 0.0:
@@ -38,9 +38,6 @@ class SingleEpoch(object):
                           ("_w0", "w0"), ("_wa", "wa")):
             setattr(self, attr, cosmo_dict[key])          # KeyError like the reference
         self.H0 = 100.0 / (2.998 * 10 ** 5)
-        if with_bao:
-            raise _lib.ChompScopeError(
-                "with_bao=True (cosmology.py:474-538) is outside the hot-path scope")
         self._with_bao = with_bao
         self._k_min = defaults.default_limits['k_min']
         self._k_max = defaults.default_limits['k_max']
@@ -52,7 +49,7 @@ class SingleEpoch(object):
         if self._ctx is None:
             self._ctx = _context()
         if self._sc is None:
-            self._ctx.epochs_set(self.cosmo_dict, [self._redshift])
+            self._ctx.epochs_set(self.cosmo_dict, [self._redshift], self._with_bao)
             self._sc = self._ctx.scalars(0)
         return self._ctx
 

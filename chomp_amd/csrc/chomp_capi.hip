@@ -72,6 +72,7 @@ struct chomp_ctx {
   size_t cap_slow = 0, cap_winfo = 0, cap_ktab = 0;
   int slow_parity = 0;
   int precision = CHOMP_PREC_F64;  // chomp_set_precision
+  int with_bao = 0;                // chomp_set_transfer
   std::vector<int> slot;           // host copy: epoch -> cosmology slot
   size_t cap_in = 0, cap_in2 = 0, cap_out = 0, cap_work = 0;
 
@@ -340,14 +341,23 @@ int chomp_epochs_set(chomp_ctx* ctx, size_t n_epoch, const chomp_cosmo* cosmo,
   if (rc) return rc;
   rc = upload(ctx, ctx->d_first, first.data(), n_epoch * sizeof(int), ctx->sh_first);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_sigma_nodes,
-                     dim3((kSigmaCount + 255) / 256 + 1 + kSGrid,
-                          (unsigned)(n_slots + (n_epoch + 255) / 256)),
-                     dim3(256), 0, ctx->stream, ctx->cfg, ctx->d_cosmo, ctx->d_z, ctx->d_first,
-                     ctx->d_slot, (int)n_slots, (int)n_epoch, ctx->d_epochs, ctx->d_snodes);
-  hipLaunchKernelGGL(k_epoch_init, dim3((unsigned)n_epoch, 2 * kProbes), dim3(64 * kInitNW), 0,
-                     ctx->stream, ctx->cfg, ctx->d_epochs, ctx->d_search, ctx->d_cand,
-                     ctx->d_snodes, ctx->d_probe, ctx->d_count);
+  const dim3 gs((kSigmaCount + 255) / 256 + 1 + kSGrid, (unsigned)(n_slots + (n_epoch + 255) / 256));
+  const dim3 gi((unsigned)n_epoch, 2 * kProbes);
+  if (ctx->with_bao) {
+    hipLaunchKernelGGL(k_sigma_nodes<true>, gs, dim3(256), 0, ctx->stream, ctx->cfg, ctx->d_cosmo,
+                       ctx->d_z, ctx->d_first, ctx->d_slot, (int)n_slots, (int)n_epoch,
+                       ctx->d_epochs, ctx->d_snodes);
+    hipLaunchKernelGGL(k_epoch_init<true>, gi, dim3(64 * kInitNW), 0, ctx->stream, ctx->cfg,
+                       ctx->d_epochs, ctx->d_search, ctx->d_cand, ctx->d_snodes, ctx->d_probe,
+                       ctx->d_count);
+  } else {
+    hipLaunchKernelGGL(k_sigma_nodes<false>, gs, dim3(256), 0, ctx->stream, ctx->cfg, ctx->d_cosmo,
+                       ctx->d_z, ctx->d_first, ctx->d_slot, (int)n_slots, (int)n_epoch,
+                       ctx->d_epochs, ctx->d_snodes);
+    hipLaunchKernelGGL(k_epoch_init<false>, gi, dim3(64 * kInitNW), 0, ctx->stream, ctx->cfg,
+                       ctx->d_epochs, ctx->d_search, ctx->d_cand, ctx->d_snodes, ctx->d_probe,
+                       ctx->d_count);
+  }
   HIPCHK(hipGetLastError());
   ctx->have_epochs = true;
   return CHOMP_OK;
@@ -363,8 +373,12 @@ int chomp_mass_setup(chomp_ctx* ctx, const chomp_halo_par* par, int mf_kind) {
   const TabLayout& L = ctx->L;
   int rcu = upload(ctx, ctx->d_mass_par, par, n * sizeof(chomp_halo_par), ctx->sh_mass);
   if (rcu) return rcu;
-  hipLaunchKernelGGL(k_nu_table, dim3(L.NM, (unsigned)n), dim3(64 * kNuNW), 0, ctx->stream, ctx->cfg,
-                     L, ctx->d_epochs, ctx->d_search, ctx->d_snodes, ctx->d_tab);
+  if (ctx->with_bao)
+    hipLaunchKernelGGL(k_nu_table<true>, dim3(L.NM, (unsigned)n), dim3(64 * kNuNW), 0, ctx->stream,
+                       ctx->cfg, L, ctx->d_epochs, ctx->d_search, ctx->d_snodes, ctx->d_tab);
+  else
+    hipLaunchKernelGGL(k_nu_table<false>, dim3(L.NM, (unsigned)n), dim3(64 * kNuNW), 0, ctx->stream,
+                       ctx->cfg, L, ctx->d_epochs, ctx->d_search, ctx->d_snodes, ctx->d_tab);
   const size_t sh = (size_t)(2 * L.NM + 8 * (L.NM - 1) + 18 * L.NM + 32 + romberg_scratch<4, 1>()) *
                     sizeof(double);
   hipLaunchKernelGGL(k_mass_setup, dim3((unsigned)n), dim3(256), sh, ctx->stream, ctx->cfg, L,
@@ -449,6 +463,18 @@ int chomp_halo_setup(chomp_ctx* ctx, const chomp_halo_par* profile,
   return CHOMP_OK;
 }
 
+int chomp_set_transfer(chomp_ctx* ctx, int kind) {
+  if (!ctx) return CHOMP_ERR_ARG;
+  if (kind != CHOMP_TRANSFER_EH && kind != CHOMP_TRANSFER_EH_BAO)
+    return fail(ctx, CHOMP_ERR_ARG, "set_transfer: unknown transfer function");
+  if (ctx->with_bao != (kind == CHOMP_TRANSFER_EH_BAO)) {
+    ctx->with_bao = kind == CHOMP_TRANSFER_EH_BAO;
+    ctx->have_epochs = ctx->have_mass = ctx->have_halo = false;   // every table depends on T(k)
+    ctx->fam_mask = 0;
+  }
+  return CHOMP_OK;
+}
+
 int chomp_hod_stats(chomp_ctx* ctx, size_t epoch0, size_t n, double* out) {
   if (!ctx || !out || n == 0) return fail(ctx, CHOMP_ERR_ARG, "hod_stats: bad args");
   if (!ctx->have_halo) return fail(ctx, CHOMP_ERR_STATE, "hod_stats before halo_setup");
@@ -476,6 +502,8 @@ static int check_power(chomp_ctx* ctx, int which, size_t epoch0, size_t n) {
   const bool hf = (which & CHOMP_P_HALOFIT) != 0;
   if (w < CHOMP_P_LIN || w > CHOMP_P_GG) return fail(ctx, CHOMP_ERR_ARG, "power: unknown spectrum");
   if (hf && w == CHOMP_P_LIN) return fail(ctx, CHOMP_ERR_ARG, "power: halofit|lin");
+  if (hf && ctx->with_bao)
+    return fail(ctx, CHOMP_ERR_SCOPE, "HaloFit on the wiggle transfer function is not accelerated");
   unsigned need = 0;
   if (w == CHOMP_P_MM && !hf) need = (1u << F_HM) | (1u << F_PPMM);
   if (w == CHOMP_P_GM) need = (1u << F_HM) | (1u << F_HG) | (1u << F_PPGM);
@@ -496,8 +524,12 @@ static int prepare_extrapolation(chomp_ctx* ctx, int which, size_t epoch0, size_
   const int w = which & 15;
   if (!(which & CHOMP_P_EXTRAPOLATE) || (which & CHOMP_P_HALOFIT) || w == CHOMP_P_LIN)
     return CHOMP_OK;
-  hipLaunchKernelGGL(k_power_extrap, dim3((unsigned)n), dim3(64), 0, ctx->stream, ctx->cfg,
-                     ctx->L, ctx->d_epochs, ctx->d_tab, w, (int)epoch0);
+  if (ctx->with_bao)
+    hipLaunchKernelGGL(k_power_extrap<true>, dim3((unsigned)n), dim3(64), 0, ctx->stream, ctx->cfg,
+                       ctx->L, ctx->d_epochs, ctx->d_tab, w, (int)epoch0);
+  else
+    hipLaunchKernelGGL(k_power_extrap<false>, dim3((unsigned)n), dim3(64), 0, ctx->stream, ctx->cfg,
+                       ctx->L, ctx->d_epochs, ctx->d_tab, w, (int)epoch0);
   HIPCHK(hipGetLastError());
   return CHOMP_OK;
 }
@@ -548,9 +580,14 @@ int chomp_power_range(chomp_ctx* ctx, int which, size_t epoch0, size_t n, const 
       if (rc) return rc;
       rc = ensure(ctx, &ctx->d_ktab, &ctx->cap_ktab, (size_t)gx8 * 1024);
       if (rc) return rc;
-      hipLaunchKernelGGL(k_power_prep, dim3(gx8), dim3(256), 0, ctx->stream, ctx->cfg, L,
-                         ctx->d_epochs, (int)epoch0, w, dk, nk, ctx->d_ktab, ctx->d_winfo,
-                         ctx->d_slow, parity);
+      if (ctx->with_bao)
+        hipLaunchKernelGGL(k_power_prep<true>, dim3(gx8), dim3(256), 0, ctx->stream, ctx->cfg, L,
+                           ctx->d_epochs, (int)epoch0, w, dk, nk, ctx->d_ktab, ctx->d_winfo,
+                           ctx->d_slow, parity);
+      else
+        hipLaunchKernelGGL(k_power_prep<false>, dim3(gx8), dim3(256), 0, ctx->stream, ctx->cfg, L,
+                           ctx->d_epochs, (int)epoch0, w, dk, nk, ctx->d_ktab, ctx->d_winfo,
+                           ctx->d_slow, parity);
       int per = n % 2 == 0 ? 2 : 1;
       // (tuning hook: rows per block of the streaming kernel; 2 measured best on MI355X)
       if (const char* ev = getenv("CHOMP_E_PER")) { int v = atoi(ev); if ((v == 1 || v == 2 || v == 4) && n % v == 0) per = v; }
@@ -570,20 +607,34 @@ int chomp_power_range(chomp_ctx* ctx, int which, size_t epoch0, size_t n, const 
       if (gy > n) gy = (unsigned)n;
       const int epy = (int)((n + gy - 1) / gy);
       gy = (unsigned)((n + epy - 1) / epy);
-      hipLaunchKernelGGL(k_power_grid, dim3(gx, gy), dim3(256), 0, ctx->stream, ctx->cfg, L,
-                         ctx->d_epochs, ctx->d_tab, w, (int)epoch0, (int)n, epy, 1, dk, nk,
-                         dout, ctx->d_slow, parity);
+      if (ctx->with_bao)
+        hipLaunchKernelGGL(k_power_grid<true>, dim3(gx, gy), dim3(256), 0, ctx->stream, ctx->cfg, L,
+                           ctx->d_epochs, ctx->d_tab, w, (int)epoch0, (int)n, epy, 1, dk, nk,
+                           dout, ctx->d_slow, parity);
+      else
+        hipLaunchKernelGGL(k_power_grid<false>, dim3(gx, gy), dim3(256), 0, ctx->stream, ctx->cfg, L,
+                           ctx->d_epochs, ctx->d_tab, w, (int)epoch0, (int)n, epy, 1, dk, nk,
+                           dout, ctx->d_slow, parity);
     }
     // per-lane pass over the listed k groups
-    hipLaunchKernelGGL(k_power_grid_lanes, dim3(1024), dim3(256), 0, ctx->stream, ctx->cfg, L,
-                       ctx->d_epochs, ctx->d_tab, w, extrap, (int)epoch0, (int)n, dk, nk, dout,
-                       ctx->d_slow, parity);
+    if (ctx->with_bao)
+      hipLaunchKernelGGL(k_power_grid_lanes<true>, dim3(1024), dim3(256), 0, ctx->stream, ctx->cfg,
+                         L, ctx->d_epochs, ctx->d_tab, w, extrap, (int)epoch0, (int)n, dk, nk, dout,
+                         ctx->d_slow, parity);
+    else
+      hipLaunchKernelGGL(k_power_grid_lanes<false>, dim3(1024), dim3(256), 0, ctx->stream, ctx->cfg,
+                         L, ctx->d_epochs, ctx->d_tab, w, extrap, (int)epoch0, (int)n, dk, nk, dout,
+                         ctx->d_slow, parity);
   } else {
     unsigned gx = (unsigned)((nk + 255) / 256);
     if (gx > 2048) gx = 2048;
     const size_t sh = (size_t)(12 * (L.NK - 1)) * sizeof(double);
-    hipLaunchKernelGGL(k_power, dim3(gx, (unsigned)n), dim3(256), sh, ctx->stream, ctx->cfg, L,
-                       ctx->d_epochs, ctx->d_tab, which, (int)epoch0, dk, nk, dout);
+    if (ctx->with_bao)
+      hipLaunchKernelGGL(k_power<true>, dim3(gx, (unsigned)n), dim3(256), sh, ctx->stream, ctx->cfg,
+                         L, ctx->d_epochs, ctx->d_tab, which, (int)epoch0, dk, nk, dout);
+    else
+      hipLaunchKernelGGL(k_power<false>, dim3(gx, (unsigned)n), dim3(256), sh, ctx->stream, ctx->cfg,
+                         L, ctx->d_epochs, ctx->d_tab, which, (int)epoch0, dk, nk, dout);
   }
   HIPCHK(hipGetLastError());
   if (mem == CHOMP_HOST) {
@@ -609,8 +660,12 @@ int chomp_sigma_r(chomp_ctx* ctx, size_t epoch, const double* scale, size_t n, d
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(ctx->d_stage_in, scale, n * sizeof(double), hipMemcpyHostToDevice,
                         ctx->stream));
-  hipLaunchKernelGGL(k_sigma_r, dim3((unsigned)n), dim3(256), 0, ctx->stream, ctx->cfg,
-                     ctx->d_epochs, (int)epoch, ctx->d_stage_in, ctx->d_snodes, ctx->d_stage_out);
+  if (ctx->with_bao)
+    hipLaunchKernelGGL(k_sigma_r<true>, dim3((unsigned)n), dim3(256), 0, ctx->stream, ctx->cfg,
+                       ctx->d_epochs, (int)epoch, ctx->d_stage_in, ctx->d_snodes, ctx->d_stage_out);
+  else
+    hipLaunchKernelGGL(k_sigma_r<false>, dim3((unsigned)n), dim3(256), 0, ctx->stream, ctx->cfg,
+                       ctx->d_epochs, (int)epoch, ctx->d_stage_in, ctx->d_snodes, ctx->d_stage_out);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out, ctx->d_stage_out, n * sizeof(double), hipMemcpyDeviceToHost,
                         ctx->stream));

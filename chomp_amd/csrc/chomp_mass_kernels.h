@@ -145,6 +145,8 @@ constexpr int kSigmaStride = 2 * kSigmaCount + 8 + kSGrid;  // doubles per cosmo
 // the coarse ln S(R) table, all by direct evaluation.  The rows y >= n_slots fill in the
 // closed-form part of every epoch record (SingleEpoch.__init__ minus its two integrals),
 // one epoch per thread, while the cosmology-only integrals run.
+// BAO: the context's transfer function (chomp_set_transfer), fixed at compile time.
+template <bool BAO>
 __global__ __launch_bounds__(256) void k_sigma_nodes(chomp_config cfg,
                                                      const chomp_cosmo* __restrict__ cosmo,
                                                      const double* __restrict__ zin,
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(256) void k_sigma_nodes(chomp_config cfg,
     B.om0 = c.omega_m0; B.ob0 = c.omega_b0; B.ol0 = c.omega_l0; B.or0 = c.omega_r0;
     B.tcmb = c.cmb_temp; B.h = c.h; B.sigma8 = c.sigma_8; B.ns = c.n_scalar;
     B.z = zin[e];
-    epoch_background(B, cfg.cosmo_precision, cfg.k_min, cfg.k_max);
+    epoch_background(B, cfg.cosmo_precision, cfg.k_min, cfg.k_max, BAO ? 1 : 0);
     B.cosmo_slot = slots[e];
     epochs[e] = B;
     return;
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(256) void k_sigma_nodes(chomp_config cfg,
     E.om0 = c.omega_m0; E.ob0 = c.omega_b0; E.ol0 = c.omega_l0; E.or0 = c.omega_r0;
     E.tcmb = c.cmb_temp; E.h = c.h; E.sigma8 = c.sigma_8; E.ns = c.n_scalar;
     E.z = zin[e];
-    epoch_background(E, cfg.cosmo_precision, cfg.k_min, cfg.k_max);
+    epoch_background(E, cfg.cosmo_precision, cfg.k_min, cfg.k_max, BAO ? 1 : 0);
   }
   __syncthreads();
   double* n = snodes + (size_t)slot * kSigmaStride;
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(256) void k_sigma_nodes(chomp_config cfg,
     const double R = i < 0 ? 8.0 : exp(make_sgrid(cfg.k_min, cfg.k_max).ln_r(i));
     double lo, hi;
     sigma_limits(E, R, &lo, &hi);
-    SigmaIntegrand f{&E, R};                      // sigma_norm = 1: amp * integral
+    SigmaIntegrandT<BAO> f{&E, R};                // sigma_norm = 1: amp * integral
     // (the ln S points only aim the search: 1e-5 and at most 2^12 panels are plenty)
     const double s2 = romberg1<4>(f, lo, hi, cfg.global_precision,
                                   i < 0 ? cfg.cosmo_precision : 1e-5,
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(256) void k_sigma_nodes(chomp_config cfg,
     x = (a + 0.5 * h) + h * (double)j;
   }
   const double k = exp(x);
-  const double T = eh_transfer(E, k);
+  const double T = transfer_t<BAO>(E, k);
   n[idx] = k;
   // Delta^2 shape over k^6: W(kR)^2 = 9 (sin y - y cos y)^2 / (k R)^6 then needs no division
   const double k3 = k * k * k;
@@ -219,6 +221,7 @@ __global__ __launch_bounds__(256) void k_sigma_nodes(chomp_config cfg,
 
 // Delta^2(k) W(kR)^2 / (amp sigma_norm^2) from the table (levels <= kSigmaLevel),
 // direct evaluation beyond.
+template <bool BAO>
 struct SigmaTabIntegrand {
   const Epoch* e;
   const double* node;      // this cosmology's table: k_j, then (k_j/H0)^(3+n) T^2 / k_j^6
@@ -234,7 +237,7 @@ struct SigmaTabIntegrand {
       const double t = s - kR * c;
       out[0] = node[kSigmaCount + idx] * nine_over_r6 * (t * t);
     } else {
-      SigmaIntegrand f{e, scale};
+      SigmaIntegrandT<BAO> f{e, scale};
       out[0] = f(ln_k) * inv_amp;
     }
   }
@@ -244,7 +247,7 @@ struct SigmaTabIntegrand {
 // one Romberg integral; `rtol` is cosmo_precision for reference-exact values.
 // UNROLL > 1 overlaps the table loads of several nodes (worth it where few blocks share a
 // CU, as in k_epoch_init; with many resident blocks the extra registers cost more).
-template <int NW, int UNROLL = 1>
+template <int NW, int UNROLL = 1, bool BAO = false>
 __device__ __forceinline__ double sigma2_block(const Epoch& E, const double* snode, double R,
                                                const chomp_config& cfg, double rtol,
                                                double* red) {
@@ -254,12 +257,12 @@ __device__ __forceinline__ double sigma2_block(const Epoch& E, const double* sno
   const double amp2 = E.amp * E.sigma_norm * E.sigma_norm;
   if (need_min > E.k_min && need_max < E.k_max) {          // fixed range: table path
     const double r3 = R * R * R;
-    SigmaTabIntegrand f{&E, snode, R, 1.0 / amp2, 9.0 / (r3 * r3)};
-    const RombergOut<1> r = romberg_group<NW, 1, SigmaTabIntegrand, UNROLL>(f, lo, hi, cfg.global_precision, rtol,
+    SigmaTabIntegrand<BAO> f{&E, snode, R, 1.0 / amp2, 9.0 / (r3 * r3)};
+    const RombergOut<1> r = romberg_group<NW, 1, SigmaTabIntegrand<BAO>, UNROLL>(f, lo, hi, cfg.global_precision, rtol,
                                                  cfg.divmax, red);
     return amp2 * r.value[0];
   }
-  SigmaIntegrand f{&E, R};
+  SigmaIntegrandT<BAO> f{&E, R};
   return romberg1<NW>(f, lo, hi, cfg.global_precision, rtol, cfg.divmax, red);
 }
 
@@ -295,11 +298,11 @@ __device__ __forceinline__ void spline_build_pcr(const double* x, const double* 
 }
 
 // nu(M) = (delta_c / sigma(R(M)))^2, cosmology.py:662-699.
-template <int NW, int UNROLL = 1>
+template <int NW, int UNROLL = 1, bool BAO = false>
 __device__ __forceinline__ double nu_of_mass_block(const Epoch& E, const double* snode,
                                                    double mass, const chomp_config& cfg,
                                                    double rtol, double* red) {
-  const double s2 = sigma2_block<NW, UNROLL>(E, snode, scale_of_mass(E, mass), cfg, rtol, red);
+  const double s2 = sigma2_block<NW, UNROLL, BAO>(E, snode, scale_of_mass(E, mass), cfg, rtol, red);
   const double sq = E.delta_c / sqrt(s2);
   return sq * sq;
 }
@@ -339,7 +342,7 @@ __device__ __forceinline__ SideThresholds side_thresholds(int side, const double
 // nu(M) at a probe: a looser Romberg tolerance first; a probe that lands within
 // kAmbiguous (in ln nu) of a band edge is redone at the reference's tolerance, so every
 // comparison that decides the stopping step is either clear of the edge or exact.
-template <int NW>
+template <int NW, bool BAO>
 __device__ __forceinline__ double nu_probe(const Epoch& E, const double* snode, double m,
                                            const chomp_config& cfg, double thr_lo,
                                            double thr_hi, double* red) {
@@ -347,10 +350,10 @@ __device__ __forceinline__ double nu_probe(const Epoch& E, const double* snode, 
   // decision rests on exactly that integral)
   const double kAmbiguous = 2e-5;
   const double rtol_probe = cfg.cosmo_precision > 1e-6 ? cfg.cosmo_precision : 1e-6;
-  double nu = nu_of_mass_block<NW, 4>(E, snode, m, cfg, rtol_probe, red);
+  double nu = nu_of_mass_block<NW, 4, BAO>(E, snode, m, cfg, rtol_probe, red);
   const double edge = fmin(fabs(log(nu / thr_lo)), fabs(log(nu / thr_hi)));
   if (edge < kAmbiguous && cfg.cosmo_precision < rtol_probe)
-    nu = nu_of_mass_block<NW, 4>(E, snode, m, cfg, cfg.cosmo_precision, red);
+    nu = nu_of_mass_block<NW, 4, BAO>(E, snode, m, cfg, cfg.cosmo_precision, red);
   return nu;
 }
 
@@ -359,7 +362,7 @@ __device__ __forceinline__ double nu_probe(const Epoch& E, const double* snode, 
 // did not certify the estimate): seed_dir != 0 fixes the walking direction; candidate
 // seed_jl is known to FAIL the threshold test (nu_l: its nu, exact or estimated -- it only
 // steers the secant); seed_jh >= 0 is known to PASS it with exact nu_h.
-template <int NW>
+template <int NW, bool BAO>
 __device__ double search_side_exact(const Epoch& E, const double* snode, int side,
                                     const chomp_config& cfg, const double* cand, double* red,
                                     int* n_eval, int seed_dir = 0, int seed_jl = 0,
@@ -369,7 +372,7 @@ __device__ double search_side_exact(const Epoch& E, const double* snode, int sid
   int dir = seed_dir;
   double nu0 = nu_l;
   if (seed_dir == 0) {
-    nu0 = nu_probe<NW>(E, snode, T.down[0], cfg, T.thr_lo, T.thr_hi, red);
+    nu0 = nu_probe<NW, BAO>(E, snode, T.down[0], cfg, T.thr_lo, T.thr_hi, red);
     ++*n_eval;
     if (T.thr_hi < nu0) dir = -1; else if (T.thr_lo > nu0) dir = +1;
   }
@@ -396,7 +399,7 @@ __device__ double search_side_exact(const Epoch& E, const double* snode, int sid
         if (want > (double)(jh - jl - 1)) want = (double)(jh - jl - 1);
         jp = jl + (int)want;
       }
-      const double nu = nu_probe<NW>(E, snode, tab[jp], cfg, T.thr_lo, T.thr_hi, red);
+      const double nu = nu_probe<NW, BAO>(E, snode, tab[jp], cfg, T.thr_lo, T.thr_hi, red);
       ++*n_eval;
       const bool pred = dir < 0 ? !(thr < nu) : !(thr > nu);
       const double tp = dir < 0 ? log(nu / thr) : log(thr / nu);
@@ -508,6 +511,7 @@ __device__ __forceinline__ SidePlan plan_side(const Epoch& E, const double* lns,
 // the record (k_sigma_nodes) on entry and the complete record on exit.
 constexpr int kProbes = 4;
 constexpr int kProbeStride = 24;   // doubles per epoch: nu[2][kProbes], chi, pad[3], plan[2][4]
+template <bool BAO>
 __global__ __launch_bounds__(64 * kInitNW) void k_epoch_init(
     chomp_config cfg, Epoch* __restrict__ epochs, double* __restrict__ search,
     const double* __restrict__ cand, const double* __restrict__ snodes,
@@ -563,7 +567,7 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_init(
       // (away from an edge candidate 0 fails by the margin of the estimate)
       if ((c > 0 || (c == 0 && plan.at_edge)) && c < kSearchJ) {
         const double* tab = plan.dir < 0 ? T.down : T.up;
-        nu_mine = nu_probe<kInitNW>(E, snode, tab[c], cfg, T.thr_lo, T.thr_hi, red);
+        nu_mine = nu_probe<kInitNW, BAO>(E, snode, tab[c], cfg, T.thr_lo, T.thr_hi, red);
       }
     }
     if (threadIdx.x == 0) {
@@ -651,7 +655,7 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_init(
       }
     }
     if (!certified)                // block-uniform: every thread read the same values
-      mass = search_side_exact<kInitNW>(E, snode, sd, cfg, cand, red, &n_eval, seed_dir, seed_jl,
+      mass = search_side_exact<kInitNW, BAO>(E, snode, sd, cfg, cand, red, &n_eval, seed_dir, seed_jl,
                                         nu_l, seed_jh, nu_h);
     if (threadIdx.x == 0) {
       search[(e * 2 + sd) * 2 + 0] = log(mass);
@@ -672,6 +676,7 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_init(
 // k_nu_table: grid (NM, n_epoch), block 64 * kNuNW: nu_i = nu_m(exp(ln_mass_i)).
 // ---------------------------------------------------------------------------
 constexpr int kNuNW = 1;         // wavefronts per sigma(R) integral of k_nu_table
+template <bool BAO>
 __global__ __launch_bounds__(64 * kNuNW) void k_nu_table(chomp_config cfg, TabLayout L,
                                                   const Epoch* __restrict__ epochs,
                                                   const double* __restrict__ search,
@@ -685,7 +690,7 @@ __global__ __launch_bounds__(64 * kNuNW) void k_nu_table(chomp_config cfg, TabLa
   __syncthreads();
   const double ln_lo = search[(e * 2 + 0) * 2], ln_hi = search[(e * 2 + 1) * 2];
   const double lnm = linspace_at(ln_lo, ln_hi, L.NM, i);
-  const double nu = nu_of_mass_block<kNuNW>(E, snodes + (size_t)E.cosmo_slot * kSigmaStride, exp(lnm), cfg,
+  const double nu = nu_of_mass_block<kNuNW, 1, BAO>(E, snodes + (size_t)E.cosmo_slot * kSigmaStride, exp(lnm), cfg,
                                             cfg.cosmo_precision, red);
   if (threadIdx.x == 0) {
     double* t = tab + (size_t)e * L.stride;

@@ -465,6 +465,11 @@ struct Epoch {
   double hf_f1, hf_f2, hf_f3, hf_k_s, hf_n_eff, hf_C, hf_a_n, hf_b_n, hf_c_n,
       hf_gamma_n, hf_alpha_n, hf_beta_n, hf_mu_n, hf_nu_n;
   double ln_st_a, ln_t_beta;       // logs used by mf_node
+  // E&H transfer function with baryon wiggles (SingleEpoch(with_bao=True),
+  // cosmology.py:474-538): flag and the k-independent constants
+  int with_bao, pad_bao;
+  double bao_hs, bao_q_scale, bao_ksilk_h, bao_alpha_b, bao_beta_b, bao_alpha_c, bao_beta_c,
+      bao_beta_node, bao_s, bao_ObO, bao_OcO;
 };
 static_assert(sizeof(Epoch) % 16 == 0, "Epoch must keep LDS carve-ups 16-byte aligned");
 
@@ -486,9 +491,11 @@ CHOMP_HD double growth_approx(double om0, double ol0, double a) {
   return coeff / (term1 - Omega_L + term3);
 }
 
+CHOMP_HD void bao_constants(Epoch& e);
+
 // SingleEpoch.__init__ minus the two integrals (chi, sigma_norm).
 CHOMP_HD void epoch_background(Epoch& e, double cosmo_precision, double k_min,
-                               double k_max) {
+                               double k_max, int with_bao = 0) {
   if (e.z < 0.0) e.z = 0.0;
   e.H0 = 100.0 / (2.998 * 100000.0);
   e.ln_H0 = log(e.H0);
@@ -530,6 +537,70 @@ CHOMP_HD void epoch_background(Epoch& e, double cosmo_precision, double k_min,
   e.eh_omh = e.om0 * e.h;
   e.sigma_norm = 1.0;
   e.amp = e.delta_H * e.delta_H / e.h * (e.growth * e.growth);
+  e.with_bao = with_bao ? 1 : 0;
+  e.pad_bao = 0;
+  if (e.with_bao) bao_constants(e);
+}
+
+// Constants of the wiggle transfer function (cosmology.py:484-527).
+CHOMP_HD void bao_constants(Epoch& e) {
+  const double theta = e.tcmb / 2.7;
+  const double Ob = e.ob0, Om = e.om0, Oc = Om - Ob, h = e.h;
+  const double Obh2 = Ob * h * h, Oh2 = Om * h * h, ObO = Ob / Om;
+  const double th2 = theta * theta, th4 = th2 * th2;
+  const double zeq = 2.5e4 * Oh2 / th4;
+  const double keq = 7.46e-2 * Oh2 / th2;
+  double b1 = 0.313 * pow(Oh2, -0.419) * (1.0 + 0.607 * pow(Oh2, 0.674));
+  double b2 = 0.238 * pow(Oh2, 0.223);
+  const double zd = 1291.0 * (pow(Oh2, 0.251) / (1.0 + 0.659 * pow(Oh2, 0.828))) *
+                    (1.0 + b1 * pow(Obh2, b2));
+  const double Req = 31.5 * Obh2 / th4 * (1000.0 / zeq);
+  const double Rd = 31.5 * Obh2 / th4 * (1000.0 / zd);
+  const double s = (2.0 / (3.0 * keq)) * sqrt(6.0 / Req) *
+                   log((sqrt(1.0 + Rd) + sqrt(Rd + Req)) / (1.0 + sqrt(Req)));
+  const double kSilk = 1.6 * pow(Obh2, 0.52) * pow(Oh2, 0.73) * (1.0 + pow(10.4 * Oh2, -0.95));
+  const double y = (1.0 + zeq) / (1.0 + zd);
+  const double G = y * (-6.0 * sqrt(1.0 + y) +
+                        (2.0 + 3.0 * y) * log((sqrt(1.0 + y) + 1.0) / (sqrt(1.0 + y) - 1.0)));
+  e.bao_alpha_b = 2.07 * keq * s * pow(1.0 + Rd, -3.0 / 4.0) * G;
+  e.bao_beta_b = 0.5 + ObO + (3.0 - 2.0 * ObO) * sqrt((17.2 * Oh2) * (17.2 * Oh2) + 1.0);
+  const double a1 = pow(46.9 * Oh2, 0.670) * (1.0 + pow(32.1 * Oh2, -0.532));
+  const double a2 = pow(12.0 * Oh2, 0.424) * (1.0 + pow(45.0 * Oh2, -0.582));
+  e.bao_alpha_c = pow(a1, -ObO) * pow(a2, -(ObO * ObO * ObO));
+  b1 = 0.944 / (1.0 + pow(458.0 * Oh2, -0.708));
+  b2 = pow(0.395 * Oh2, -0.0266);
+  e.bao_beta_c = 1.0 / (1.0 + b1 * (pow(Oc / Om, b2) - 1.0));
+  e.bao_beta_node = 8.41 * pow(Oh2, 0.435);
+  e.bao_s = s;
+  e.bao_hs = h * s;                       // ks = k h s
+  e.bao_q_scale = h / (13.41 * keq);      // q = k h / (13.41 keq)
+  e.bao_ksilk_h = h / kSilk;              // k h / kSilk
+  e.bao_ObO = ObO;
+  e.bao_OcO = Oc / Om;
+}
+
+// cosmology.py:474-538.
+CHOMP_HD double eh_bao_transfer(const Epoch& e, double k) {
+  const double ks = k * e.bao_hs;
+  const double q = k * e.bao_q_scale;
+  const double q2 = q * q;
+  const double c386 = 386.0 / (1.0 + 69.9 * pow(q, 1.08));
+  const double ks54 = ks / 5.4, f = 1.0 / (1.0 + (ks54 * ks54) * (ks54 * ks54));
+  const double Lc = log(kE + 1.8 * e.bao_beta_c * q);
+  const double T_c1 = Lc / (Lc + (14.2 + c386) * q2);
+  const double T_ca = Lc / (Lc + (14.2 / e.bao_alpha_c + c386) * q2);
+  const double Tc = f * T_c1 + (1.0 - f) * T_ca;
+  const double L1 = log(kE + 1.8 * q);
+  const double T_11 = L1 / (L1 + (14.2 + c386) * q2);
+  const double bn = e.bao_beta_node / ks;
+  const double stilde = e.bao_s / cbrt(1.0 + bn * bn * bn);
+  const double ks52 = ks / 5.2;
+  const double Tb1 = T_11 / (1.0 + ks52 * ks52);
+  const double bb = e.bao_beta_b / ks;
+  const double Tb2 = (e.bao_alpha_b / (1.0 + bb * bb * bb)) * exp(-pow(k * e.bao_ksilk_h, 1.4));
+  const double x = k * stilde;                          // numpy.sinc(x / pi) = sin x / x
+  const double sinc = x == 0.0 ? 1.0 : sin(x) / x;
+  return e.bao_ObO * (sinc * (Tb1 + Tb2)) + e.bao_OcO * Tc;
 }
 
 // cosmology.py:449-472
@@ -573,7 +644,12 @@ CHOMP_HD double fast_log(double x) {
 // Stage E: 2 pi^2 (k/H0)^(3+n) T(k)^2 / k^3 -- linear_power(k) without its amplitude
 // (cosmology.py:449-472, 574-600) -- arranged with two divisions: q as one quotient, the
 // transfer function as L0 D / (L0 D + N q^2) with D = 1 + 62.5 q, N = 14.2 D + 731.
-CHOMP_HD double power_shape(const Epoch& e, double ln_k, double k) {
+template <bool BAO>
+CHOMP_HD double power_shape_t(const Epoch& e, double ln_k, double k) {
+  if (BAO) {
+    const double Tb = eh_bao_transfer(e, k);
+    return 2.0 * kPi * kPi * exp(fma(e.ns, ln_k, -(3.0 + e.ns) * e.ln_H0)) * Tb * Tb;
+  }
   const double t = 1.0 + 0.43 * k * e.eh_s;
   const double t2 = t * t, t4 = t2 * t2;
   const double q = k * e.eh_theta * t4 / (e.eh_omh * fma(e.eh_alpha, t4, 1.0 - e.eh_alpha));
@@ -584,19 +660,46 @@ CHOMP_HD double power_shape(const Epoch& e, double ln_k, double k) {
   const double T = LD / fma(N, q * q, LD);
   return 2.0 * kPi * kPi * exp(fma(e.ns, ln_k, -(3.0 + e.ns) * e.ln_H0)) * T * T;
 }
+// (transfer function chosen at run time: callers off the streaming path)
+CHOMP_HD double power_shape(const Epoch& e, double ln_k, double k) {
+  return e.with_bao ? power_shape_t<true>(e, ln_k, k) : power_shape_t<false>(e, ln_k, k);
+}
 
-// Delta^2(k) = k^3 P(k)/(2 pi^2), cosmology.py:574-587, from ln k.
-CHOMP_HD double delta_k_ln(const Epoch& e, double ln_k, double k) {
-  const double T = eh_transfer(e, k);
+// SingleEpoch.transfer_function (cosmology.py:556-572).
+CHOMP_HD double transfer_function(const Epoch& e, double k) {
+  return e.with_bao ? eh_bao_transfer(e, k) : eh_transfer(e, k);
+}
+// The same with the choice made at compile time: the sigma(R) kernels are instantiated
+// once per transfer function, so that the no-wiggle instance carries no trace (registers,
+// code) of the other.
+template <bool BAO>
+CHOMP_HD double transfer_t(const Epoch& e, double k) {
+  return BAO ? eh_bao_transfer(e, k) : eh_transfer(e, k);
+}
+
+// Delta^2(k) = k^3 P(k)/(2 pi^2), cosmology.py:574-587, from ln k.  BAO: the transfer
+// function, fixed at compile time in device code (see transfer_t).
+template <bool BAO>
+CHOMP_HD double delta_k_ln_t(const Epoch& e, double ln_k, double k) {
+  const double T = transfer_t<BAO>(e, k);
   return e.amp * e.sigma_norm * e.sigma_norm * exp((3.0 + e.ns) * (ln_k - e.ln_H0)) *
          T * T;
 }
 
 // linear_power(k), cosmology.py:589-600
-CHOMP_HD double linear_power(const Epoch& e, double k) {
+template <bool BAO>
+CHOMP_HD double linear_power_t(const Epoch& e, double k) {
   if (!(k > 1e-16)) return 1e-16;
   const double lk = log(k);
-  return 2.0 * kPi * kPi * delta_k_ln(e, lk, k) / (k * k * k);
+  return 2.0 * kPi * kPi * delta_k_ln_t<BAO>(e, lk, k) / (k * k * k);
+}
+
+// Run-time choice of the transfer function (host-side checks; device code uses the _t forms).
+CHOMP_HD double delta_k_ln(const Epoch& e, double ln_k, double k) {
+  return e.with_bao ? delta_k_ln_t<true>(e, ln_k, k) : delta_k_ln_t<false>(e, ln_k, k);
+}
+CHOMP_HD double linear_power(const Epoch& e, double k) {
+  return e.with_bao ? linear_power_t<true>(e, k) : linear_power_t<false>(e, k);
 }
 
 // sigma_r limits, cosmology.py:611-632
@@ -614,7 +717,8 @@ CHOMP_HD void sigma_limits(const Epoch& e, double scale, double* ln_lo, double* 
 
 // Integrand of sigma^2(R) over ln k divided by 2 pi^2 (cosmology.py:644-660):
 // dk P W^2 k^2 / (2 pi^2) = Delta^2(k) W(kR)^2.
-struct SigmaIntegrand {
+template <bool BAO>
+struct SigmaIntegrandT {
   const Epoch* e;
   double scale;
   CHOMP_HD double operator()(double ln_k) const {
@@ -624,9 +728,12 @@ struct SigmaIntegrand {
     fast_sincos(kR, &s, &c);
     const double kR2 = kR * kR;
     const double W = 3.0 * (s / (kR2 * kR) - c / kR2);
-    return delta_k_ln(*e, ln_k, k) * W * W;
+    const double T = transfer_t<BAO>(*e, k);
+    return e->amp * e->sigma_norm * e->sigma_norm * exp((3.0 + e->ns) * (ln_k - e->ln_H0)) *
+           T * T * W * W;
   }
 };
+typedef SigmaIntegrandT<false> SigmaIntegrand;
 
 // HaloFit sigma^2(R) with a Gaussian filter, halo.py:1321-1323.
 struct HalofitSigmaIntegrand {
@@ -634,7 +741,7 @@ struct HalofitSigmaIntegrand {
   double R;
   CHOMP_HD double operator()(double ln_k) const {
     const double k = exp(ln_k);
-    return delta_k_ln(*e, ln_k, k) * exp(-k * k * R * R);
+    return delta_k_ln_t<false>(*e, ln_k, k) * exp(-k * k * R * R);   // (HaloFit: no-wiggle only)
   }
 };
 

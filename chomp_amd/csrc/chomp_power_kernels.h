@@ -27,9 +27,12 @@ __device__ __forceinline__ PowerFam power_families(int w) {
 
 // Above k_max with Halo(extrapolate=True) (halo.py:300-312, 341-367, 405-431); x[] are
 // the epoch's misc[3..7] written by k_power_extrap.
+// BAO (here and below): the context's transfer function, a compile-time choice in device
+// code (chomp_set_transfer; transfer_t in chomp_math.h).
+template <bool BAO>
 __device__ __forceinline__ double power_tail(const Epoch& E, const double* x, int w, double kv,
                                              double k_max) {
-  if (w == CHOMP_P_MM) return linear_power(E, kv) * x[0];
+  if (w == CHOMP_P_MM) return linear_power_t<BAO>(E, kv) * x[0];
   const double* vs = w == CHOMP_P_GM ? x + 1 : x + 3;          // value at k_max, log-slope
   return pow(kv / k_max, vs[1]) * vs[0];
 }
@@ -37,7 +40,7 @@ __device__ __forceinline__ double power_tail(const Epoch& E, const double* x, in
 __device__ __forceinline__ double halofit_mm(const Epoch& E, double k) {
   // halo.py:1339-1360
   const double lk = log(k);
-  const double dk = delta_k_ln(E, lk, k);
+  const double dk = delta_k_ln_t<false>(E, lk, k);      // (HaloFit: no-wiggle contexts only)
   const double y = k / E.hf_k_s;
   const double d2q = dk * (pow(1.0 + dk, E.hf_beta_n) / (1.0 + E.hf_alpha_n * dk) *
                            exp(-(y / 4.0 + y * y / 8.0)));
@@ -52,7 +55,7 @@ __device__ __forceinline__ double halofit_mm(const Epoch& E, double k) {
 // linear form in ln k, the linear spectrum comes from power_shape (halo.py:1339-1360).
 __device__ __forceinline__ double halofit_mm_ln(const Epoch& E, double amp2, double lk, double k) {
   const double k3 = k * k * k;
-  const double dk = amp2 * power_shape(E, lk, k) * k3 * (1.0 / (2.0 * kPi * kPi));
+  const double dk = amp2 * power_shape_t<false>(E, lk, k) * k3 * (1.0 / (2.0 * kPi * kPi));
   const double ln_y = lk - log(E.hf_k_s);               // (log of a per-epoch constant)
   const double y = exp(ln_y);
   const double d2q = dk * exp(E.hf_beta_n * fast_log(1.0 + dk) - (y * 0.25 + y * y * 0.125)) /
@@ -112,15 +115,20 @@ struct PowerEval {
     return w != CHOMP_P_LIN && !(halofit && w == CHOMP_P_MM);
   }
   // after the barrier: k < k_min constant (halo.py:314-317)
-  __device__ __forceinline__ void finish() {
+  template <bool BAO>
+  __device__ __forceinline__ void finish_t() {
     amp2 = E->amp * E->sigma_norm * E->sigma_norm;
     if (w != CHOMP_P_LIN && !halofit) {
       const double ha = pp_poly(ca, 0, 0.0), hb = pp_poly(cb, 0, 0.0), p0 = pp_poly(cp, 0, 0.0);
-      c_lo = ha * hb + p0 / linear_power(*E, k_min);
+      c_lo = ha * hb + p0 / linear_power_t<BAO>(*E, k_min);
     }
   }
-  __device__ __forceinline__ double operator()(double kv) const {
-    if (w == CHOMP_P_LIN) return linear_power(*E, kv);
+  // (the projection kernels only run on no-wiggle contexts)
+  __device__ __forceinline__ void finish() { finish_t<false>(); }
+  __device__ __forceinline__ double operator()(double kv) const { return eval_t<false>(kv); }
+  template <bool BAO>
+  __device__ __forceinline__ double eval_t(double kv) const {
+    if (w == CHOMP_P_LIN) return linear_power_t<BAO>(*E, kv);
     if (halofit) {
       const double pmm = halofit_mm(*E, kv);
       if (w == CHOMP_P_MM) return pmm;
@@ -133,16 +141,16 @@ struct PowerEval {
       }
       return pmm * ha * hb + pp;
     }
-    if (kv < k_min) return linear_power(*E, kv) * c_lo;
+    if (kv < k_min) return linear_power_t<BAO>(*E, kv) * c_lo;
     if (extrap ? kv < k_max : kv <= k_max) {
       const double lk = log(kv);
       const double ha = spline_eval_uniform(x0, dx, ca, NK, lk);
       const double hb = spline_eval_uniform(x0, dx, cb, NK, lk);
       const double pp = spline_eval_uniform(x0, dx, cp, NK, lk);
-      const double plin = 2.0 * kPi * kPi * delta_k_ln(*E, lk, kv) / (kv * kv * kv);
+      const double plin = 2.0 * kPi * kPi * delta_k_ln_t<BAO>(*E, lk, kv) / (kv * kv * kv);
       return plin * ha * hb + pp;
     }
-    if (extrap) return power_tail(*E, tail, w, kv, k_max);
+    if (extrap) return power_tail<BAO>(*E, tail, w, kv, k_max);
     return 0.0;                                           // k > k_max (or NaN)
   }
   // The same spectrum for callers that integrate over ln k (w(theta), xi(r)) and so hold
@@ -168,13 +176,14 @@ struct PowerEval {
     i = i < 0 ? 0 : (i > NK - 2 ? NK - 2 : i);
     const double d = lk - (x0 + dx * (double)i);
     const double ha = pp_poly(ca, i, d), hb = pp_poly(cb, i, d), pp = pp_poly(cp, i, d);
-    return amp2 * power_shape(*E, lk, kv) * ha * hb + pp;
+    return amp2 * power_shape_t<false>(*E, lk, kv) * ha * hb + pp;
   }
 };
 
 // Halo(extrapolate=True): the constants of the continuation above k_max, from the knot
 // tables of spectrum w (halo.py:300-312: misc[3]; :341-352 / :405-416: value at k_max and
 // mean log-slope over knots -7..-1 into misc[4,5] (gm) / misc[6,7] (gg)).  grid n, block 64.
+template <bool BAO>
 __global__ void k_power_extrap(chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs,
                                double* __restrict__ tab, int w, int epoch0) {
   __shared__ double lv[6], lx[6];
@@ -191,11 +200,11 @@ __global__ void k_power_extrap(chomp_config cfg, TabLayout L, const Epoch* __res
     const int j = NK - 7 + i;
     const double x = linspace_at(log(cfg.k_min), log(cfg.k_max), NK, j);
     lx[i] = x;
-    lv[i] = log(linear_power(E, exp(x)) * ka[j] * kb[j] + kp[j]);
+    lv[i] = log(linear_power_t<BAO>(E, exp(x)) * ka[j] * kb[j] + kp[j]);
   }
   __syncthreads();
   if (i == 0) {
-    const double plin = linear_power(E, cfg.k_max);
+    const double plin = linear_power_t<BAO>(E, cfg.k_max);
     const double ha = ka[NK - 1], hb = kb[NK - 1], pp = kp[NK - 1];
     if (w == CHOMP_P_MM) {
       t[L.off_misc + 3] = ha * hb + pp / plin;
@@ -209,6 +218,7 @@ __global__ void k_power_extrap(chomp_config cfg, TabLayout L, const Epoch* __res
   }
 }
 
+template <bool BAO>
 __global__ __launch_bounds__(256) void k_power(chomp_config cfg, TabLayout L,
                                                const Epoch* __restrict__ epochs,
                                                const double* __restrict__ tab, int which,
@@ -222,11 +232,11 @@ __global__ __launch_bounds__(256) void k_power(chomp_config cfg, TabLayout L,
   PowerEval P;
   P.stage(cfg, L, &E, tab + (size_t)e * L.stride, which, sm);
   __syncthreads();
-  P.finish();
+  P.template finish_t<BAO>();
   double* o = out + (size_t)blockIdx.y * nk;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nk;
        i += (size_t)gridDim.x * blockDim.x)
-    o[i] = P(k[i]);
+    o[i] = P.template eval_t<BAO>(k[i]);
 }
 
 // ---------------------------------------------------------------------------
@@ -243,25 +253,26 @@ __global__ __launch_bounds__(256) void k_power(chomp_config cfg, TabLayout L,
 // Algorithmic traffic: 8 B read per k + 8 B written per (k, epoch) sample.
 // ---------------------------------------------------------------------------
 // P(k) of epoch table t for one k on the per-lane path (any k, any interval).
+template <bool BAO>
 __device__ __forceinline__ double power_lane(const chomp_config& cfg, const TabLayout& L,
                                              const Epoch& E, const double* t, int fa, int fb,
                                              int fp, int w, bool extrap, double kv) {
-  if (w == CHOMP_P_LIN) return linear_power(E, kv);
+  if (w == CHOMP_P_LIN) return linear_power_t<BAO>(E, kv);
   const double x0 = log(cfg.k_min);
   const double dx = (log(cfg.k_max) - x0) / (double)(L.NK - 1);
   if (kv < cfg.k_min) {
     const double c_lo = t[L.off_kpp[fa]] * t[L.off_kpp[fb]] +
-                        t[L.off_kpp[fp]] / linear_power(E, cfg.k_min);
-    return linear_power(E, kv) * c_lo;
+                        t[L.off_kpp[fp]] / linear_power_t<BAO>(E, cfg.k_min);
+    return linear_power_t<BAO>(E, kv) * c_lo;
   }
   if (extrap ? kv < cfg.k_max : kv <= cfg.k_max) {
     const double lk = log(kv);
     const double ha = spline_eval_uniform(x0, dx, t + L.off_kpp[fa], L.NK, lk);
     const double hb = spline_eval_uniform(x0, dx, t + L.off_kpp[fb], L.NK, lk);
     const double pp = spline_eval_uniform(x0, dx, t + L.off_kpp[fp], L.NK, lk);
-    return 2.0 * kPi * kPi * delta_k_ln(E, lk, kv) / (kv * kv * kv) * ha * hb + pp;
+    return 2.0 * kPi * kPi * delta_k_ln_t<BAO>(E, lk, kv) / (kv * kv * kv) * ha * hb + pp;
   }
-  if (extrap) return power_tail(E, t + L.off_misc + 3, w, kv, cfg.k_max);
+  if (extrap) return power_tail<BAO>(E, t + L.off_misc + 3, w, kv, cfg.k_max);
   return 0.0;
 }
 
@@ -333,6 +344,7 @@ __device__ __forceinline__ void slow_list_append(int* slow, int parity, int k_gr
 // The row-walking streaming pass (epochs of different cosmologies, or small grids).
 // grid (ceil(nk / 512), ceil(n_epoch / epochs_per_y)), block 256.  A wavefront whose k
 // do not qualify for the fast path only enters itself in the slow list.
+template <bool BAO>
 __global__ __launch_bounds__(256) void k_power_grid(chomp_config cfg, TabLayout L,
                                                     const Epoch* __restrict__ epochs,
                                                     const double* __restrict__ tab, int w,
@@ -397,8 +409,8 @@ __global__ __launch_bounds__(256) void k_power_grid(chomp_config cfg, TabLayout 
     const bool same = j > 0 && qc > q_lo && c.flag != 0.0;
     if (!same) {
       const Epoch& E = epochs[epoch0 + qc];
-      shape0 = power_shape(E, s.lk0, k0);
-      shape1 = power_shape(E, s.lk1, k1);
+      shape0 = power_shape_t<BAO>(E, s.lk0, k0);
+      shape1 = power_shape_t<BAO>(E, s.lk1, k1);
     }
     double ha0 = fma(fma(fma(c.a3, d0, c.a2), d0, c.a1), d0, c.a0);
     double pp0 = fma(fma(fma(c.p3, d0, c.p2), d0, c.p1), d0, c.p0);
@@ -454,6 +466,7 @@ constexpr int kWaveIdxMask = 0xffff, kWaveSlow = 1 << 16, kWaveTwo = 1 << 17;
 // grid roundup8(ceil(nk / 512)), block 256.  ktab[2 i] = ln k_i - x_idx, ktab[2 i + 1] = shape_i,
 // negative when k_i lies in the upper one of the wavefront's two knot intervals;
 // winfo[g] = lowest knot interval of k group g | kWaveTwo | kWaveSlow.
+template <bool BAO>
 __global__ __launch_bounds__(256) void k_power_prep(chomp_config cfg, TabLayout L,
                                                     const Epoch* __restrict__ epochs,
                                                     int e_shape, int w,
@@ -482,7 +495,7 @@ __global__ __launch_bounds__(256) void k_power_prep(chomp_config cfg, TabLayout 
   const double dx = (log(cfg.k_max) - x0) / (double)(NK - 1);
   const bool s0 = s.idx0 != idxu, s1 = s.idx1 != idxu;
   const double xa = x0 + dx * (double)idxu, xb = x0 + dx * (double)(idxu + 1);
-  const double sh0 = power_shape(E, s.lk0, s.k0), sh1 = power_shape(E, s.lk1, s.k1);
+  const double sh0 = power_shape_t<BAO>(E, s.lk0, s.k0), sh1 = power_shape_t<BAO>(E, s.lk1, s.k1);
   double4 v;
   v.x = s.lk0 - (s0 ? xb : xa); v.y = s0 ? -sh0 : sh0;
   v.z = s.lk1 - (s1 ? xb : xa); v.w = s1 ? -sh1 : sh1;
@@ -568,6 +581,7 @@ __global__ __launch_bounds__(256) void k_power_stream(TabLayout L, const double*
 // per-epoch coefficient loads of this path are a dependent chain), a fully listed grid
 // -> one item per group.  In-range k still re-use the Eisenstein-Hu shape across epochs
 // of one cosmology; k outside [k_min, k_max] take the full formula (halo.py:314-320).
+template <bool BAO>
 __global__ __launch_bounds__(256) void k_power_grid_lanes(
     chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs,
     const double* __restrict__ tab, int w, bool extrap, int epoch0, int n_epoch,
@@ -602,8 +616,8 @@ __global__ __launch_bounds__(256) void k_power_grid_lanes(
       const bool same = q > q_lo && t[L.off_misc + 2] != 0.0;
       const double A = t[L.off_misc + 1];
       if (!same && w != CHOMP_P_LIN) {
-        sh0 = power_shape(E, s.lk0, s.k0);
-        sh1 = power_shape(E, s.lk1, s.k1);
+        sh0 = power_shape_t<BAO>(E, s.lk0, s.k0);
+        sh1 = power_shape_t<BAO>(E, s.lk1, s.k1);
       }
       if (s.have0) {
         double r;
@@ -613,7 +627,7 @@ __global__ __launch_bounds__(256) void k_power_grid_lanes(
           const double pp = pp_poly(t + L.off_kpp[F.fp], s.idx0, e0);
           r = fma(A * sh0, ha * hb, pp);
         } else {
-          r = power_lane(cfg, L, E, t, F.fa, F.fb, F.fp, w, extrap, s.k0);
+          r = power_lane<BAO>(cfg, L, E, t, F.fa, F.fb, F.fp, w, extrap, s.k0);
         }
         o[0] = r;
       }
@@ -625,7 +639,7 @@ __global__ __launch_bounds__(256) void k_power_grid_lanes(
           const double pp = pp_poly(t + L.off_kpp[F.fp], s.idx1, e1);
           r = fma(A * sh1, ha * hb, pp);
         } else {
-          r = power_lane(cfg, L, E, t, F.fa, F.fb, F.fp, w, extrap, s.k1);
+          r = power_lane<BAO>(cfg, L, E, t, F.fa, F.fb, F.fp, w, extrap, s.k1);
         }
         o[1] = r;
       }
@@ -634,6 +648,7 @@ __global__ __launch_bounds__(256) void k_power_grid_lanes(
 }
 
 // sigma_r at arbitrary scales (SingleEpoch.sigma_r): grid n, block 256.
+template <bool BAO>
 __global__ __launch_bounds__(256) void k_sigma_r(chomp_config cfg,
                                                  const Epoch* __restrict__ epochs, int e,
                                                  const double* __restrict__ scale,
@@ -644,7 +659,7 @@ __global__ __launch_bounds__(256) void k_sigma_r(chomp_config cfg,
   copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
                kEpochDoubles);
   __syncthreads();
-  const double s2 = sigma2_block<4>(E, snodes + (size_t)E.cosmo_slot * kSigmaStride, scale[blockIdx.x], cfg,
+  const double s2 = sigma2_block<4, 1, BAO>(E, snodes + (size_t)E.cosmo_slot * kSigmaStride, scale[blockIdx.x], cfg,
                                     cfg.cosmo_precision, red);
   if (threadIdx.x == 0) out[blockIdx.x] = sqrt(s2);
 }
@@ -698,7 +713,9 @@ __global__ void k_eval(TabLayout L, const Epoch* __restrict__ epochs, int e,
       case CHOMP_EV_HOD_SATELLITE: r = zheng_satellite(E, v); break;
       case CHOMP_EV_VIRIAL_RADIUS: r = exp((E.ln_rv_const + log(v)) * (1.0 / 3.0)); break;
       case CHOMP_EV_CONCENTRATION: r = exp(E.ln_c_const + E.beta * log(v)); break;
-      case CHOMP_EV_DELTA_K: r = delta_k_ln(E, log(v), v); break;
+      case CHOMP_EV_DELTA_K:
+        r = E.with_bao ? delta_k_ln_t<true>(E, log(v), v) : delta_k_ln_t<false>(E, log(v), v);
+        break;
       default: r = 0.0;
     }
     out[i] = r;

@@ -88,9 +88,10 @@ class Halo(object):
         if self._ctx is None:
             self._ctx = cosmology._context()
         ctx = self._ctx
-        esig = (tuple(sorted(self.cosmo.cosmo_dict.items())), self.cosmo._redshift)
+        bao = bool(getattr(self.cosmo, "_with_bao", False))
+        esig = (tuple(sorted(self.cosmo.cosmo_dict.items())), self.cosmo._redshift, bao)
         if esig != self._epoch_sig:
-            ctx.epochs_set(self.cosmo.cosmo_dict, [self.cosmo._redshift])
+            ctx.epochs_set(self.cosmo.cosmo_dict, [self.cosmo._redshift], bao)
             self._epoch_sig = esig
             self._mass_sig = None
             self._nbar_valid = False

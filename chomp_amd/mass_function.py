@@ -38,7 +38,8 @@ class MassFunction(object):
         if self._ctx is None:
             self._ctx = cosmology._context()
         if sig != self._sig:
-            self._ctx.epochs_set(self.cosmo.cosmo_dict, [self.cosmo._redshift])
+            self._ctx.epochs_set(self.cosmo.cosmo_dict, [self.cosmo._redshift],
+                                 getattr(self.cosmo, "_with_bao", False))
             self._ctx.mass_setup(self.halo_dict, self._kind)
             self._sc = self._ctx.scalars(0)
             self._sig = sig

@@ -324,6 +324,14 @@ int chomp_wtheta(chomp_ctx* ctx, int which, size_t epoch, double k_min,
 int chomp_cell(chomp_ctx* ctx, int which, size_t epoch, double D_z,
                const double* ell, size_t n, double* out, int mem);
 
+/* SingleEpoch(..., with_bao=...) (cosmology.py:39, 87, 556-572): which Eisenstein & Hu
+ * transfer function the context's epochs use -- the no-wiggle fit (default,
+ * cosmology.py:449-472) or the one with baryon wiggles (cosmology.py:474-538).  Call it
+ * before chomp_epochs_set; changing it invalidates every table. */
+#define CHOMP_TRANSFER_EH 0
+#define CHOMP_TRANSFER_EH_BAO 1
+int chomp_set_transfer(chomp_ctx* ctx, int kind);
+
 /* Halo.calculate_bias / calculate_m_eff / calculate_f_sat (halo.py:709-838) of epochs
  * [epoch0, epoch0 + n): out[3 i + {0, 1, 2}] = effective bias, effective halo mass,
  * satellite fraction (host buffer).  Needs chomp_halo_setup (n_bar). */

@@ -77,8 +77,8 @@ def _rom(f, a, b, rtol, prec, args=()):
 # ---------------------------------------------------------------------------
 # L1: single-epoch cosmology (cosmology.py:25-728)
 # ---------------------------------------------------------------------------
-def epoch(cosmo_dict=None, redshift=0.0, limits=None, prec=None):
-    """cosmology.py:39-119."""
+def epoch(cosmo_dict=None, redshift=0.0, limits=None, prec=None, with_bao=False):
+    """cosmology.py:39-119.  with_bao: the E&H transfer function with wiggles (:474-538)."""
     cd = default_cosmo_dict if cosmo_dict is None else cosmo_dict
     lim = default_limits if limits is None else limits
     prec = default_precision if prec is None else prec
@@ -86,7 +86,7 @@ def epoch(cosmo_dict=None, redshift=0.0, limits=None, prec=None):
         raise NotImplementedError("w(z) != -1 is outside the hot-path scope")
     if redshift < 0.0:
         redshift = 0.0
-    e = Table(cosmo_dict=cd, z=redshift, prec=prec, limits=lim)
+    e = Table(cosmo_dict=cd, z=redshift, prec=prec, limits=lim, with_bao=bool(with_bao))
     e.om0, e.ob0, e.ol0, e.or0 = (cd["omega_m0"], cd["omega_b0"],
                                   cd["omega_l0"], cd["omega_r0"])
     e.tcmb, e.h, e.sigma_8, e.n = (cd["cmb_temp"], cd["h"], cd["sigma_8"],
@@ -168,6 +168,54 @@ def rho_bar(e):
     return rho_crit(e) * omega_m(e)                          # :440-447
 
 
+def eh_bao_transfer(e, k):
+    """cosmology.py:474-538: Eisenstein & Hu (1998) with baryon wiggles, as the reference
+    writes it (the second b1, b2 belong to beta_c; T0t's denominator takes q(k))."""
+    k = numpy.asarray(k, dtype=float)
+    theta = e.tcmb / 2.7
+    Ob, Om = e.ob0, e.om0
+    Oc, O, h = Om - Ob, Om, e.h
+    Obh2, Oh2, ObO = Ob * h ** 2, O * h ** 2, Ob / O
+    zeq = 2.5e4 * Oh2 * theta ** (-4)
+    keq = 7.46e-2 * Oh2 * theta ** (-2)
+    b1 = 0.313 * Oh2 ** (-0.419) * (1. + 0.607 * Oh2 ** 0.674)
+    b2 = 0.238 * Oh2 ** 0.223
+    zd = 1291. * (Oh2 ** 0.251 / (1. + 0.659 * Oh2 ** 0.828)) * (1. + b1 * Obh2 ** b2)
+    R = lambda z: 31.5 * Obh2 * theta ** (-4) * (1000. / z)
+    Req, Rd = R(zeq), R(zd)
+    s = (2. / (3. * keq)) * numpy.sqrt(6. / Req) * numpy.log(
+        (numpy.sqrt(1. + Rd) + numpy.sqrt(Rd + Req)) / (1. + numpy.sqrt(Req)))
+    ks = k * h * s
+    kSilk = 1.6 * Obh2 ** 0.52 * Oh2 ** 0.73 * (1. + (10.4 * Oh2) ** (-0.95))
+    q = k * h / (13.41 * keq)
+    G = lambda y: y * (-6. * numpy.sqrt(1. + y) + (2 + 3 * y) * numpy.log(
+        (numpy.sqrt(1. + y) + 1.) / (numpy.sqrt(1. + y) - 1.)))
+    alpha_b = 2.07 * keq * s * (1. + Rd) ** (-3. / 4.) * G((1. + zeq) / (1. + zd))
+    beta_b = 0.5 + ObO + (3. - 2. * ObO) * numpy.sqrt((17.2 * Oh2) ** 2 + 1.)
+    C = lambda a: (14.2 / a) + 386. / (1. + 69.9 * q ** 1.08)
+    T0t = lambda a, b: numpy.log(numpy.e + 1.8 * b * q) / (
+        numpy.log(numpy.e + 1.8 * b * q) + C(a) * q ** 2)
+    a1 = (46.9 * Oh2) ** 0.670 * (1. + (32.1 * Oh2) ** (-0.532))
+    a2 = (12. * Oh2) ** 0.424 * (1. + (45. * Oh2) ** (-0.582))
+    alpha_c = a1 ** (-ObO) * a2 ** (-ObO ** 3)
+    b1 = 0.944 * (1. + (458. * Oh2) ** (-0.708)) ** (-1)
+    b2 = (0.395 * Oh2) ** (-0.0266)
+    beta_c = 1. / (1. + b1 * ((Oc / O) ** b2 - 1))
+    f = 1. / (1. + (ks / 5.4) ** 4)
+    Tc = f * T0t(1, beta_c) + (1. - f) * T0t(alpha_c, beta_c)
+    beta_node = 8.41 * (Oh2 ** 0.435)
+    stilde = s / (1. + (beta_node / ks) ** 3) ** (1. / 3.)
+    Tb1 = T0t(1., 1.) / (1. + (ks / 5.2) ** 2)
+    Tb2 = (alpha_b / (1. + (beta_b / ks) ** 3)) * numpy.exp(-(k * h / kSilk) ** 1.4)
+    Tb = numpy.sinc(k * stilde / numpy.pi) * (Tb1 + Tb2)
+    return ObO * Tb + (Oc / O) * Tc
+
+
+def transfer_function(e, k):
+    """cosmology.py:556-572."""
+    return eh_bao_transfer(e, k) if getattr(e, "with_bao", False) else eh_transfer(e, k)
+
+
 def eh_transfer(e, k):
     """cosmology.py:449-472, with the reference's deviations from EH98 kept:
     (Omb2)**(3/4) -> **0 under Py2, (1+0.43ks)**4, q = k*theta/Gamma."""
@@ -187,7 +235,7 @@ def eh_transfer(e, k):
 
 def delta_k(e, k):
     """cosmology.py:574-587."""
-    d = (e.delta_H ** 2 * (k / e.H0) ** (3 + e.n) * eh_transfer(e, k) ** 2) / e.h
+    d = (e.delta_H ** 2 * (k / e.H0) ** (3 + e.n) * transfer_function(e, k) ** 2) / e.h
     return d * (e.growth * e.growth * e.sigma_norm * e.sigma_norm)
 
 

@@ -322,6 +322,20 @@ def g10(ns):
     save("g10_hod_stats", **out)
 
 
+def g11(ns):
+    """SingleEpoch(with_bao=True) (cosmology.py:474-538, 556-572) and a Halo built on it."""
+    k = numpy.logspace(-3, 2, 64)
+    out = {"k": k, "z": numpy.array(0.3), "scale": numpy.array([0.5, 8.0, 30.0])}
+    c = ns.cosmology.SingleEpoch(0.3, with_bao=True)
+    out.update(transfer=c.transfer_function(k), linear=c.linear_power(k),
+               sigma_r=numpy.array([c.sigma_r(x) for x in out["scale"]]),
+               sigma_norm=numpy.array(c._sigma_norm))
+    h = ns.halo.Halo(0.3, cosmo_single_epoch=c)
+    out.update(power_mm=h.power_mm(k), power_gm=h.power_gm(k),
+               ln_mass=h.mass._ln_mass_array, nu=h.mass._nu_array)
+    save("g11_bao", **out)
+
+
 def pins():
     """Known-answer literals held by the reference's own tests (unit_test.py),
     restricted to the classes that pass against the shipped code."""
@@ -354,7 +368,7 @@ def pins():
 
 
 def main():
-    names = sys.argv[1:] or ["pins", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    names = sys.argv[1:] or ["pins", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     ns = ref_loader.load()
     cwd = os.getcwd()
     with tempfile.TemporaryDirectory() as tmp:

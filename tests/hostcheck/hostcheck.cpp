@@ -67,6 +67,14 @@ void hc_epoch(const double* cosmo, double z, double sigma_norm, Epoch* e) {
   epoch_background(*e, 1.48e-8, 0.001, 100.0);
   e->sigma_norm = sigma_norm;
 }
+void hc_epoch_bao(const double* cosmo, double z, double sigma_norm, Epoch* e) {
+  hc_epoch(cosmo, z, sigma_norm, e);
+  epoch_background(*e, 1.48e-8, 0.001, 100.0, 1);
+  e->sigma_norm = sigma_norm;
+}
+void hc_transfer(const Epoch* e, const double* k, int n, double* out) {
+  for (int i = 0; i < n; ++i) out[i] = transfer_function(*e, k[i]);
+}
 int hc_sizeof_epoch() { return (int)sizeof(Epoch); }
 void hc_linear_power(const Epoch* e, const double* k, int n, double* out) {
   for (int i = 0; i < n; ++i) out[i] = linear_power(*e, k[i]);

@@ -168,6 +168,27 @@ def test_background_and_linear_power(hc, z):
         assert numpy.max(numpy.abs(got - ref)) < 1e-9 * numpy.max(ref)
 
 
+def test_bao_transfer_function(hc):
+    """cosmology.py:474-538 against the oracle (itself equal to the reference, G11)."""
+    z = 0.3
+    e = o.epoch(None, z, with_bao=True)
+    n = hc.hc_sizeof_epoch()
+    buf = (ctypes.c_char * n)()
+    cd = o.default_cosmo_dict
+    c = numpy.array([cd[k] for k in ("omega_m0", "omega_b0", "omega_l0", "omega_r0",
+                                     "cmb_temp", "h", "sigma_8", "n_scalar")])
+    hc.hc_epoch_bao(_p(c), ctypes.c_double(z), ctypes.c_double(e.sigma_norm), buf)
+    k = numpy.logspace(-5, 4, 700)
+    out = numpy.empty_like(k)
+    hc.hc_transfer(buf, _p(k), k.size, _p(out))
+    assert rel_err(out, o.eh_bao_transfer(e, k)) < 5e-13
+    hc.hc_linear_power(buf, _p(k), k.size, _p(out))
+    assert rel_err(out, o.linear_power(e, k)) < 1e-12
+    hc.hc_power_shape(buf, _p(k), k.size, _p(out))
+    assert rel_err(out, o.linear_power(e, k)) < 1e-12
+    assert rel_err(o.eh_bao_transfer(e, k), o.eh_transfer(e, k)) > 0.05      # wiggles are there
+
+
 def test_y_nfw_mass_function_hod(hc):
     z = 0.5
     e = o.epoch(None, z)

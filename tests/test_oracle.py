@@ -241,3 +241,15 @@ def test_g10_hod_stats():
             bias, m_eff, f_sat = o.hod_stats(t)
             assert numpy.allclose([bias, m_eff, t.n_bar], g["%s_%d" % (tag, i)], rtol=1e-12)
             assert 0.05 < f_sat < 0.5
+
+
+def test_g11_bao_transfer():
+    """SingleEpoch(with_bao=True) (cosmology.py:474-538, 556-572) and a Halo on top of it."""
+    g = load_golden("g11_bao")
+    e = o.epoch(None, float(g["z"]), with_bao=True)
+    assert rel_err(o.transfer_function(e, g["k"]), g["transfer"]) < 1e-13
+    assert rel_err(o.linear_power(e, g["k"]), g["linear"]) < 1e-12
+    assert abs(e.sigma_norm / float(g["sigma_norm"]) - 1) < 1e-12
+    assert rel_err(numpy.array([o.sigma_r(e, x) for x in g["scale"]]), g["sigma_r"]) < 1e-12
+    m = o.mass_table(e)
+    assert numpy.array_equal(m.ln_mass, g["ln_mass"]) and rel_err(m.nu_arr, g["nu"]) < 1e-12
