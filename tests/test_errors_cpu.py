@@ -18,8 +18,10 @@ def test_missing_keys_raise_keyerror():
 
 def test_scope_errors():
     from chomp_amd import cosmology, halo, kernel, _lib
-    with pytest.raises(_lib.ChompScopeError):
-        cosmology.SingleEpoch(0.0, with_bao=True)
+    c = cosmology.SingleEpoch(0.0, with_bao=True)     # accelerated
+    assert c._with_bao is True
+    c.set_cosmology(dict(c.cosmo_dict))               # re-runs __init__: drops it, as the reference
+    assert c._with_bao is False
     h = halo.Halo(0.0, extrapolate=True)          # accelerated since SURVEY 8(f) rank 2
     assert h.get_extrapolation() and (h._power_code(_lib.P_GM) & _lib.P_EXTRAPOLATE)
     assert h._power_code(_lib.P_LIN) == _lib.P_LIN
