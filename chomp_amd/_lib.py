@@ -97,7 +97,7 @@ EXPORTS = [
     "chomp_kernel_setup", "chomp_kernel_info", "chomp_kernel_table",
     "chomp_kernel_eval", "chomp_window_eval", "chomp_wtheta", "chomp_cell",
     "chomp_set_precision", "chomp_xi3d", "chomp_spline_eval", "chomp_hod_stats",
-    "chomp_set_transfer",
+    "chomp_set_transfer", "chomp_kernel_raw",
 ]
 
 
@@ -201,6 +201,7 @@ def lib():
         L.chomp_kernel_info.argtypes = [vp, c_double_p]
         L.chomp_kernel_table.argtypes = [vp, i, c_double_p, sz]
         L.chomp_kernel_eval.argtypes = [vp, vp, sz, vp, i]
+        L.chomp_kernel_raw.argtypes = [vp, vp, sz, vp, i]
         L.chomp_window_eval.argtypes = [vp, i, vp, sz, vp, i]
         L.chomp_wtheta.argtypes = [vp, i, sz, d, d, d, vp, sz, vp, i]
         L.chomp_cell.argtypes = [vp, i, sz, d, vp, sz, vp, i]
@@ -492,6 +493,9 @@ class Context(object):
 
     def kernel_eval(self, ln_ktheta):
         return self._map1(self._L.chomp_kernel_eval, ln_ktheta)
+
+    def kernel_raw(self, ln_ktheta):
+        return self._map1(self._L.chomp_kernel_raw, ln_ktheta)
 
     def window_eval(self, which, chi):
         return self._map1(self._L.chomp_window_eval, chi, int(which))

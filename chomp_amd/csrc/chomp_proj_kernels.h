@@ -402,7 +402,11 @@ struct KernelIntegrand {
 __global__ __launch_bounds__(256) void k_proj_kernel_knots(chomp_config cfg, ProjLayout L,
                                                            const ProjDev* __restrict__ pdg,
                                                            double* __restrict__ tab,
-                                                           const BesselTab* __restrict__ bess_g) {
+                                                           const BesselTab* __restrict__ bess_g,
+                                                           const double* __restrict__ ln_in,
+                                                           double* __restrict__ out) {
+  // ln_in == nullptr: the 50 knots of the spline table (Kernel._initialize_spline);
+  // otherwise Kernel.raw_kernel at the caller's ln(k theta), results into `out`.
   extern __shared__ __align__(16) double sm[];
   __shared__ ProjDev pd;
   __shared__ BesselTab B;
@@ -416,7 +420,7 @@ __global__ __launch_bounds__(256) void k_proj_kernel_knots(chomp_config cfg, Pro
   P.bess = &B;
   __syncthreads();
   const int i = blockIdx.x;
-  const double ktheta = exp(tab[L.k_ln + i]);
+  const double ktheta = exp(ln_in ? ln_in[i] : tab[L.k_ln + i]);
   double chi_max = pd.j_limit / ktheta;                            // kernel.py:689-691
   if (chi_max >= pd.chi_max) chi_max = pd.chi_max;
   int level = 0;
@@ -431,8 +435,12 @@ __global__ __launch_bounds__(256) void k_proj_kernel_knots(chomp_config cfg, Pro
                     cfg.divmax, red, &level);
   }
   if (threadIdx.x == 0) {
-    tab[L.k_arr + i] = v;
-    tab[L.k_lev + i] = (double)level;
+    if (out) {
+      out[i] = v;
+    } else {
+      tab[L.k_arr + i] = v;
+      tab[L.k_lev + i] = (double)level;
+    }
   }
 }
 

@@ -282,6 +282,17 @@ class Kernel(object):
     def kernel(self, ln_ktheta):
         return self._dev().kernel_eval(numpy.asarray(ln_ktheta, dtype=numpy.float64))
 
+    def raw_kernel(self, ln_ktheta):
+        """kernel.py:678-704: the chi integral at ln(k theta) itself (no spline)."""
+        x = numpy.asarray(ln_ktheta, dtype=numpy.float64)
+        out = self._dev().kernel_raw(numpy.ascontiguousarray(x).ravel())
+        return float(out[0]) if x.ndim == 0 else out.reshape(x.shape)
+
+    def kernel_weighted_mean(self, function):
+        raise _lib.ChompScopeError(
+            "kernel_weighted_mean (kernel.py:731-753) integrates a Python callable: "
+            "outside the accelerated scope")
+
 
 class GalaxyGalaxyLensingKernel(Kernel):
     """J2 variant (kernel.py:784-839)."""

@@ -306,6 +306,10 @@ int chomp_kernel_info(chomp_ctx* ctx, double* out);
 #define CHOMP_KTAB_LEVELS 9
 int chomp_kernel_table(chomp_ctx* ctx, int table, double* out, size_t n);
 
+/* Kernel.raw_kernel(ln_ktheta) (kernel.py:678-704): the projection integral itself, not
+ * its 50-knot spline. */
+int chomp_kernel_raw(chomp_ctx* ctx, const double* ln_ktheta, size_t n,
+                     double* out, int mem);
 /* Kernel.kernel(ln_ktheta) (kernel.py:714-729); argument is ln(k*theta). */
 int chomp_kernel_eval(chomp_ctx* ctx, const double* ln_ktheta, size_t n,
                       double* out, int mem);

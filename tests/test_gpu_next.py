@@ -258,3 +258,23 @@ def test_bao_transfer_function():
     assert c._with_bao is False
     plain = cosmology.SingleEpoch(z)
     assert rel_err(c.linear_power(k), plain.linear_power(k)) < 1e-12
+
+
+def test_raw_kernel():
+    """kernel.py:678-704: raw_kernel is the chi integral itself; at the table knots it is
+    the tabulated value bit for bit, between them it is what the spline approximates."""
+    from chomp_amd import kernel
+    d = kernel.dNdzMagLim(0.0, 2.0, 2.0, 0.3, 2.0)
+    w = kernel.WindowFunctionGalaxy(d)
+    wl = kernel.WindowFunctionConvergence(kernel.dNdzGaussian(0.0, 2.0, 1.0, 0.2))
+    for kern in (kernel.Kernel(1e-5, 1.0, w, w),
+                 kernel.GalaxyGalaxyLensingKernel(1e-5, 1.0, w, wl)):
+        knots, tab = kern._ln_ktheta_array, kern._kernel_array
+        assert numpy.array_equal(kern.raw_kernel(knots), tab)
+        mid = 0.5 * (knots[:-1] + knots[1:])[::7]
+        raw = kern.raw_kernel(mid)
+        scale = numpy.max(numpy.abs(tab))
+        assert numpy.max(numpy.abs(raw - kern.kernel(mid))) < 1e-2 * scale   # spline error of 200 knots
+        assert isinstance(kern.raw_kernel(float(mid[0])), float)
+    with pytest.raises(Exception):
+        kern.kernel_weighted_mean(lambda z: z)
