@@ -3,6 +3,7 @@
 Drop-in mirrors of the reference's modules (same class, keyword and method names):
 
     from chomp_amd import cosmology, mass_function, hod, halo, kernel, correlation
+    from chomp_amd import covariance, simulation_design
 
 plus the batched entry point the reference lacks, ``chomp_amd.grid.HaloGrid``:
 P(k, z) on a whole (k, z) grid -- or a batch of cosmologies -- in one set of kernel
@@ -17,12 +18,13 @@ from . import defaults
 from ._lib import ChompError, ChompScopeError, build
 
 __all__ = ["defaults", "cosmology", "mass_function", "hod", "halo", "kernel",
-           "correlation", "grid", "build", "ChompError", "ChompScopeError"]
+           "correlation", "covariance", "simulation_design", "grid", "build",
+           "ChompError", "ChompScopeError"]
 
 
 def __getattr__(name):
     if name in ("cosmology", "mass_function", "hod", "halo", "kernel",
-                "correlation", "grid"):
+                "correlation", "covariance", "simulation_design", "grid"):
         import importlib
         return importlib.import_module("." + name, __name__)
     raise AttributeError(name)

@@ -98,6 +98,7 @@ EXPORTS = [
     "chomp_kernel_eval", "chomp_window_eval", "chomp_wtheta", "chomp_cell",
     "chomp_set_precision", "chomp_xi3d", "chomp_spline_eval", "chomp_hod_stats",
     "chomp_set_transfer", "chomp_kernel_raw",
+    "chomp_covariance_table", "chomp_covariance_gaussian",
 ]
 
 
@@ -208,6 +209,9 @@ def lib():
         L.chomp_set_precision.argtypes = [vp, i]
         L.chomp_hod_stats.argtypes = [vp, sz, sz, c_double_p]
         L.chomp_set_transfer.argtypes = [vp, i]
+        L.chomp_covariance_table.argtypes = [vp, i, sz, d, c_double_p, c_double_p,
+                                             c_double_p, sz]
+        L.chomp_covariance_gaussian.argtypes = [vp, d, d, d, d, vp, sz, vp, i]
         L.chomp_xi3d.argtypes = [vp, i, sz, d, d, vp, sz, vp, i]
         L.chomp_spline_eval.argtypes = [vp, c_double_p, c_double_p, sz, c_double_p, sz, i,
                                         c_double_p]
@@ -503,6 +507,28 @@ class Context(object):
     def wtheta(self, which, epoch, k_min, k_max, D_z, theta):
         return self._map1(self._L.chomp_wtheta, theta, int(which), epoch,
                           float(k_min), float(k_max), float(D_z))
+
+    def covariance_table(self, which, epoch, D_z):
+        """(ln_K, projected spectrum, Romberg levels), each [kernel_npoints]."""
+        n = self.config.kernel_npoints
+        ln_K, proj, lev = numpy.empty(n), numpy.empty(n), numpy.empty(n)
+        self._check(self._L.chomp_covariance_table(
+            self._h, int(which), epoch, float(D_z), ln_K.ctypes.data_as(c_double_p),
+            proj.ctypes.data_as(c_double_p), lev.ctypes.data_as(c_double_p), n))
+        return ln_K, proj, lev.astype(int)
+
+    def covariance_gaussian(self, j0_limit, area, poisson_a, poisson_b, theta_a, theta_b):
+        ta = numpy.ascontiguousarray(theta_a, dtype=numpy.float64).ravel()
+        tb = numpy.ascontiguousarray(theta_b, dtype=numpy.float64).ravel()
+        assert ta.size == tb.size
+        th = numpy.concatenate([ta, tb])
+        out = numpy.empty(ta.size)
+        if ta.size:
+            self._check(self._L.chomp_covariance_gaussian(
+                self._h, float(j0_limit), float(area), float(poisson_a), float(poisson_b),
+                ctypes.c_void_p(th.ctypes.data), ta.size, ctypes.c_void_p(out.ctypes.data),
+                HOST))
+        return out
 
     def hod_stats(self, epoch0=0, n=None):
         """[n, 3]: effective bias, effective halo mass, satellite fraction."""

@@ -107,9 +107,9 @@ class Correlation(object):
     def set_hod_object(self, input_hod):
         self.halo.set_hod_object(input_hod)
 
-    def _prepare(self):
+    def _prepare(self, power_name=None):
         """Halo tables and projection tables in ONE device context."""
-        code, need = _POWER[self._power_name]
+        code, need = _POWER[self._power_name if power_name is None else power_name]
         if isinstance(self.halo, halo_mod.HaloFit) and code != _lib.P_LIN:
             self.halo._ensure_halofit()
             code |= _lib.P_HALOFIT

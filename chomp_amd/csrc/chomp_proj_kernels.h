@@ -85,14 +85,19 @@ struct ProjState {
   ProjDev host;            // host copy of the scalars (refreshed by kernel_info)
   ProjDev* d_pd = nullptr;
   double* d_tab = nullptr;
+  bool cov_ready = false;  // covariance table (chomp_covariance_table) valid
+  double* d_cov = nullptr;
 };
 inline void proj_free(ProjState& p) {
   if (p.d_pd) (void)hipFree(p.d_pd);
   if (p.d_tab) (void)hipFree(p.d_tab);
+  if (p.d_cov) (void)hipFree(p.d_cov);
   p.d_pd = nullptr;
   p.d_tab = nullptr;
+  p.d_cov = nullptr;
   p.ready = false;
   p.me_ready = false;
+  p.cov_ready = false;
 }
 
 // ---------------------------------------------------------------------------
@@ -841,6 +846,155 @@ __global__ __launch_bounds__(256) void k_cell(chomp_config cfg, TabLayout HL, Pr
   const double v = romberg1<4>(f, pd.chi_min, pd.chi_max, cfg.global_precision,
                                cfg.corr_precision, cfg.divmax, red);
   if (threadIdx.x == 0) out[blockIdx.x] = v;
+}
+
+// ---------------------------------------------------------------------------
+// Gaussian covariance of w(theta): Covariance(corr, corr), covariance.py:361-543
+// ---------------------------------------------------------------------------
+// Table layout of the covariance state: ln K knots | projected spectrum | its spline |
+// scalars {ln_K_min, ln_K_max, D_z, chi_peak}.
+struct CovLayout {
+  int N, ln_K, proj, pp, lev, scal, work, total;
+};
+inline CovLayout make_cov_layout(int N) {
+  CovLayout C;
+  C.N = N;
+  int o = 0;
+  C.ln_K = o; o += N;
+  C.proj = o; o += N;
+  C.pp = o; o += 4 * (N - 1);
+  C.lev = o; o += N;
+  C.scal = o; o += 8;
+  C.work = o; o += 2 * N;
+  C.total = (o + 7) & ~7;
+  return C;
+}
+
+// covariance.py:545-552 with kernel.py:1066-1071 (_halo_a_integrand)
+struct CovProjIntegrand {
+  const PowerEval* P;
+  const ProjLds* G;
+  double K, norm;
+  __device__ __forceinline__ double operator()(double chi) const {
+    const double D = G->me.growth_factor(G->me.redshift(chi));
+    return norm * (*P)(K / chi) * (G->wa(chi) * G->wb(chi) * D * D / (chi * chi));
+  }
+};
+
+// grid N (= kernel_npoints), block 256: one ln K knot of Covariance._halo_a_spline per
+// workgroup (covariance.py:455-543, the matching_corrs branch).
+__global__ __launch_bounds__(256) void k_cov_proj_knots(chomp_config cfg, TabLayout HL,
+                                                        ProjLayout L, CovLayout C,
+                                                        const Epoch* __restrict__ epochs, int e,
+                                                        const double* __restrict__ htab, int which,
+                                                        const ProjDev* __restrict__ pdg,
+                                                        const double* __restrict__ ptab,
+                                                        double D_z, double* __restrict__ ctab) {
+  extern __shared__ __align__(16) double sm[];
+  __shared__ Epoch E;
+  __shared__ ProjDev pd;
+  __shared__ double red[romberg_scratch<4, 2>()];
+  __shared__ double chi_peak_s;
+  copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
+               kEpochDoubles);
+  copy_doubles(reinterpret_cast<double*>(&pd), reinterpret_cast<const double*>(pdg), kProjDoubles);
+  __syncthreads();
+  PowerEval P;
+  P.stage(cfg, HL, &E, htab + (size_t)e * HL.stride, which, sm);
+  ProjLds G;
+  G.stage(L, pd, ptab, sm + 12 * (HL.NK - 1));
+  G.bess = nullptr;
+  if (threadIdx.x == 0)                                  // :466: a growth factor used as z
+    chi_peak_s = me_view(L, pd, ptab, 0).comoving_distance(D_z);
+  __syncthreads();
+  P.finish();
+  const int i = blockIdx.x;
+  // pd.chi_min / chi_max are Covariance._chi_min_a / _chi_max_a (:132-141 = kernel.py:610-612)
+  const double ln_K_min = log(cfg.k_min * pd.chi_min), ln_K_max = log(cfg.k_max * pd.chi_max);
+  const double ln_K = linspace_at(ln_K_min, ln_K_max, C.N, i);
+  const double K = exp(ln_K);
+  double chi_min = K / cfg.k_max, chi_max = K / cfg.k_min;
+  if (chi_min < pd.chi_min) chi_min = pd.chi_min;
+  if (chi_max > pd.chi_max) chi_max = pd.chi_max;
+  CovProjIntegrand f{&P, &G, K, 1.0};
+  const double norm_int = f(chi_peak_s);
+  f.norm = norm_int > 0.0 ? 1.0 / norm_int : 1.0;
+  int level = 0;
+  const double v = romberg1<4>(f, chi_min, chi_max, cfg.global_precision, cfg.corr_precision,
+                               cfg.divmax, red, &level);
+  if (threadIdx.x == 0) {
+    ctab[C.ln_K + i] = ln_K;
+    ctab[C.proj + i] = v / f.norm;
+    ctab[C.lev + i] = (double)level;
+    if (i == 0) {
+      ctab[C.scal + 0] = ln_K_min;
+      ctab[C.scal + 1] = ln_K_max;
+      ctab[C.scal + 2] = D_z;
+      ctab[C.scal + 3] = chi_peak_s;
+    }
+  }
+}
+
+__global__ void k_cov_spline(CovLayout C, double* __restrict__ ctab) {
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    spline_build(ctab + C.ln_K, ctab + C.proj, C.N, ctab + C.pp, ctab + C.work);
+}
+
+// covariance.py:397-453 (_covariance_G_integrand, matching_corrs: the second two-point
+// term repeats the first)
+struct CovGIntegrand {
+  const double *xk, *pp;
+  int N;
+  const BesselTab* B;
+  double theta_a, theta_b, inv_D2, poiss_a, poiss_b, norm;
+  __device__ __forceinline__ double operator()(double ln_K) const {
+    const double K = exp(ln_K);
+    const double s = spline_eval(xk, pp, N, log(K));
+    const double Pa = s * inv_D2, Pb = s * inv_D2;
+    const double t1 = Pa * Pb + Pa * poiss_b + Pb * poiss_a;
+    return K * K * norm * (t1 + t1) * bessel_j<0>(K * theta_a, *B) * bessel_j<0>(K * theta_b, *B);
+  }
+};
+
+// grid n pairs, block 256: Covariance.covariance_G(theta_a, theta_b) (covariance.py:361-395).
+__global__ __launch_bounds__(256) void k_cov_gaussian(chomp_config cfg, CovLayout C,
+                                                      const double* __restrict__ ctab,
+                                                      const BesselTab* __restrict__ bess_g,
+                                                      double j0_limit, double area,
+                                                      double poiss_a, double poiss_b,
+                                                      const double* __restrict__ theta_a,
+                                                      const double* __restrict__ theta_b,
+                                                      double* __restrict__ out,
+                                                      double* __restrict__ levels) {
+  extern __shared__ __align__(16) double sm[];
+  __shared__ BesselTab B;
+  __shared__ double red[romberg_scratch<4, 2>()];
+  double* xk = sm;
+  double* pp = sm + C.N;
+  copy_doubles(xk, ctab + C.ln_K, C.N);
+  copy_doubles(pp, ctab + C.pp, 4 * (C.N - 1));
+  copy_doubles(reinterpret_cast<double*>(&B), reinterpret_cast<const double*>(bess_g),
+               (int)(sizeof(BesselTab) / sizeof(double)));
+  __syncthreads();
+  const double ln_K_min = ctab[C.scal + 0], ln_K_hi = ctab[C.scal + 1], D_z = ctab[C.scal + 2];
+  const double ta = theta_a[blockIdx.x], tb = theta_b[blockIdx.x];
+  double ln_K_max = log(fmax(j0_limit / ta, j0_limit / tb));
+  double v = 0.0;
+  int level = 0;
+  if (ln_K_max > ln_K_hi) ln_K_max = ln_K_hi;
+  if (ln_K_max > ln_K_min) {
+    CovGIntegrand f{xk, pp, C.N, &B, 0.0, 0.0, 1.0 / (D_z * D_z), poiss_a, poiss_b, 1.0};
+    const double norm = 1.0 / f(0.0);                    // :390
+    f.theta_a = ta;
+    f.theta_b = tb;
+    f.norm = norm;
+    v = romberg1<4>(f, ln_K_min, ln_K_max, cfg.global_precision, cfg.corr_precision,
+                    cfg.divmax, red, &level) / (norm * 2.0 * kPi * area);
+  }
+  if (threadIdx.x == 0) {
+    out[blockIdx.x] = v;
+    if (levels) levels[blockIdx.x] = (double)level;
+  }
 }
 
 }  // namespace chomp

@@ -324,6 +324,27 @@ int chomp_window_eval(chomp_ctx* ctx, int which_window, const double* chi,
 int chomp_wtheta(chomp_ctx* ctx, int which, size_t epoch, double k_min,
                  double k_max, double D_z, const double* theta, size_t n,
                  double* out, int mem);
+/* Gaussian covariance of w(theta), Covariance(corr, corr) with nongaussian_cov=False.
+ *
+ * chomp_covariance_table replaces Covariance._initialize_halo_splines (covariance.py:455-543,
+ * the matching_corrs branch): on kernel_npoints knots in ln K, from ln(k_min chi_min) to
+ * ln(k_max chi_max) (covariance.py:159-175), the projected spectrum
+ *   int dchi P(K/chi) W_a(chi) W_b(chi) D(chi)^2 / chi^2
+ * of `which` of halo epoch `epoch` (moved to the kernel's z_bar by the caller, :460) with
+ * the reference's limits, normalisation and Romberg tolerances, and its spline.  D_z is
+ * MultiEpoch.growth_factor(z_bar) (:464).  ln_K / proj / levels (each [n = kernel_npoints],
+ * host, may be NULL) receive the knots, the table and the Romberg levels reached.
+ *
+ * chomp_covariance_gaussian replaces Covariance.covariance_G (covariance.py:361-453) for n
+ * pairs of bin centres: theta holds theta_a[n] then theta_b[n] (radians).  j0_limit is
+ * Covariance._j0_limit (:188-189), area the survey area in steradians, poisson_a /
+ * poisson_b the shot-noise terms proj_power_poisson(0) / (2) of the integrand (:427-432). */
+int chomp_covariance_table(chomp_ctx* ctx, int which, size_t epoch, double D_z,
+                           double* ln_K, double* proj, double* levels, size_t n);
+int chomp_covariance_gaussian(chomp_ctx* ctx, double j0_limit, double area,
+                              double poisson_a, double poisson_b,
+                              const double* theta, size_t n, double* out, int mem);
+
 /* CorrelationFourier.correlation(l) (correlation.py:360-392): Limber C_l. */
 int chomp_cell(chomp_ctx* ctx, int which, size_t epoch, double D_z,
                const double* ell, size_t n, double* out, int mem);

@@ -1085,3 +1085,112 @@ def cell(kt, power, ell, D_z, prec=None, levels=None):
         if levels is not None:
             levels.append(level)
     return numpy.array(out)
+
+
+# ---------------------------------------------------------------------------
+# L6: Gaussian covariance of w(theta) (covariance.py), Covariance(corr, corr) with
+# nongaussian_cov=False.  In that use the window comparisons of covariance.py:108-115
+# come out [F, F, F, F, T, T] whatever the windows are (kernel.py:248-259 compares the
+# windows' private MultiEpoch copies by identity), so the shot-noise factors of the G
+# integrand (pairs 0 and 2) vanish and only the Poisson term keeps them (pairs 4, 5).
+# ---------------------------------------------------------------------------
+def annular_bins(theta_min_deg, theta_max_deg, bins_per_decade=5.0):
+    """covariance.py:52-75 and AnnulusBin (:1085-1103): arrays inner, outer, center,
+    delta (radians)."""
+    d2r = numpy.pi / 180.0
+    lmin = numpy.log10(theta_min_deg * d2r)
+    lmax = numpy.log10(theta_max_deg * d2r)
+    inner, outer = [], []
+    unit_double = numpy.floor(lmin) * bins_per_decade
+    theta = numpy.power(10.0, unit_double / (1.0 * bins_per_decade))
+    while theta < numpy.power(10.0, lmax):
+        if theta >= numpy.power(10.0, lmin) and theta < numpy.power(10.0, lmax):
+            inner.append(theta)
+            outer.append(numpy.power(10.0, (unit_double + 1.0) / (1.0 * bins_per_decade)))
+        unit_double += 1.0
+        theta = numpy.power(10.0, unit_double / (1.0 * bins_per_decade))
+    inner, outer = numpy.array(inner), numpy.array(outer)
+    center = numpy.power(10.0, 0.5 * (numpy.log10(inner) + numpy.log10(outer)))
+    return inner, outer, center, outer - inner
+
+
+def covariance_table(kt, power, limits=None, levels=None):
+    """covariance.py:130-175 + _initialize_halo_splines (:455-543), matching
+    correlations: the projected spectrum int dchi P(K/chi) W_a W_b D^2/chi^2 on
+    kernel_npoints knots in ln K.  ``power``: k -> P(k), the halo already at z_bar."""
+    prec, me = kt.prec, kt.me
+    limits = default_limits if limits is None else limits
+    cv = Table(kt=kt, prec=prec, limits=limits)
+    z_min_a = max(kt.wa.z_min, kt.wb.z_min)
+    z_max_a = min(kt.wa.z_max, kt.wb.z_max)
+    cv.chi_min = float(me_chi(me, z_min_a))
+    if cv.chi_min < prec["window_precision"]:
+        cv.chi_min = prec["window_precision"]
+    cv.chi_max = float(me_chi(me, z_max_a))
+    cv.ln_K_min = numpy.log(limits["k_min"] * cv.chi_min)
+    cv.ln_K_max = numpy.log(limits["k_max"] * cv.chi_max)
+    cv.ln_K = numpy.linspace(cv.ln_K_min, cv.ln_K_max, prec["kernel_npoints"])
+    cv.j0_limit = special.jn_zeros(0, prec["kernel_bessel_limit"])[-1]
+    cv.D_z = float(me_growth(me, kt.z_bar))                      # :464
+    chi_peak = float(me_chi(me, cv.D_z))                         # :466 (a growth factor as z)
+
+    def integrand(chi, ln_K, norm):                              # :545-552, kernel.py:1066-1071
+        D = me_growth(me, me.z_spline(chi))
+        return (norm * power(numpy.exp(ln_K) / chi) *
+                (window(kt.wa, chi) * window(kt.wb, chi) * D * D / (chi * chi)))
+
+    cv.proj = numpy.empty(cv.ln_K.size)
+    for i, ln_K in enumerate(cv.ln_K):
+        chi_min = max(numpy.exp(ln_K) / limits["k_max"], cv.chi_min)
+        chi_max = min(numpy.exp(ln_K) / limits["k_min"], cv.chi_max)
+        norm_int = integrand(chi_peak, ln_K, 1.0)
+        norm = 1.0 / norm_int if norm_int > 0.0 else 1.0
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", AccuracyWarning)
+            val, level = romberg(integrand, chi_min, chi_max, args=(ln_K, norm),
+                                 vec_func=True, tol=prec["global_precision"],
+                                 rtol=prec["corr_precision"], divmax=prec["divmax"],
+                                 return_level=True)
+        cv.proj[i] = val / norm
+        if levels is not None:
+            levels.append(level)
+    cv.proj_spline = InterpolatedUnivariateSpline(cv.ln_K, cv.proj)
+    return cv
+
+
+def covariance_G_integrand(cv, ln_K, theta_a, theta_b, norm=1.0, poisson=(0.0, 0.0)):
+    """covariance.py:397-453 with matching_corrs (two_point_term2 = two_point_term1)."""
+    K = numpy.exp(ln_K)
+    Pa = cv.proj_spline(numpy.log(K)) / (cv.D_z ** 2)
+    Pb = cv.proj_spline(numpy.log(K)) / (cv.D_z ** 2)
+    t1 = Pa * Pb + Pa * poisson[1] + Pb * poisson[0]
+    return K * K * norm * (t1 + t1) * special.j0(K * theta_a) * special.j0(K * theta_b)
+
+
+def covariance_G(cv, theta_a, theta_b, area, poisson=(0.0, 0.0), levels=None):
+    """covariance.py:361-395."""
+    ln_K_max = numpy.log(max(cv.j0_limit / theta_a, cv.j0_limit / theta_b))
+    if ln_K_max > cv.ln_K_max:
+        ln_K_max = cv.ln_K_max
+    elif ln_K_max <= cv.ln_K_min:
+        return 0.0
+    norm = 1.0 / covariance_G_integrand(cv, 0.0, 0.0, 0.0, 1.0, poisson)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", AccuracyWarning)
+        val, level = romberg(lambda x: covariance_G_integrand(cv, x, theta_a, theta_b, norm,
+                                                              poisson),
+                             cv.ln_K_min, ln_K_max, vec_func=True,
+                             tol=cv.prec["global_precision"], rtol=cv.prec["corr_precision"],
+                             divmax=cv.prec["divmax"], return_level=True)
+    if levels is not None:
+        levels.append(level)
+    return val / (norm * 2.0 * numpy.pi * area)
+
+
+def covariance_P(theta, delta, area, n_a, n_b, variance, shear_cross=False):
+    """covariance.py:338-359 for Covariance(corr, corr): only window pairs 4 and 5 are
+    'equal' (see the section header), so term3 is the whole Poisson term."""
+    dens_a, dens_b = n_a / area, n_b / area                      # density[4], density[5]
+    term3 = (variance * variance / dens_a) * (variance * variance / dens_b) * (
+        1.0 + (1 if shear_cross else 0))
+    return term3 / (2.0 * numpy.pi * area * theta * delta)

@@ -336,6 +336,60 @@ def g11(ns):
     save("g11_bao", **out)
 
 
+def g12(ns):
+    """SURVEY 8(f) rank 4, Gaussian part: Covariance(corr, corr) with nongaussian_cov=False
+    (covariance.py:46-200, 297-543): the projected-spectrum table over ln K, covariance_G for
+    every pair of bins, the Poisson term and get_covariance().  Case "mag": galaxy x
+    convergence windows, power_mm, no shot noise in the G integrand (windows differ);
+    case "auto": one galaxy window used twice, power_gg, shot noise on."""
+    import contextlib
+    import io
+    out = {}
+    for tag, ps, kws in (
+            ("mag", "power_mm", dict(bins_per_decade=2.0, survey_area_deg2=25.0,
+                                     n_a=[1.0e10, 1.0e10], n_b=[1.0e10, 1.0e10], variance=1.0)),
+            ("auto", "power_gg", dict(bins_per_decade=3.0, survey_area_deg2=100.0,
+                                      n_a=2.0e6, n_b=2.0e6, variance=0.3))):
+        cm = ns.cosmology.MultiEpoch(0.0, 5.0)
+        wa = ns.kernel.WindowFunctionGalaxy(
+            ns.kernel.dNdzMagLim(0.0, 2.0, 2.0, 0.3, 2.0), cm)
+        wb = wa if tag == "auto" else ns.kernel.WindowFunctionConvergence(
+            ns.kernel.dNdzGaussian(0.0, 2.0, 1.0, 0.2), cm)
+        kern = ns.kernel.Kernel(1e-6 * deg_to_rad, 100.0 * deg_to_rad, wa, wb, cm)
+        corr = ns.correlation.Correlation(0.01, 1.0, kern, input_halo=ns.halo.Halo(0.0),
+                                          power_spec=ps)
+        with contextlib.redirect_stdout(io.StringIO()):
+            cv = ns.covariance.Covariance(corr, corr, nongaussian_cov=False, power_spec=ps,
+                                          **kws)
+            cv._initialize_halo_splines()
+            bins = cv.annular_bins
+            nb = len(bins)
+            G = numpy.zeros((nb, nb))
+            for i in range(nb):
+                for j in range(nb):
+                    G[i, j] = cv.covariance_G(bins[i].center, bins[j].center,
+                                              bins[i].delta, bins[j].delta)
+            P = numpy.array([cv.covariance_P(b.delta, b.center) for b in bins])
+            full = numpy.asarray(cv.get_covariance(), dtype=float)
+        out.update({
+            tag + "_inner": numpy.array([b.inner for b in bins]),
+            tag + "_outer": numpy.array([b.outer for b in bins]),
+            tag + "_center": numpy.array([b.center for b in bins]),
+            tag + "_ln_K": cv._ln_K_array,
+            tag + "_proj": cv._halo_a_spline(cv._ln_K_array),
+            tag + "_scalars": numpy.array([cv._D_z_a, cv._chi_min_a, cv._chi_max_a,
+                                           cv._ln_K_min, cv._ln_K_max, cv._j0_limit,
+                                           cv.area, cv._z_bar_G_a]),
+            tag + "_equal_windows": numpy.array(cv.equal_windows),
+            tag + "_cosmic_shear": numpy.array(cv.cosmic_shear, dtype=bool),
+            tag + "_G": G, tag + "_P": P, tag + "_cov": full,
+            tag + "_K_probe": numpy.linspace(cv._ln_K_min, cv._ln_K_max, 23),
+        })
+        out[tag + "_G_integrand"] = cv._covariance_G_integrand(
+            out[tag + "_K_probe"], bins[0].center, bins[-1].center, bins[0].delta, 1.0)
+    save("g12_covariance_gaussian", **out)
+
+
 def pins():
     """Known-answer literals held by the reference's own tests (unit_test.py),
     restricted to the classes that pass against the shipped code."""
@@ -368,7 +422,7 @@ def pins():
 
 
 def main():
-    names = sys.argv[1:] or ["pins", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    names = sys.argv[1:] or ["pins", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     ns = ref_loader.load()
     cwd = os.getcwd()
     with tempfile.TemporaryDirectory() as tmp:

@@ -25,7 +25,7 @@ import warnings
 
 REFERENCE_DIR = "/root/reference"
 MODULES = ("defaults", "cosmology", "mass_function", "hod", "halo", "kernel",
-           "correlation")
+           "correlation", "perturbation_spectra", "halo_trispectrum", "covariance")
 
 _here = os.path.dirname(os.path.abspath(__file__))
 _root = os.path.dirname(os.path.dirname(_here))

@@ -107,3 +107,39 @@ def test_correlation3d_host_logic():
     one = correlation.Correlation3d(2.0, 2.0)
     assert one.r_array.tolist() == [2.0] and one._power_name == "linear_power"
     assert isinstance(halo.HaloExclusion(0.2), halo.Halo)
+
+
+def test_covariance_host_logic():
+    """covariance.py:46-130: bins, survey scalars and the scope of the accelerated class."""
+    from chomp_amd import correlation, covariance, kernel, _lib
+    from oracle import chomp_oracle as o
+    w = kernel.WindowFunctionGalaxy(kernel.dNdzMagLim(0.0, 2.0, 2.0, 0.3, 2.0))
+    ws = kernel.WindowFunctionConvergence(kernel.dNdzGaussian(0.0, 2.0, 1.0, 0.2))
+    kern = kernel.Kernel(1e-8, 1.0, w, ws)
+    corr = correlation.Correlation.__new__(correlation.Correlation)   # no device here
+    corr.log_theta_min = numpy.log10(0.01 * numpy.pi / 180)
+    corr.log_theta_max = numpy.log10(1.0 * numpy.pi / 180)
+    corr.kernel = kern
+
+    class _H(object):
+        power_mm = None
+    corr.halo = _H()
+    with pytest.raises(_lib.ChompScopeError):
+        covariance.Covariance(corr, corr)                      # nongaussian_cov defaults to True
+    other = correlation.Correlation.__new__(correlation.Correlation)
+    other.__dict__.update(corr.__dict__)
+    with pytest.raises(_lib.ChompScopeError):
+        covariance.Covariance(corr, other, nongaussian_cov=False)
+    cv = covariance.Covariance(corr, corr, bins_per_decade=3.0, survey_area_deg2=100.0,
+                               n_a=[2e6, 3e6], n_b=4e6, variance=0.3, nongaussian_cov=False)
+    inner, outer, center, delta = o.annular_bins(0.01, 1.0, 3.0)
+    assert numpy.array_equal([b.center for b in cv.annular_bins], center)
+    assert numpy.array_equal([b.delta for b in cv.annular_bins], delta)
+    assert (cv.n_a1, cv.n_a2, cv.n_b1, cv.n_b2) == (2e6, 3e6, 4e6, 4e6)
+    assert cv.cosmic_shear == [False, False] or list(cv.cosmic_shear) == [0, 0]
+    assert cv.proj_power_poisson(0) == 0.0
+    assert cv.proj_power_poisson(4) == 0.09 / (2e6 / cv.area)
+    p = cv.covariance_P(delta[1], center[1])
+    assert abs(p / o.covariance_P(center[1], delta[1], cv.area, 2e6, 3e6, 0.3) - 1) < 1e-14
+    with pytest.raises(_lib.ChompScopeError):
+        cv.covariance_NG(0.01, 0.01)

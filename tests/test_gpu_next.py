@@ -278,3 +278,65 @@ def test_raw_kernel():
         assert isinstance(kern.raw_kernel(float(mid[0])), float)
     with pytest.raises(Exception):
         kern.kernel_weighted_mean(lambda z: z)
+
+
+def test_gaussian_covariance():
+    """SURVEY 8(f) rank 4, Gaussian part: Covariance(corr, corr, nongaussian_cov=False)
+    against the reference (G12): the projected-spectrum table over ln K, covariance_G of
+    every bin pair, the Poisson term, get_covariance() and the written file."""
+    from chomp_amd import correlation, covariance, halo, kernel
+    from oracle import chomp_oracle as o
+    g = load_golden("g12_covariance_gaussian")
+    for tag, ps, kws in (
+            ("mag", "power_mm", dict(bins_per_decade=2.0, survey_area_deg2=25.0,
+                                     n_a=[1.0e10, 1.0e10], n_b=[1.0e10, 1.0e10], variance=1.0)),
+            ("auto", "power_gg", dict(bins_per_decade=3.0, survey_area_deg2=100.0,
+                                      n_a=2.0e6, n_b=2.0e6, variance=0.3))):
+        wa = kernel.WindowFunctionGalaxy(kernel.dNdzMagLim(0.0, 2.0, 2.0, 0.3, 2.0))
+        wb = wa if tag == "auto" else kernel.WindowFunctionConvergence(
+            kernel.dNdzGaussian(0.0, 2.0, 1.0, 0.2))
+        from chomp_amd import cosmology
+        cm = cosmology.MultiEpoch(0.0, 5.0)
+        d2r = numpy.pi / 180.0
+        kern = kernel.Kernel(1e-6 * d2r, 100.0 * d2r, wa, wb, cm)
+        corr = correlation.Correlation(0.01, 1.0, kern, input_halo=halo.Halo(0.0),
+                                       power_spec=ps)
+        cv = covariance.Covariance(corr, corr, nongaussian_cov=False, power_spec=ps, **kws)
+        bins = cv.annular_bins
+        assert numpy.allclose([b.center for b in bins], g[tag + "_center"], rtol=1e-15)
+        assert numpy.allclose([b.inner for b in bins], g[tag + "_inner"], rtol=1e-15)
+        assert list(cv.equal_windows) == list(g[tag + "_equal_windows"])
+        assert [bool(x) for x in cv.cosmic_shear] == list(g[tag + "_cosmic_shear"])
+        cv._initialize_halo_splines()
+        sc = g[tag + "_scalars"]       # D_z, chi_min, chi_max, ln_K_min, ln_K_max, j0, area, z_bar
+        assert abs(cv._D_z_a / sc[0] - 1) < 1e-9 and abs(cv._z_bar_G_a - sc[7]) < 1e-12
+        assert abs(cv._ln_K_min - sc[3]) < 1e-9 and abs(cv._ln_K_max - sc[4]) < 1e-9
+        assert abs(cv._j0_limit / sc[5] - 1) < 1e-14 and abs(cv.area / sc[6] - 1) < 1e-14
+        assert numpy.allclose(cv._ln_K_array, g[tag + "_ln_K"], rtol=0, atol=1e-9)
+        scale = numpy.max(numpy.abs(g[tag + "_proj"]))
+        assert numpy.max(numpy.abs(cv._halo_a_array - g[tag + "_proj"])) < 1e-6 * scale
+        big = numpy.abs(g[tag + "_proj"]) > 1e-6 * scale
+        assert rel_err(cv._halo_a_array[big], g[tag + "_proj"][big]) < RTOL
+        nb = len(bins)
+        G = numpy.array([[cv.covariance_G(a.center, b.center, a.delta, b.delta) for b in bins]
+                         for a in bins])
+        assert rel_err(G, g[tag + "_G"]) < RTOL
+        P = numpy.array([cv.covariance_P(b.delta, b.center) for b in bins])
+        assert rel_err(P, g[tag + "_P"]) < 1e-12
+        full = cv.get_covariance()
+        assert full.shape == (nb, nb) and rel_err(full, g[tag + "_cov"]) < RTOL
+        assert abs(cv.covariance(bins[0], bins[0]) / g[tag + "_cov"][0, 0] - 1) < RTOL
+        assert abs(cv.covariance(bins[0], bins[1]) / g[tag + "_cov"][0, 1] - 1) < RTOL
+    # the Romberg levels of the last case against the oracle's (the stopping rule is part
+    # of the answer)
+    me = o.multi_epoch(0.0, 5.0)
+    ow = o.window_table("galaxy", o.dndz_maglim(0.0, 2.0, 2.0, 0.3, 2.0), me)
+    kt = o.kernel_table(1e-6 * d2r, 100 * d2r, ow, ow, me)
+    e = o.epoch(None, kt.z_bar)
+    t = o.halo_table(e, o.mass_table(e), o.zheng(), families=("gg",))
+    lev = []
+    ocv = o.covariance_table(kt, lambda k: o.halo_power(t, "gg", k), levels=lev)
+    agree = numpy.mean(numpy.asarray(lev) == cv._halo_a_levels)
+    assert agree >= 0.9, (lev, cv._halo_a_levels)
+    with pytest.raises(Exception):
+        covariance.Covariance(corr, corr)                  # trispectrum terms: scope error

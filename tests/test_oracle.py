@@ -253,3 +253,31 @@ def test_g11_bao_transfer():
     assert rel_err(numpy.array([o.sigma_r(e, x) for x in g["scale"]]), g["sigma_r"]) < 1e-12
     m = o.mass_table(e)
     assert numpy.array_equal(m.ln_mass, g["ln_mass"]) and rel_err(m.nu_arr, g["nu"]) < 1e-12
+
+
+def test_g12_gaussian_covariance():
+    """Covariance(corr, corr, nongaussian_cov=False) (covariance.py:46-543) against the
+    reference: the "mag" case of G12 (galaxy x convergence windows, power_mm)."""
+    g = load_golden("g12_covariance_gaussian")
+    d2r = numpy.pi / 180.0
+    me = o.multi_epoch(0.0, 5.0)
+    wa = o.window_table("galaxy", o.dndz_maglim(0.0, 2.0, 2.0, 0.3, 2.0), me)
+    wb = o.window_table("convergence", o.dndz_gaussian(0.0, 2.0, 1.0, 0.2), me)
+    kt = o.kernel_table(1e-6 * d2r, 100 * d2r, wa, wb, me)
+    e = o.epoch(None, kt.z_bar)
+    t = o.halo_table(e, o.mass_table(e), o.zheng(), families=("mm",))
+    cv = o.covariance_table(kt, lambda k: o.halo_power(t, "mm", k))
+    inner, outer, center, delta = o.annular_bins(0.01, 1.0, 2.0)
+    assert numpy.array_equal(center, g["mag_center"]) and numpy.array_equal(inner, g["mag_inner"])
+    assert numpy.array_equal(cv.ln_K, g["mag_ln_K"])
+    scale = numpy.max(numpy.abs(g["mag_proj"]))
+    assert numpy.max(numpy.abs(cv.proj - g["mag_proj"])) < 1e-13 * scale
+    gi = o.covariance_G_integrand(cv, g["mag_K_probe"], center[0], center[-1])
+    assert numpy.max(numpy.abs(gi - g["mag_G_integrand"])) < 1e-11 * numpy.max(
+        numpy.abs(g["mag_G_integrand"]))        # (the table is ~0 at its ends: absolute scale)
+    area = 25.0 * d2r * d2r
+    G = numpy.array([[o.covariance_G(cv, a, b, area) for b in center] for a in center])
+    assert rel_err(G, g["mag_G"]) < 1e-12
+    P = numpy.array([o.covariance_P(c, d, area, 1e10, 1e10, 1.0) for c, d in zip(center, delta)])
+    assert rel_err(P, g["mag_P"]) < 1e-14
+    assert rel_err(G + numpy.diag(P), g["mag_cov"]) < 1e-12
