@@ -336,7 +336,22 @@ def main():
     nk_big = args.roofline_nk
     k_big = torch.logspace(-3, 2, nk_big, dtype=torch.float64, device=dev)
     buf_big = torch.empty((n_local, nk_big), dtype=torch.float64, device=dev)
+    # (the first ~100 launches after the compute-bound Stage K phase run at a varying,
+    #  lower rate while the device's clocks settle -- rocprof trace in DESIGN.md section 6 --
+    #  so the streaming stage gets a warm-up train of its own)
+    for _ in range(200):
+        hg.power(which, k_big, out=buf_big)
     t_e_big = timed(lambda: hg.power(which, k_big, out=buf_big), 100)
+    # per-kernel durations of the same call (HIP events recorded by the library around its
+    # three launches, on the stream they run on): the last call of 5 back-to-back trains
+    hg.ctx.set_timing(True)
+    per_kernel = []
+    for _ in range(5):
+        for _ in range(40):
+            hg.power(which, k_big, out=buf_big)
+        per_kernel.append(hg.ctx.get_timing())
+    hg.ctx.set_timing(False)
+    t_prep, t_stream, t_lanes = (float(x) * 1e-6 for x in numpy.mean(per_kernel, axis=0))
     # Algorithmic bytes of one Stage-E launch: k is read once (8 B per k) and one
     # P value is written per (k, z) sample (8 B).  SURVEY 8(d) prices the per-z
     # explicit-k call at 16 B/sample (k re-read for every z); the grid launch shares
@@ -344,21 +359,31 @@ def main():
     # 8 nk + 8 nk nz.  Both are reported; `achieved` uses the launch's own bytes.
     bytes_big = 8.0 * nk_big + 8.0 * n_local * nk_big
     bytes_c2 = 8.0 * NK + 8.0 * n_local * NK
-    traffic = None
+    traffic = traffic_call = None
     try:      # HBM bytes per launch from rocprofv3 PMC passes (profiles/)
         with open(os.path.join(ROOT, "profiles", "stage_e_pmc.json")) as fh:
             pmc = json.load(fh)
         if pmc.get("nk") == nk_big and pmc.get("nz") == n_local:
-            traffic = pmc["hbm_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
+            traffic_call = pmc["hbm_bytes_per_launch"]
+            name = [n for n in pmc["WRITE_SIZE_KiB_raw_by_kernel"] if n.startswith("k_power_stream")][0]
+            traffic = 1024.0 * (2.0 * pmc["FETCH_SIZE_KiB_raw_by_kernel"][name] +
+                                pmc["WRITE_SIZE_KiB_raw_by_kernel"][name])
+    except (OSError, ValueError, KeyError, IndexError):
         pass
-    roof = {"bound": "hbm", "kernel": "Stage E = one chomp_power call: k_power_prep + k_power_stream + "
-                      "k_power_grid_lanes (HIP events around the call; the three rocprof "
-                      "averages add up to avg_launch_us)",
+    roof = {"bound": "hbm", "kernel": "k_power_stream (the dominant kernel of a Stage E call: it writes "
+                      "every output sample; HIP events around its launch on the context's stream)",
             "workload": "%d k x %d z (enlarged grid, SURVEY 8(d))" % (nk_big, n_local),
-            "achieved": bytes_big / t_e_big / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": bytes_big / t_e_big / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-            "bytes_per_launch": bytes_big, "avg_launch_us": t_e_big * 1e6,
+            "achieved": bytes_big / t_stream / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": bytes_big / t_stream / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+            "bytes_per_launch": bytes_big, "avg_launch_us": t_stream * 1e6,
+            # the whole chomp_power call = k_power_prep + k_power_stream + k_power_grid_lanes
+            # (HIP events around 100 back-to-back calls): what a caller of Stage E sees
+            "whole_call": {"kernels_us": {"k_power_prep": t_prep * 1e6,
+                                          "k_power_stream": t_stream * 1e6,
+                                          "k_power_grid_lanes": t_lanes * 1e6},
+                           "avg_call_us": t_e_big * 1e6, "traffic": traffic_call,
+                           "achieved": bytes_big / t_e_big / 1e9,
+                           "frac": bytes_big / t_e_big / 1e9 / HBM_PEAK_GBS},
             "achieved_at_16B_per_sample": 16.0 * n_local * nk_big / t_e_big / 1e9,
             "c2_grid": {"achieved": bytes_c2 / t_e_c2 / 1e9, "avg_launch_us": t_e_c2 * 1e6,
                         "bytes_per_launch": bytes_c2},

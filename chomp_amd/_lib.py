@@ -99,6 +99,7 @@ EXPORTS = [
     "chomp_set_precision", "chomp_xi3d", "chomp_spline_eval", "chomp_hod_stats",
     "chomp_set_transfer", "chomp_kernel_raw",
     "chomp_covariance_table", "chomp_covariance_gaussian",
+    "chomp_set_timing", "chomp_get_timing",
 ]
 
 
@@ -209,6 +210,8 @@ def lib():
         L.chomp_set_precision.argtypes = [vp, i]
         L.chomp_hod_stats.argtypes = [vp, sz, sz, c_double_p]
         L.chomp_set_transfer.argtypes = [vp, i]
+        L.chomp_set_timing.argtypes = [vp, i]
+        L.chomp_get_timing.argtypes = [vp, c_double_p, sz]
         L.chomp_covariance_table.argtypes = [vp, i, sz, d, c_double_p, c_double_p,
                                              c_double_p, sz]
         L.chomp_covariance_gaussian.argtypes = [vp, d, d, d, d, vp, sz, vp, i]
@@ -507,6 +510,16 @@ class Context(object):
     def wtheta(self, which, epoch, k_min, k_max, D_z, theta):
         return self._map1(self._L.chomp_wtheta, theta, int(which), epoch,
                           float(k_min), float(k_max), float(D_z))
+
+    def set_timing(self, on=True):
+        self._check(self._L.chomp_set_timing(self._h, int(bool(on))))
+
+    def get_timing(self):
+        """Microseconds of (k_power_prep, k_power_stream, k_power_grid_lanes) of the last
+        timed streaming power() call."""
+        out = numpy.empty(3)
+        self._check(self._L.chomp_get_timing(self._h, out.ctypes.data_as(c_double_p), 3))
+        return out
 
     def covariance_table(self, which, epoch, D_z):
         """(ln_K, projected spectrum, Romberg levels), each [kernel_npoints]."""

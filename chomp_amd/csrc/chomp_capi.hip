@@ -73,6 +73,9 @@ struct chomp_ctx {
   int slow_parity = 0;
   int precision = CHOMP_PREC_F64;  // chomp_set_precision
   int with_bao = 0;                // chomp_set_transfer
+  int timing = 0;                  // chomp_set_timing: HIP events around the Stage E launches
+  bool timing_valid = false;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<int> slot;           // host copy: epoch -> cosmology slot
   size_t cap_in = 0, cap_in2 = 0, cap_out = 0, cap_work = 0;
 
@@ -289,11 +292,39 @@ void chomp_ctx_destroy(chomp_ctx* ctx) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   proj_free(ctx->proj);
+  for (hipEvent_t e : ctx->ev)
+    if (e) (void)hipEventDestroy(e);
   if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
 
 const char* chomp_last_error(chomp_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+int chomp_set_timing(chomp_ctx* ctx, int on) {
+  if (!ctx) return CHOMP_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (on)
+    for (hipEvent_t& e : ctx->ev)
+      if (!e) HIPCHK(hipEventCreate(&e));
+  ctx->timing = on ? 1 : 0;
+  ctx->timing_valid = false;
+  return CHOMP_OK;
+}
+
+int chomp_get_timing(chomp_ctx* ctx, double* us, size_t n) {
+  if (!ctx || !us || n != 3) return fail(ctx, CHOMP_ERR_ARG, "get_timing: us[3]");
+  if (!ctx->timing || !ctx->timing_valid)
+    return fail(ctx, CHOMP_ERR_STATE,
+                "get_timing: no timed streaming chomp_power call (chomp_set_timing, large grid)");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipEventSynchronize(ctx->ev[3]));
+  for (int i = 0; i < 3; ++i) {
+    float ms = 0.0f;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));
+    us[i] = 1e3 * (double)ms;
+  }
+  return CHOMP_OK;
+}
 
 int chomp_sync(chomp_ctx* ctx) {
   if (!ctx) return CHOMP_ERR_ARG;
@@ -580,6 +611,9 @@ int chomp_power_range(chomp_ctx* ctx, int which, size_t epoch0, size_t n, const 
       if (rc) return rc;
       rc = ensure(ctx, &ctx->d_ktab, &ctx->cap_ktab, (size_t)gx8 * 1024);
       if (rc) return rc;
+      const bool timed = ctx->timing != 0;
+      ctx->timing_valid = false;
+      if (timed) HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
       if (ctx->with_bao)
         hipLaunchKernelGGL(k_power_prep<true>, dim3(gx8), dim3(256), 0, ctx->stream, ctx->cfg, L,
                            ctx->d_epochs, (int)epoch0, w, dk, nk, ctx->d_ktab, ctx->d_winfo,
@@ -588,6 +622,7 @@ int chomp_power_range(chomp_ctx* ctx, int which, size_t epoch0, size_t n, const 
         hipLaunchKernelGGL(k_power_prep<false>, dim3(gx8), dim3(256), 0, ctx->stream, ctx->cfg, L,
                            ctx->d_epochs, (int)epoch0, w, dk, nk, ctx->d_ktab, ctx->d_winfo,
                            ctx->d_slow, parity);
+      if (timed) HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
       int per = n % 2 == 0 ? 2 : 1;
       // (tuning hook: rows per block of the streaming kernel; 2 measured best on MI355X)
       if (const char* ev = getenv("CHOMP_E_PER")) { int v = atoi(ev); if ((v == 1 || v == 2 || v == 4) && n % v == 0) per = v; }
@@ -601,6 +636,10 @@ int chomp_power_range(chomp_ctx* ctx, int which, size_t epoch0, size_t n, const 
         default: CHOMP_STREAM(2); break;
       }
 #undef CHOMP_STREAM
+      if (timed) {
+        HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
+        ctx->timing_valid = true;
+      }
     } else {
       // enough blocks to fill 256 CUs: split the epochs over blockIdx.y when nk is small
       unsigned gy = (2048 + gx - 1) / gx;
@@ -625,6 +664,7 @@ int chomp_power_range(chomp_ctx* ctx, int which, size_t epoch0, size_t n, const 
       hipLaunchKernelGGL(k_power_grid_lanes<false>, dim3(1024), dim3(256), 0, ctx->stream, ctx->cfg,
                          L, ctx->d_epochs, ctx->d_tab, w, extrap, (int)epoch0, (int)n, dk, nk, dout,
                          ctx->d_slow, parity);
+    if (ctx->timing_valid) HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
   } else {
     unsigned gx = (unsigned)((nk + 255) / 256);
     if (gx > 2048) gx = 2048;

@@ -104,6 +104,15 @@ int chomp_ctx_create(const chomp_config* cfg, int device, void* hip_stream,
                      chomp_ctx** out);
 void chomp_ctx_destroy(chomp_ctx* ctx);
 const char* chomp_last_error(chomp_ctx* ctx);
+/* Measurement aid (no counterpart in the reference).  With timing on, the streaming shape
+ * of chomp_power / chomp_power_range (large grid of one cosmology) brackets its three
+ * launches -- k_power_prep, k_power_stream, k_power_grid_lanes -- with HIP events on the
+ * context's stream; chomp_get_timing waits for the last such call and returns their
+ * durations in microseconds (us[3], n = 3).  CHOMP_ERR_STATE when the last call took
+ * another launch shape or timing is off. */
+int chomp_set_timing(chomp_ctx* ctx, int on);
+int chomp_get_timing(chomp_ctx* ctx, double* us, size_t n);
+
 /* Block until everything queued on the context's stream has finished. */
 int chomp_sync(chomp_ctx* ctx);
 

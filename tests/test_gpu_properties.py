@@ -310,3 +310,24 @@ def test_c4_full_size_properties():
     assert rel_err(interp, g["cl_power_gg"]) < 5e-4
     assert rel_err(cf.correlation(ref_ell), g["cl_power_gg"]) < RTOL
     assert numpy.array_equal(cf.correlation(ell[near]), cl[near])
+
+
+def test_stage_e_timing_facility():
+    """chomp_set_timing / chomp_get_timing: per-kernel HIP-event durations of a streaming
+    Stage E call; a state error when the last call took another launch shape."""
+    import torch
+    from chomp_amd import grid, _lib
+    hg = grid.HaloGrid(numpy.linspace(0.0, 1.0, 8))
+    k = torch.logspace(-3, 2, 1 << 20, dtype=torch.float64, device="cuda")
+    hg.ctx.set_timing(True)
+    ref = hg.power("power_mm", k)
+    us = hg.ctx.get_timing()
+    assert us.shape == (3,) and numpy.all(us > 0) and us[1] > us[2]
+    hg.ctx.set_timing(False)
+    assert torch.equal(ref, hg.power("power_mm", k))          # timing does not change results
+    with pytest.raises(_lib.ChompError):
+        hg.ctx.get_timing()
+    hg.ctx.set_timing(True)
+    hg.power("power_mm", k[:4096].contiguous())               # small grid: row-walking shape
+    with pytest.raises(_lib.ChompError):
+        hg.ctx.get_timing()
