@@ -158,7 +158,8 @@ struct PowerEval {
   // lookup, and the linear spectrum uses the two-division arrangement of Stage E
   // (power_shape).  Agrees with operator() to rounding.
   // HF: compile-time copy of `halofit`, so that each instance carries one formula only.
-  template <bool HF>
+  // BAO: the context's transfer function (compile time, as in eval_t).
+  template <bool HF, bool BAO = false>
   __device__ __forceinline__ double at_ln(double lk, double kv) const {
     const bool in = kv >= k_min && kv <= k_max;
     if (HF) {
@@ -171,12 +172,12 @@ struct PowerEval {
       return pmm * pp_poly(ca, i, d) * pp_poly(cb, i, d) + pp_poly(cp, i, d);
     }
     if (w == CHOMP_P_LIN || !in || (extrap && !(kv < k_max)))
-      return (*this)(kv);                                 // the rarely taken branches
+      return eval_t<BAO>(kv);                             // the rarely taken branches
     int i = (int)floor((lk - x0) * inv_dx);
     i = i < 0 ? 0 : (i > NK - 2 ? NK - 2 : i);
     const double d = lk - (x0 + dx * (double)i);
     const double ha = pp_poly(ca, i, d), hb = pp_poly(cb, i, d), pp = pp_poly(cp, i, d);
-    return amp2 * power_shape_t<false>(*E, lk, kv) * ha * hb + pp;
+    return amp2 * power_shape_t<BAO>(*E, lk, kv) * ha * hb + pp;
   }
 };
 

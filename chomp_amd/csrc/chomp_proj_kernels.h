@@ -501,14 +501,14 @@ __global__ void k_window_eval(ProjLayout L, const ProjDev* __restrict__ pd,
 }
 
 // correlation.py:270-275
-template <bool HF>               // HF: the spectrum is a HaloFit one
+template <bool HF, bool BAO = false>   // HF: a HaloFit spectrum; BAO: wiggle transfer function
 struct WthetaIntegrand {
   const PowerEval* P;
   const KernelView* K;
   double theta, inv_D2, ln_theta;
   __device__ __forceinline__ double operator()(double ln_k) const {
     const double k = exp(ln_k);
-    return k * k / (2.0 * kPi) * P->template at_ln<HF>(ln_k, k) * inv_D2 * (*K)(ln_k + ln_theta);
+    return k * k / (2.0 * kPi) * P->template at_ln<HF, BAO>(ln_k, k) * inv_D2 * (*K)(ln_k + ln_theta);
   }
 };
 
@@ -516,7 +516,7 @@ struct WthetaIntegrand {
 // theta run to 2^18..2^20 nodes (the kernel oscillates in ln k theta) and set the launch's
 // duration, hence the wide group.
 constexpr int kWthetaNW = 16;
-template <bool HF>
+template <bool HF, bool BAO>
 __global__ __launch_bounds__(64 * kWthetaNW) void k_wtheta(chomp_config cfg, TabLayout HL, ProjLayout L,
                                                 const Epoch* __restrict__ epochs, int e,
                                                 const double* __restrict__ htab, int which,
@@ -535,9 +535,9 @@ __global__ __launch_bounds__(64 * kWthetaNW) void k_wtheta(chomp_config cfg, Tab
   double* kpp = sm + 12 * (HL.NK - 1);
   copy_doubles(kpp, ptab + L.k_pp, 4 * (L.NKT - 1));
   __syncthreads();
-  P.finish();
+  P.template finish_t<BAO>();
   const KernelView K{kpp, L.NKT, pd->ln_kt_min, pd->ln_kt_max};
-  WthetaIntegrand<HF> f{&P, &K, theta[blockIdx.x], 1.0 / (D_z * D_z), log(theta[blockIdx.x])};
+  WthetaIntegrand<HF, BAO> f{&P, &K, theta[blockIdx.x], 1.0 / (D_z * D_z), log(theta[blockIdx.x])};
   const double v = romberg1<kWthetaNW>(f, log(k_min), log(k_max), cfg.global_precision,
                                cfg.corr_precision, cfg.divmax, red);
   if (threadIdx.x == 0) out[blockIdx.x] = v;
@@ -746,18 +746,21 @@ __global__ __launch_bounds__(256) void k_wtheta_mixed(chomp_config cfg, TabLayou
 }
 
 // correlation.py:496-501 (Correlation3d._correlation_integrand)
+template <bool BAO>
 struct Xi3dIntegrand {
   const PowerEval* P;
   const BesselTab* B;
   double r;
   __device__ __forceinline__ double operator()(double ln_k) const {
     const double k = exp(ln_k);
-    const double p = P->halofit ? P->template at_ln<true>(ln_k, k) : P->template at_ln<false>(ln_k, k);
+    const double p = (!BAO && P->halofit) ? P->template at_ln<true>(ln_k, k)
+                                          : P->template at_ln<false, BAO>(ln_k, k);
     return k * k / (2.0 * kPi) * p * bessel_j<0>(k * r, *B);
   }
 };
 
 // grid n_r, block 256: one separation per workgroup.
+template <bool BAO>
 __global__ __launch_bounds__(256) void k_xi3d(chomp_config cfg, TabLayout HL,
                                               const Epoch* __restrict__ epochs, int e,
                                               const double* __restrict__ htab, int which,
@@ -776,8 +779,8 @@ __global__ __launch_bounds__(256) void k_xi3d(chomp_config cfg, TabLayout HL,
   PowerEval P;
   P.stage(cfg, HL, &E, htab + (size_t)e * HL.stride, which, sm);
   __syncthreads();
-  P.finish();
-  Xi3dIntegrand f{&P, &B, r[blockIdx.x]};
+  P.template finish_t<BAO>();
+  Xi3dIntegrand<BAO> f{&P, &B, r[blockIdx.x]};
   const double v = romberg1<4>(f, log(k_min), log(k_max), cfg.global_precision,
                                cfg.corr_precision, cfg.divmax, red);
   if (threadIdx.x == 0) out[blockIdx.x] = v;
@@ -809,17 +812,19 @@ __global__ void k_spline_eval(const double* __restrict__ xk, const double* __res
 }
 
 // correlation.py:387-392
+template <bool BAO>
 struct CellIntegrand {
   const PowerEval* P;
   const ProjLds* G;
   double ell, inv_D2;
   __device__ __forceinline__ double operator()(double chi) const {
     const double D = G->me.growth_factor(G->me.redshift(chi));
-    return (*P)(ell / chi) * inv_D2 * G->wa(chi) * G->wb(chi) * D * D / (chi * chi);
+    return P->template eval_t<BAO>(ell / chi) * inv_D2 * G->wa(chi) * G->wb(chi) * D * D / (chi * chi);
   }
 };
 
 // grid n_ell, block 256: one multipole per workgroup.
+template <bool BAO>
 __global__ __launch_bounds__(256) void k_cell(chomp_config cfg, TabLayout HL, ProjLayout L,
                                               const Epoch* __restrict__ epochs, int e,
                                               const double* __restrict__ htab, int which,
@@ -841,8 +846,8 @@ __global__ __launch_bounds__(256) void k_cell(chomp_config cfg, TabLayout HL, Pr
   G.stage(L, pd, ptab, sm + 12 * (HL.NK - 1));
   G.bess = nullptr;
   __syncthreads();
-  P.finish();
-  CellIntegrand f{&P, &G, ell[blockIdx.x], 1.0 / (D_z * D_z)};
+  P.template finish_t<BAO>();
+  CellIntegrand<BAO> f{&P, &G, ell[blockIdx.x], 1.0 / (D_z * D_z)};
   const double v = romberg1<4>(f, pd.chi_min, pd.chi_max, cfg.global_precision,
                                cfg.corr_precision, cfg.divmax, red);
   if (threadIdx.x == 0) out[blockIdx.x] = v;
@@ -871,18 +876,20 @@ inline CovLayout make_cov_layout(int N) {
 }
 
 // covariance.py:545-552 with kernel.py:1066-1071 (_halo_a_integrand)
+template <bool BAO>
 struct CovProjIntegrand {
   const PowerEval* P;
   const ProjLds* G;
   double K, norm;
   __device__ __forceinline__ double operator()(double chi) const {
     const double D = G->me.growth_factor(G->me.redshift(chi));
-    return norm * (*P)(K / chi) * (G->wa(chi) * G->wb(chi) * D * D / (chi * chi));
+    return norm * P->template eval_t<BAO>(K / chi) * (G->wa(chi) * G->wb(chi) * D * D / (chi * chi));
   }
 };
 
 // grid N (= kernel_npoints), block 256: one ln K knot of Covariance._halo_a_spline per
 // workgroup (covariance.py:455-543, the matching_corrs branch).
+template <bool BAO>
 __global__ __launch_bounds__(256) void k_cov_proj_knots(chomp_config cfg, TabLayout HL,
                                                         ProjLayout L, CovLayout C,
                                                         const Epoch* __restrict__ epochs, int e,
@@ -907,7 +914,7 @@ __global__ __launch_bounds__(256) void k_cov_proj_knots(chomp_config cfg, TabLay
   if (threadIdx.x == 0)                                  // :466: a growth factor used as z
     chi_peak_s = me_view(L, pd, ptab, 0).comoving_distance(D_z);
   __syncthreads();
-  P.finish();
+  P.template finish_t<BAO>();
   const int i = blockIdx.x;
   // pd.chi_min / chi_max are Covariance._chi_min_a / _chi_max_a (:132-141 = kernel.py:610-612)
   const double ln_K_min = log(cfg.k_min * pd.chi_min), ln_K_max = log(cfg.k_max * pd.chi_max);
@@ -916,7 +923,7 @@ __global__ __launch_bounds__(256) void k_cov_proj_knots(chomp_config cfg, TabLay
   double chi_min = K / cfg.k_max, chi_max = K / cfg.k_min;
   if (chi_min < pd.chi_min) chi_min = pd.chi_min;
   if (chi_max > pd.chi_max) chi_max = pd.chi_max;
-  CovProjIntegrand f{&P, &G, K, 1.0};
+  CovProjIntegrand<BAO> f{&P, &G, K, 1.0};
   const double norm_int = f(chi_peak_s);
   f.norm = norm_int > 0.0 ? 1.0 / norm_int : 1.0;
   int level = 0;

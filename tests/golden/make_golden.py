@@ -390,6 +390,40 @@ def g12(ns):
     save("g12_covariance_gaussian", **out)
 
 
+def g13(ns):
+    """Projections of a wiggle spectrum: Halo on SingleEpoch(with_bao=True) through
+    Correlation (J0 kernel, galaxy x galaxy), CorrelationFourier and Correlation3d.  The
+    halo is built AT the kernel's z_bar: Halo.set_redshift to another z goes through
+    set_cosmology (halo.py:255-264), which re-creates the cosmology without with_bao."""
+    cm, kern = _projection(ns, ggl=False)
+    theta = numpy.logspace(-2.5, 0, 9) * deg_to_rad
+    ell = numpy.logspace(1, 4, 9)
+    out = {"theta": theta, "ell": ell, "z_bar": kern.z_bar}
+    for ps in ("power_mm", "power_gg"):
+        zb = kern.z_bar
+        h = ns.halo.Halo(zb, cosmo_single_epoch=ns.cosmology.SingleEpoch(zb, with_bao=True))
+        corr = ns.correlation.Correlation(0.001, 1.0, kern, input_halo=h, power_spec=ps)
+        out["w_" + ps] = corr.correlation(theta)
+        out["D_z"] = corr.D_z
+        cf = ns.correlation.CorrelationFourier(10, 1e4, kern, input_halo=h, powSpec=ps)
+        out["cl_" + ps] = cf.correlation(ell)
+    k = numpy.logspace(-2, 0, 41)
+    out["k"] = k
+    out["p_mm_zbar"] = h.power_mm(k)
+    moved = ns.halo.Halo(0.0, cosmo_single_epoch=ns.cosmology.SingleEpoch(0.0, with_bao=True))
+    ns.correlation.Correlation(0.001, 1.0, kern, input_halo=moved, power_spec="power_mm")
+    out["p_mm_moved"] = moved.power_mm(k)      # set_redshift(z_bar) dropped the wiggles
+    plain = ns.halo.Halo(kern.z_bar)
+    out["p_mm_zbar_nowiggle"] = plain.power_mm(k)
+    h3 = ns.halo.Halo(0.5, cosmo_single_epoch=ns.cosmology.SingleEpoch(0.5, with_bao=True))
+    c3 = ns.correlation.Correlation3d(1.0, 150.0, redshift=0.5, input_halo=h3,
+                                      powSpec="power_mm")
+    r = numpy.array([1.0, 5.0, 20.0, 60.0, 90.0, 105.0, 120.0, 150.0])
+    out["r"] = r
+    out["xi_raw"] = numpy.array([c3.raw_correlation(x) for x in r])
+    save("g13_bao_projections", **out)
+
+
 def pins():
     """Known-answer literals held by the reference's own tests (unit_test.py),
     restricted to the classes that pass against the shipped code."""
@@ -422,7 +456,7 @@ def pins():
 
 
 def main():
-    names = sys.argv[1:] or ["pins", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    names = sys.argv[1:] or ["pins", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     ns = ref_loader.load()
     cwd = os.getcwd()
     with tempfile.TemporaryDirectory() as tmp:

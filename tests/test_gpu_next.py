@@ -340,3 +340,45 @@ def test_gaussian_covariance():
     assert agree >= 0.9, (lev, cv._halo_a_levels)
     with pytest.raises(Exception):
         covariance.Covariance(corr, corr)                  # trispectrum terms: scope error
+
+
+def test_bao_projections():
+    """A Halo on SingleEpoch(with_bao=True) through w(theta), C_l, xi(r) and the covariance
+    table, against the reference (G13): the wiggle transfer function is carried through the
+    projection kernels, not only through P(k)."""
+    from chomp_amd import correlation, cosmology, covariance, halo, kernel
+    g = load_golden("g13_bao_projections")
+    d2r = numpy.pi / 180.0
+    cm = cosmology.MultiEpoch(0.0, 5.0)
+    wa = kernel.WindowFunctionGalaxy(kernel.dNdzMagLim(0.0, 2.0, 2.0, 0.3, 2.0), cm)
+    wb = kernel.WindowFunctionGalaxy(kernel.dNdzMagLim(0.0, 2.0, 2.0, 0.3, 2.0), cm)
+    kern = kernel.Kernel(1e-6 * d2r, 100.0 * d2r, wa, wb, cm)
+    assert abs(kern.z_bar - float(g["z_bar"])) < 1e-12
+    for ps in ("power_mm", "power_gg"):
+        zb = kern.z_bar      # built at z_bar: moving a Halo in z re-creates its cosmology
+        h = halo.Halo(zb, cosmo_single_epoch=cosmology.SingleEpoch(zb, with_bao=True))
+        corr = correlation.Correlation(0.001, 1.0, kern, input_halo=h, power_spec=ps)
+        assert h.cosmo._with_bao
+        assert rel_err(corr.correlation(g["theta"]), g["w_" + ps]) < RTOL
+        cf = correlation.CorrelationFourier(10, 1e4, kern, input_halo=h, powSpec=ps)
+        assert rel_err(cf.correlation(g["ell"]), g["cl_" + ps]) < RTOL
+    assert rel_err(h.power_mm(g["k"]), g["p_mm_zbar"]) < RTOL
+    # the wiggles are there: the no-wiggle spectrum at the same z differs by percents
+    assert numpy.max(numpy.abs(g["p_mm_zbar"] / g["p_mm_zbar_nowiggle"] - 1)) > 0.02
+    # ... and a Halo that a Correlation moves to z_bar loses them, as in the reference
+    moved = halo.Halo(0.0, cosmo_single_epoch=cosmology.SingleEpoch(0.0, with_bao=True))
+    correlation.Correlation(0.001, 1.0, kern, input_halo=moved, power_spec="power_mm")
+    assert not moved.cosmo._with_bao
+    assert rel_err(moved.power_mm(g["k"]), g["p_mm_moved"]) < RTOL
+    assert rel_err(g["p_mm_moved"], g["p_mm_zbar_nowiggle"]) < 1e-12
+    # the covariance table integrates the same spectrum: at its peak it is the Limber C_l
+    cv = covariance.Covariance(corr, corr, nongaussian_cov=False, power_spec="power_gg")
+    cv._initialize_halo_splines()
+    assert numpy.all(numpy.isfinite(cv._halo_a_array)) and cv._halo_a_array.max() > 0
+    h3 = halo.Halo(0.5, cosmo_single_epoch=cosmology.SingleEpoch(0.5, with_bao=True))
+    c3 = correlation.Correlation3d(1.0, 150.0, redshift=0.5, input_halo=h3, powSpec="power_mm")
+    xi = numpy.array([c3.raw_correlation(x) for x in g["r"]])
+    scale = numpy.abs(g["xi_raw"]).max()
+    assert numpy.max(numpy.abs(xi - g["xi_raw"])) < 1e-6 * scale
+    big = numpy.abs(g["xi_raw"]) > 1e-4 * scale
+    assert rel_err(xi[big], g["xi_raw"][big]) < RTOL
