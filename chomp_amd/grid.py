@@ -123,6 +123,20 @@ class HaloGrid(object):
         return gather_rows_async(local, self.n_all, self.world, out=self._bufs["full"][turn])
 
 
+_ORDER_CACHE = {}
+
+
+def _order_tensor(n_all, world, device):
+    """unshard_order as a device index tensor, built once (a per-step host-to-device copy
+    would stall the stream the next set-up is queued on)."""
+    import torch
+    key = (n_all, world, str(device))
+    t = _ORDER_CACHE.get(key)
+    if t is None:
+        t = _ORDER_CACHE[key] = torch.as_tensor(unshard_order(n_all, world), device=device)
+    return t
+
+
 class PendingRows(object):
     """Handle of an all-gather in flight; wait() returns the [n_all, nk] grid in epoch
     order (stream-ordered: it does not block the host)."""
@@ -136,9 +150,8 @@ class PendingRows(object):
             return self._full[:self._n_all]
         if self._work is not None:
             self._work.wait()
-        order = torch.as_tensor(unshard_order(self._n_all, self._world),
-                                device=self._full.device)
-        return self._full.index_select(0, order)
+        return self._full.index_select(0, _order_tensor(self._n_all, self._world,
+                                                        self._full.device))
 
 
 def gather_rows_async(local, n_all, world, out=None):
