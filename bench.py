@@ -232,6 +232,8 @@ def main():
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--roofline-nk", type=int, default=1 << 20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true",
+                    help="development runs: the timed steps only (no stage split, roofline)")
     ap.add_argument("--rehearse", action="store_true",
                     help="test-only: run the N > 1 path on ONE GPU (every rank on device 0, "
                          "gloo all-gather through host memory); the numbers mean nothing")
@@ -317,6 +319,16 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = nz * NK * args.steps / elapsed
 
+    if args.no_roofline:
+        if rank == 0:
+            print(json.dumps({"metric": "halo-model P(k,z) samples/sec (development run)",
+                              "value": value, "unit": "samples/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": ms_per_step}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     # ---- stage split and roofline (rank 0's shard; HIP events on the kernel stream)
     def timed(fn, reps):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

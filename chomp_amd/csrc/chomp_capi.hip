@@ -211,6 +211,8 @@ int alloc_epochs(chomp_ctx* ctx, size_t n) {
   HIPCHK(hipMalloc(&ctx->d_hod, n * sizeof(HodDev)));
   HIPCHK(hipMalloc(&ctx->d_nodes, n * 3 * (size_t)kNodeStride * sizeof(double)));
   HIPCHK(hipMalloc(&ctx->d_snodes, n * (size_t)kSigmaStride * sizeof(double)));
+  // (holds the arrival counters of k_sigma_nodes: zero once, the kernel resets them)
+  HIPCHK(hipMemsetAsync(ctx->d_snodes, 0, n * (size_t)kSigmaStride * sizeof(double), ctx->stream));
   HIPCHK(hipMalloc(&ctx->d_slot, n * sizeof(int)));
   HIPCHK(hipMalloc(&ctx->d_first, n * sizeof(int)));
   ctx->cap_epoch = n;
@@ -372,7 +374,7 @@ int chomp_epochs_set(chomp_ctx* ctx, size_t n_epoch, const chomp_cosmo* cosmo,
   if (rc) return rc;
   rc = upload(ctx, ctx->d_first, first.data(), n_epoch * sizeof(int), ctx->sh_first);
   if (rc) return rc;
-  const dim3 gs((kSigmaCount + 255) / 256 + 1 + kSGrid, (unsigned)(n_slots + (n_epoch + 255) / 256));
+  const dim3 gs(kSigmaNodeBlocks + kSGrid, (unsigned)(n_slots + (n_epoch + 255) / 256));
   const dim3 gi((unsigned)n_epoch, 2 * kProbes);
   if (ctx->with_bao) {
     hipLaunchKernelGGL(k_sigma_nodes<true>, gs, dim3(256), 0, ctx->stream, ctx->cfg, ctx->d_cosmo,

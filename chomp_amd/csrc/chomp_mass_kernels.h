@@ -134,15 +134,22 @@ __host__ __device__ inline SGrid make_sgrid(double k_min, double k_max) {
   return g;
 }
 constexpr int kSigmaOffI8 = 2 * kSigmaCount, kSigmaOffLnS = 2 * kSigmaCount + 8;
-constexpr int kSigmaStride = 2 * kSigmaCount + 8 + kSGrid;  // doubles per cosmology: k[], d2[],
-                                                   // I8 = int dlnk d2 W(8k)^2 (sigma_8 norm.), ln S[]
+constexpr int kSigmaNodeBlocks = (kSigmaCount + 255) / 256;
+constexpr int kSigmaOffPart = kSigmaOffLnS + kSGrid;
+// doubles per cosmology: k[], d2[], I8 = int dlnk d2 W(8k)^2 (sigma_8 normalisation; the slot
+// after it is the arrival counter of the node blocks), ln S[], and the node blocks'
+// per-level partial sums of the sigma_8 integrand
+constexpr int kSigmaStride = kSigmaOffPart + kSigmaNodeBlocks * (kSigmaLevel + 1);
 
 // Everything here depends on the cosmology only, not on z, so it is built once per
 // distinct cosmology of the batch ("slot"; the z-axis of a (k, z) grid is one slot).
-// grid (ceil(kSigmaCount / 256) + 1 + kSGrid, n_slots + ceil(n_epoch / 256)), block 256;
-// first[s] = an epoch that has cosmology s.  For y < n_slots: after the node-table
-// blocks, one x-block does the sigma_8 integral (cosmology.py:118-119) and kSGrid blocks
-// the coarse ln S(R) table, all by direct evaluation.  The rows y >= n_slots fill in the
+// grid (kSigmaNodeBlocks + kSGrid, n_slots + ceil(n_epoch / 256)), block 256;
+// first[s] = an epoch that has cosmology s.  For y < n_slots: the node-table blocks, then
+// kSGrid blocks for the coarse ln S(R) table (direct evaluation).  The sigma_8 integral
+// (cosmology.py:118-119) lives on the same nodes as the table: every node block also sums
+// the sigma_8 integrand of its nodes per Romberg level, and the last one to finish replays
+// scipy's rows and stopping test from the level sums -- the integral costs one pass over
+// the table instead of a chain of levels.  The rows y >= n_slots fill in the
 // closed-form part of every epoch record (SingleEpoch.__init__ minus its two integrals),
 // one epoch per thread, while the cosmology-only integrals run.
 // BAO: the context's transfer function (chomp_set_transfer), fixed at compile time.
@@ -181,42 +188,132 @@ __global__ __launch_bounds__(256) void k_sigma_nodes(chomp_config cfg,
   }
   __syncthreads();
   double* n = snodes + (size_t)slot * kSigmaStride;
-  const int nb = (int)gridDim.x - 1 - kSGrid;     // node-table blocks
+  const int nb = (int)gridDim.x - kSGrid;         // node-table blocks
   if ((int)blockIdx.x >= nb) {
-    const int i = (int)blockIdx.x - nb - 1;       // -1: sigma_8 block, else ln S point
-    const double R = i < 0 ? 8.0 : exp(make_sgrid(cfg.k_min, cfg.k_max).ln_r(i));
+    const int i = (int)blockIdx.x - nb;           // ln S point
+    const double R = exp(make_sgrid(cfg.k_min, cfg.k_max).ln_r(i));
     double lo, hi;
     sigma_limits(E, R, &lo, &hi);
     SigmaIntegrandT<BAO> f{&E, R};                // sigma_norm = 1: amp * integral
-    // (the ln S points only aim the search: 1e-5 and at most 2^12 panels are plenty)
-    const double s2 = romberg1<4>(f, lo, hi, cfg.global_precision,
-                                  i < 0 ? cfg.cosmo_precision : 1e-5,
-                                  i < 0 || cfg.divmax < 12 ? cfg.divmax : 12, red);
-    if (threadIdx.x == 0) {
-      if (i < 0) n[kSigmaOffI8] = s2 / E.amp;
-      else n[kSigmaOffLnS + i] = log(s2 / E.amp);
-    }
+    // (the ln S points only aim the search: 1e-5 and at most 2^10 panels are plenty -- only
+    //  R > 100 Mpc/h would go on to 2^11, where the cap costs ~1e-4 of an estimate that the
+    //  probes certify anyway)
+    const double s2 = romberg1<4>(f, lo, hi, cfg.global_precision, 1e-5,
+                                  cfg.divmax < 10 ? cfg.divmax : 10, red);
+    if (threadIdx.x == 0) n[kSigmaOffLnS + i] = log(s2 / E.amp);
     return;
   }
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= kSigmaCount) return;
+  const bool live = idx < kSigmaCount;
   const double a = log(cfg.k_min), b = log(cfg.k_max);
-  double x;
-  if (idx < 2) {
-    x = idx == 0 ? a : b;
-  } else {
-    const int m = idx - 1;
-    const int lev = 32 - __builtin_clz((unsigned)m);
-    const long j = m - (1 << (lev - 1));
-    const double h = (b - a) / (double)(1L << (lev - 1));
-    x = (a + 0.5 * h) + h * (double)j;
+  // sigma_8 on the table's range? (cosmology.py:611-632 keeps [k_min, k_max] for R = 8
+  // with any sensible limits; otherwise the finisher integrates directly)
+  const bool tab8 = 0.1 / 8.0 > cfg.k_min && 14.0662 / 8.0 < cfg.k_max && cfg.divmax >= 1;
+  int lev = 0;
+  double g = 0.0;
+  if (live) {
+    double x;
+    if (idx < 2) {
+      x = idx == 0 ? a : b;
+    } else {
+      const int m = idx - 1;
+      lev = 32 - __builtin_clz((unsigned)m);
+      const long j = m - (1 << (lev - 1));
+      const double h = (b - a) / (double)(1L << (lev - 1));
+      x = (a + 0.5 * h) + h * (double)j;
+    }
+    const double k = exp(x);
+    const double T = transfer_t<BAO>(E, k);
+    n[idx] = k;
+    // Delta^2 shape over k^6: W(kR)^2 = 9 (sin y - y cos y)^2 / (k R)^6 then needs no division
+    const double k3 = k * k * k;
+    const double d2k6 = exp((3.0 + E.ns) * (x - E.ln_H0)) * T * T / (k3 * k3);
+    n[kSigmaCount + idx] = d2k6;
+    double sn, cs;
+    fast_sincos(8.0 * k, &sn, &cs);
+    const double t = sn - 8.0 * k * cs;
+    g = d2k6 * (9.0 / 262144.0) * (t * t);        // 9 / 8^6
   }
-  const double k = exp(x);
-  const double T = transfer_t<BAO>(E, k);
-  n[idx] = k;
-  // Delta^2 shape over k^6: W(kR)^2 = 9 (sin y - y cos y)^2 / (k R)^6 then needs no division
-  const double k3 = k * k * k;
-  n[kSigmaCount + idx] = exp((3.0 + E.ns) * (x - E.ln_H0)) * T * T / (k3 * k3);
+  // per-level sums of this block's nodes (level-major order: a block holds <= 2 levels,
+  // block 0 levels 0..8)
+  double* part = n + kSigmaOffPart + (size_t)blockIdx.x * (kSigmaLevel + 1);
+  __shared__ double wsum[4][kSigmaLevel + 1];
+  __shared__ int last_block;
+  const int first_idx = blockIdx.x * blockDim.x, last_idx = first_idx + (int)blockDim.x - 1;
+  const int lev_lo = first_idx < 2 ? 0 : 32 - __builtin_clz((unsigned)(first_idx - 1));
+  const int lev_hi = last_idx < 2 ? 0 : 32 - __builtin_clz((unsigned)(last_idx - 1));
+  const int wv = threadIdx.x >> 6;
+  for (int l = 0; l <= kSigmaLevel; ++l) {
+    double v = 0.0;
+    if (l >= lev_lo && l <= lev_hi) v = wave_sum(live && lev == l ? g : 0.0);
+    if ((threadIdx.x & 63) == 0) wsum[wv][l] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x <= kSigmaLevel)
+    part[threadIdx.x] = ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) +
+                        wsum[3][threadIdx.x];
+  int* arrivals = reinterpret_cast<int*>(n + kSigmaOffI8 + 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();               // partial sums (and table) visible before the arrival counts
+    last_block = atomicAdd(arrivals, 1) == nb - 1 ? 1 : 0;
+  }
+  __syncthreads();
+  if (!last_block) return;
+  // ---- last node block of this cosmology: sigma_8 from the level sums
+  __threadfence();
+  __shared__ double stage[kSigmaNodeBlocks * (kSigmaLevel + 1)];
+  __shared__ double S[kSigmaLevel + 1];
+  __shared__ double i8;
+  __shared__ int converged;
+  for (int q = threadIdx.x; q < nb * (kSigmaLevel + 1); q += blockDim.x)   // all loads in flight
+    stage[q] = __hip_atomic_load(n + kSigmaOffPart + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (threadIdx.x <= kSigmaLevel) {
+    double t = 0.0;
+    for (int q = 0; q < nb; ++q) t += stage[q * (kSigmaLevel + 1) + threadIdx.x];
+    S[threadIdx.x] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    // scipy.integrate.romberg's rows and stopping test on the level sums, as the replay of
+    // chomp_romberg.h does them: lane m holds the trapezoid estimate T_m, row i is
+    // sum_m C[i][m] T_m (one multiply and one butterfly per row)
+    const int lane = threadIdx.x;
+    const double range = b - a;
+    double ordsum = 0.5 * S[0], nn = 1.0;
+    double result = range * ordsum, prev = result;
+    double Tl = lane == 0 ? result : 0.0;
+    int conv = 0;
+    const int top = cfg.divmax < kSigmaLevel ? cfg.divmax : kSigmaLevel;
+    for (int i = 1; tab8 && i <= top && !conv; ++i) {
+      nn *= 2.0;
+      ordsum += S[i];
+      const double Ti = range * ordsum / nn;
+      if (lane == i) Tl = Ti;
+      result = wave_sum(lane < 32 ? CHOMP_ROMBERG_C[i][lane & 31] * Tl : 0.0);
+      const double err = fabs(result - prev);
+      prev = result;
+      if (err < cfg.global_precision || err < cfg.cosmo_precision * fabs(result)) conv = 1;
+    }
+    // (divmax below the table's level: scipy returns the last row, unconverged)
+    if (tab8 && !conv && cfg.divmax <= kSigmaLevel) conv = 1;
+    if (lane == 0) {
+      converged = conv;
+      i8 = result;
+      *arrivals = 0;
+    }
+  }
+  __syncthreads();
+  if (!converged) {                // beyond the table (or off its range): direct evaluation
+    double lo, hi;
+    sigma_limits(E, 8.0, &lo, &hi);
+    SigmaIntegrandT<BAO> f{&E, 8.0};              // sigma_norm = 1: amp * integral
+    const double s2 = romberg1<4>(f, lo, hi, cfg.global_precision, cfg.cosmo_precision,
+                                  cfg.divmax, red);
+    if (threadIdx.x == 0) i8 = s2 / E.amp;
+  }
+  if (threadIdx.x == 0) n[kSigmaOffI8] = i8;
 }
 
 // Delta^2(k) W(kR)^2 / (amp sigma_norm^2) from the table (levels <= kSigmaLevel),
@@ -258,8 +355,8 @@ __device__ __forceinline__ double sigma2_block(const Epoch& E, const double* sno
   if (need_min > E.k_min && need_max < E.k_max) {          // fixed range: table path
     const double r3 = R * R * R;
     SigmaTabIntegrand<BAO> f{&E, snode, R, 1.0 / amp2, 9.0 / (r3 * r3)};
-    const RombergOut<1> r = romberg_group<NW, 1, SigmaTabIntegrand<BAO>, UNROLL>(f, lo, hi, cfg.global_precision, rtol,
-                                                 cfg.divmax, red);
+    const RombergOut<1> r = romberg_group<NW, 1, SigmaTabIntegrand<BAO>, UNROLL>(
+        f, lo, hi, cfg.global_precision, rtol, cfg.divmax, red);
     return amp2 * r.value[0];
   }
   SigmaIntegrandT<BAO> f{&E, R};
