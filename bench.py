@@ -135,14 +135,18 @@ def projection_bench(args, world, rank, local):
     from chomp_amd import cosmology, correlation, halo, kernel
     d2r = numpy.pi / 180.0
     cm = cosmology.MultiEpoch(0.0, 5.0)
-    wa = kernel.WindowFunctionGalaxy(kernel.dNdzMagLim(0.0, 2.0, 2.0, 0.3, 2.0), cm)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):     # (the reference's z_max warning)
+        lens_a = kernel.dNdzMagLim(0.0, 2.0, 2.0, 0.3, 2.0)
+        lens_b = kernel.dNdzMagLim(0.0, 2.0, 2.0, 0.3, 2.0)
+    wa = kernel.WindowFunctionGalaxy(lens_a, cm)
     if ggl:
         wb = kernel.WindowFunctionConvergence(kernel.dNdzGaussian(0.0, 2.0, 1.0, 0.2), cm)
         kern = kernel.GalaxyGalaxyLensingKernel(1e-6 * d2r, 100.0 * d2r, wa, wb, cm)
         h = halo.HaloFit(0.0)
         spec = "power_gm"
     else:
-        wb = kernel.WindowFunctionGalaxy(kernel.dNdzMagLim(0.0, 2.0, 2.0, 0.3, 2.0), cm)
+        wb = kernel.WindowFunctionGalaxy(lens_b, cm)
         kern = kernel.Kernel(1e-6 * d2r, 100.0 * d2r, wa, wb, cm)
         h = halo.Halo(0.0)
         spec = "power_gg"

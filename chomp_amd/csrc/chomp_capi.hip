@@ -69,7 +69,8 @@ struct chomp_ctx {
   int* d_slow = nullptr;           // Stage E: 2 counters + list of k groups for the per-lane pass
   int* d_winfo = nullptr;          // Stage E: per k group knot interval / flags (k_power_prep)
   double* d_ktab = nullptr;        // Stage E: per-k (offset, shape) table (k_power_prep)
-  size_t cap_slow = 0, cap_winfo = 0, cap_ktab = 0;
+  double* d_wnodes = nullptr;      // w(theta): theta-independent integrand factor on the Romberg nodes
+  size_t cap_slow = 0, cap_winfo = 0, cap_ktab = 0, cap_wnodes = 0;
   int slow_parity = 0;
   int precision = CHOMP_PREC_F64;  // chomp_set_precision
   int with_bao = 0;                // chomp_set_transfer
@@ -289,7 +290,7 @@ void chomp_ctx_destroy(chomp_ctx* ctx) {
   void* ptrs[] = {ctx->d_sici, ctx->d_j0, ctx->d_j2, ctx->d_tinker, ctx->d_gl16,
                   ctx->d_cand, ctx->d_cosmo, ctx->d_z, ctx->d_epochs, ctx->d_search, ctx->d_probe, ctx->d_count, ctx->d_pending,
                   ctx->d_tab, ctx->d_mass_par, ctx->d_profile, ctx->d_hod, ctx->d_nodes, ctx->d_snodes, ctx->d_slot, ctx->d_first,
-                  ctx->d_stage_in, ctx->d_stage_in2, ctx->d_stage_out, ctx->d_work, ctx->d_slow,
+                  ctx->d_stage_in, ctx->d_stage_in2, ctx->d_stage_out, ctx->d_work, ctx->d_slow, ctx->d_wnodes,
                   ctx->d_winfo, ctx->d_ktab};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);

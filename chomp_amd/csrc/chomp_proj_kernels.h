@@ -512,6 +512,60 @@ struct WthetaIntegrand {
   }
 };
 
+// Every theta integrates over the same ln k range, so all of them visit the same Romberg
+// nodes and the theta-independent factor k^2/(2 pi) P(k)/D_z^2 of the integrand is
+// tabulated once per call on the level-LT grid (level-major, as the sigma(R) and halo node
+// tables): per node a theta block then only evaluates the kernel spline.
+// grid ceil((2^LT + 1) / 256), block 256.
+constexpr int kWthetaTabLevel = 20;     // 2^20 + 1 doubles = 8 MiB: the default divmax
+template <bool HF, bool BAO>
+__global__ __launch_bounds__(256) void k_wtheta_nodes(chomp_config cfg, TabLayout HL,
+                                                      const Epoch* __restrict__ epochs, int e,
+                                                      const double* __restrict__ htab, int which,
+                                                      double k_min, double k_max, double D_z,
+                                                      int LT, double* __restrict__ nodes) {
+  extern __shared__ __align__(16) double sm[];
+  __shared__ Epoch E;
+  copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
+               kEpochDoubles);
+  PowerEval P;
+  P.stage(cfg, HL, &E, htab + (size_t)e * HL.stride, which, sm);
+  __syncthreads();
+  P.template finish_t<BAO>();
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx > (1L << LT)) return;
+  const double a = log(k_min), b = log(k_max), intrange = b - a;
+  double x;
+  if (idx < 2) {
+    x = idx == 0 ? a : b;
+  } else {                                   // the node arithmetic of chomp_romberg.h
+    const unsigned m = (unsigned)(idx - 1);
+    const int lev = 32 - __builtin_clz(m);
+    const long j = (long)m - (1L << (lev - 1));
+    const double h = intrange / (double)(1L << (lev - 1));
+    x = (a + 0.5 * h) + h * (double)j;
+  }
+  const double k = exp(x);
+  nodes[idx] = k * k / (2.0 * kPi) * P.template at_ln<HF, BAO>(x, k) * (1.0 / (D_z * D_z));
+}
+
+// correlation.py:270-275 from the node table (levels <= LT), directly beyond
+template <bool HF, bool BAO>
+struct WthetaTabIntegrand {
+  const double* nodes;
+  int LT;
+  WthetaIntegrand<HF, BAO> direct;
+  __device__ __forceinline__ void operator()(double ln_k, double (&out)[1], int lev,
+                                             long j) const {
+    if (lev <= LT) {
+      const long idx = lev == 0 ? j : 1 + (1L << (lev - 1)) + j;
+      out[0] = nodes[idx] * (*direct.K)(ln_k + direct.ln_theta);
+    } else {
+      out[0] = direct(ln_k);
+    }
+  }
+};
+
 // grid n_theta, block 64 * kWthetaNW: one theta per workgroup.  The integrals of large
 // theta run to 2^18..2^20 nodes (the kernel oscillates in ln k theta) and set the launch's
 // duration, hence the wide group.
@@ -524,7 +578,8 @@ __global__ __launch_bounds__(64 * kWthetaNW) void k_wtheta(chomp_config cfg, Tab
                                                 const double* __restrict__ ptab, double k_min,
                                                 double k_max, double D_z,
                                                 const double* __restrict__ theta,
-                                                double* __restrict__ out) {
+                                                double* __restrict__ out,
+                                                const double* __restrict__ nodes, int LT) {
   extern __shared__ __align__(16) double sm[];
   __shared__ Epoch E;
   __shared__ double red[romberg_scratch<kWthetaNW, 2>()];
@@ -537,10 +592,12 @@ __global__ __launch_bounds__(64 * kWthetaNW) void k_wtheta(chomp_config cfg, Tab
   __syncthreads();
   P.template finish_t<BAO>();
   const KernelView K{kpp, L.NKT, pd->ln_kt_min, pd->ln_kt_max};
-  WthetaIntegrand<HF, BAO> f{&P, &K, theta[blockIdx.x], 1.0 / (D_z * D_z), log(theta[blockIdx.x])};
-  const double v = romberg1<kWthetaNW>(f, log(k_min), log(k_max), cfg.global_precision,
-                               cfg.corr_precision, cfg.divmax, red);
-  if (threadIdx.x == 0) out[blockIdx.x] = v;
+  const double th = theta[blockIdx.x];
+  WthetaTabIntegrand<HF, BAO> f{nodes, LT, {&P, &K, th, 1.0 / (D_z * D_z), log(th)}};
+  const RombergOut<1> r = romberg_group<kWthetaNW, 1>(f, log(k_min), log(k_max),
+                                                      cfg.global_precision, cfg.corr_precision,
+                                                      cfg.divmax, red);
+  if (threadIdx.x == 0) out[blockIdx.x] = r.value[0];
 }
 
 // ---------------------------------------------------------------------------
