@@ -70,7 +70,8 @@ struct chomp_ctx {
   int* d_winfo = nullptr;          // Stage E: per k group knot interval / flags (k_power_prep)
   double* d_ktab = nullptr;        // Stage E: per-k (offset, shape) table (k_power_prep)
   double* d_wnodes = nullptr;      // w(theta): theta-independent integrand factor on the Romberg nodes
-  size_t cap_slow = 0, cap_winfo = 0, cap_ktab = 0, cap_wnodes = 0;
+  double* d_deep = nullptr;        // k_halo_deep_*: Romberg state and chunk sums of the listed knots
+  size_t cap_slow = 0, cap_winfo = 0, cap_ktab = 0, cap_wnodes = 0, cap_deep = 0;
   int slow_parity = 0;
   int precision = CHOMP_PREC_F64;  // chomp_set_precision
   int with_bao = 0;                // chomp_set_transfer
@@ -290,7 +291,7 @@ void chomp_ctx_destroy(chomp_ctx* ctx) {
   void* ptrs[] = {ctx->d_sici, ctx->d_j0, ctx->d_j2, ctx->d_tinker, ctx->d_gl16,
                   ctx->d_cand, ctx->d_cosmo, ctx->d_z, ctx->d_epochs, ctx->d_search, ctx->d_probe, ctx->d_count, ctx->d_pending,
                   ctx->d_tab, ctx->d_mass_par, ctx->d_profile, ctx->d_hod, ctx->d_nodes, ctx->d_snodes, ctx->d_slot, ctx->d_first,
-                  ctx->d_stage_in, ctx->d_stage_in2, ctx->d_stage_out, ctx->d_work, ctx->d_slow, ctx->d_wnodes,
+                  ctx->d_stage_in, ctx->d_stage_in2, ctx->d_stage_out, ctx->d_work, ctx->d_slow, ctx->d_wnodes, ctx->d_deep,
                   ctx->d_winfo, ctx->d_ktab};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -477,7 +478,34 @@ int chomp_halo_setup(chomp_ctx* ctx, const chomp_halo_par* profile,
     // when the list is long, cheap to launch when it is empty
     unsigned gd = (unsigned)(L.NK * n * ng);
     if (gd > 2048) gd = 2048;
-    if (n * ng <= 4) {             // few epochs: wide groups, the deep knots set the duration
+    const bool hod_groups = groups[0] > 0 || groups[1] > 0 || groups[2] > 0;
+    if (n * ng <= 4 && hod_groups) {
+      // few epochs, HOD integrands (the ones that run to 2^18..2^20 nodes): every level of
+      // the listed knots is spread over the whole grid -- head, then (level, advance) per
+      // level; finished knots cost a flag test, an empty list one load per block
+      const int top = ctx->cfg.divmax;
+      const size_t items = (size_t)L.NK * n * ng;
+      const int pstride = top > kDeepHead ? (int)(((size_t)1 << (top - 1)) / kDeepChunk) : 1;
+      const int rcd = ensure(ctx, &ctx->d_deep, &ctx->cap_deep,
+                             items * ((size_t)kDeepState + 2 * (size_t)pstride));
+      if (rcd) return rcd;
+      double* d_state = ctx->d_deep;
+      double* d_part = ctx->d_deep + items * kDeepState;
+      const size_t shw = (size_t)(L.NM + 8 * (L.NM - 1) + romberg_scratch<4, 2>()) * sizeof(double);
+      hipLaunchKernelGGL(k_halo_deep_head, dim3((unsigned)items), dim3(256), shw, ctx->stream,
+                         ctx->cfg, L, ctx->d_epochs, ctx->d_tab, ctx->d_profile, ctx->d_hod,
+                         ctx->d_sici, groups[0], groups[1], groups[2], kmask, (int)n,
+                         ctx->d_pending, d_state);
+      for (int lev = kDeepHead + 1; lev <= top; ++lev) {
+        hipLaunchKernelGGL(k_halo_deep_level, dim3(1024), dim3(256), shw, ctx->stream, ctx->cfg,
+                           L, ctx->d_epochs, ctx->d_tab, ctx->d_profile, ctx->d_hod, ctx->d_sici,
+                           groups[0], groups[1], groups[2], kmask, (int)n, ctx->d_pending,
+                           d_state, d_part, pstride, lev);
+        hipLaunchKernelGGL(k_halo_deep_advance, dim3((unsigned)((items + 3) / 4)), dim3(256), 0,
+                           ctx->stream, ctx->cfg, L, ctx->d_tab, groups[0], groups[1], groups[2],
+                           kmask, (int)n, ctx->d_pending, d_state, d_part, pstride, lev);
+      }
+    } else if (n * ng <= 4) {      // few epochs: wide groups, the deep knots set the duration
       const size_t shw = (size_t)(L.NM + 8 * (L.NM - 1) + romberg_scratch<8, 2>()) * sizeof(double);
       hipLaunchKernelGGL(k_halo_knots_deep<8>, dim3(gd), dim3(512), shw, ctx->stream, ctx->cfg,
                          L, ctx->d_epochs, ctx->d_tab, ctx->d_profile, ctx->d_hod, ctx->d_sici,

@@ -419,6 +419,236 @@ __global__ __launch_bounds__(64 * NW) void k_halo_knots_deep(
 }
 
 // ---------------------------------------------------------------------------
+// The deep knots of a FEW epochs (a single Halo object: at most 150 knots): with one block
+// per knot the handful of integrals that run to 2^20 nodes would set the duration on a
+// mostly idle chip, so each Romberg level is spread over the whole grid instead.
+//   k_halo_deep_head     one block per listed knot: levels <= kDeepHead by direct
+//                        evaluation; knots that stop there are final, the others leave
+//                        their Romberg state (chomp_romberg.h `dump`) in `state`
+//   k_halo_deep_level    level i: the 2^(i-1) new nodes of every unfinished knot in chunks
+//                        of kDeepChunk nodes over all blocks; partial sums per chunk
+//   k_halo_deep_advance  level i: one wavefront per knot adds the chunk sums in order and
+//                        does the row / stopping test of scipy.integrate.romberg
+// The host queues head, then (level, advance) for every level up to divmax; finished knots
+// cost a flag test.  Same nodes, same rows and stopping rule as k_halo_knots_deep -- only
+// the order in which a level's node values are added differs.
+// ---------------------------------------------------------------------------
+constexpr int kDeepHead = 11;                 // levels of the head pass (2049 nodes)
+constexpr int kDeepChunk = 2048;              // nodes per work item of a level pass
+// per knot: 2 x kRombergDump state, a, b, done[2], level[2], value[2]
+constexpr int kDeepState = 2 * kRombergDump + 8;
+constexpr int kDsA = 2 * kRombergDump, kDsB = kDsA + 1, kDsDone = kDsA + 2, kDsLevel = kDsA + 4,
+              kDsValue = kDsA + 6;
+
+struct DeepItem {
+  int ik, e, group, fa, fb;
+  bool pa, pb;
+};
+__device__ __forceinline__ DeepItem deep_item(const TabLayout& L, const int* pending, int p,
+                                              int n_epoch, int g0, int g1, int g2,
+                                              unsigned mask, const double* tab) {
+  DeepItem d;
+  const int item = pending[2 + p], NK = L.NK;
+  d.ik = item % NK;
+  d.e = (item / NK) % n_epoch;
+  const int zg = item / (NK * n_epoch);
+  d.group = zg == 0 ? g0 : (zg == 1 ? g1 : g2);
+  d.fa = group_fa(d.group);
+  d.fb = group_fb(d.group);
+  const double* lev = tab + (size_t)d.e * L.stride + L.off_levels;
+  d.pa = d.group != 2 && (mask & (1u << d.fa)) && lev[d.fa * NK + d.ik] == kPendingLevel;
+  d.pb = (mask & (1u << d.fb)) && lev[d.fb * NK + d.ik] == kPendingLevel;
+  return d;
+}
+
+// One node of a knot's integrand pair (group 2 has one integrand: out[0] = 0).
+__device__ __forceinline__ void deep_eval(int group, const HaloCtx& c, bool pa, double x,
+                                          double (&out)[2]) {
+  if (group == 0) {
+    IntegrandMM f{c};
+    f(x, out);
+  } else if (group == 1) {
+    IntegrandGM f{c, pa};
+    f(x, out);
+  } else {
+    IntegrandGG f{c};
+    double o1[1];
+    f(x, o1);
+    out[0] = 0.0;
+    out[1] = o1[0];
+  }
+}
+
+// grid any (blocks stride over the list), block 256.
+__global__ __launch_bounds__(256) void k_halo_deep_head(
+    chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs, double* __restrict__ tab,
+    const chomp_halo_par* __restrict__ profile, const HodDev* __restrict__ hod,
+    const SiCiTab* __restrict__ sici_g, int g0, int g1, int g2, unsigned mask, int n_epoch,
+    const int* __restrict__ pending, double* __restrict__ state) {
+  extern __shared__ __align__(16) double sm[];
+  __shared__ Epoch E;
+  __shared__ SiCiTab S;
+  const int NK = L.NK;
+  const int count = pending[0];
+  for (int p = blockIdx.x; p < count; p += gridDim.x) {
+    __syncthreads();               // (previous knot done with E, S, sm)
+    const DeepItem d = deep_item(L, pending, p, n_epoch, g0, g1, g2, mask, tab);
+    double* st = state + (size_t)p * kDeepState;
+    if (d.group < 0 || d.group > 2 || (!d.pa && !d.pb)) {
+      if (threadIdx.x == 0) { st[kDsDone] = 1.0; st[kDsDone + 1] = 1.0; }
+      continue;
+    }
+    double* t = tab + (size_t)d.e * L.stride;
+    HaloLds H;
+    H.stage(L, E, S, epochs, d.e, t, profile, hod, sici_g, sm);
+    double* red = H.rest;
+    const double a = group_lower(E, d.group), b = log(E.nu_max);
+    HaloCtx c{&E, &S, H.nu_knots, H.lnm_pp, L.NM,
+              linspace_at(log(cfg.k_min), log(cfg.k_max), NK, d.ik), (mask & kMaskExclusion) != 0};
+    const int top = cfg.divmax < kDeepHead ? cfg.divmax : kDeepHead;
+    double va, vb;
+    int la, lb;
+    bool ca, cb;
+    if (d.group == 0) {
+      IntegrandMM f{c};
+      const RombergOut<2> r = romberg_group<4, 2>(f, a, b, cfg.global_precision,
+                                                  cfg.halo_precision, top, red, st);
+      va = r.value[0]; vb = r.value[1]; la = r.level[0]; lb = r.level[1];
+      ca = r.converged[0]; cb = r.converged[1];
+    } else if (d.group == 1) {
+      IntegrandGM f{c, d.pa};
+      const RombergOut<2> r = romberg_group<4, 2>(f, a, b, cfg.global_precision,
+                                                  cfg.halo_precision, top, red, st);
+      va = r.value[0]; vb = r.value[1]; la = r.level[0]; lb = r.level[1];
+      ca = r.converged[0]; cb = r.converged[1];
+    } else {
+      IntegrandGG f{c};
+      const RombergOut<1> r = romberg_group<4, 1>(f, a, b, cfg.global_precision,
+                                                  cfg.halo_precision, top, red,
+                                                  st + kRombergDump);
+      va = 0.0; vb = r.value[0]; la = 0; lb = r.level[0];
+      ca = true; cb = r.converged[0];
+    }
+    if (threadIdx.x == 0) {
+      const bool last = cfg.divmax <= kDeepHead;       // scipy returns the last row then
+      const bool fin_a = !d.pa || ca || last, fin_b = !d.pb || cb || last;
+      double* lev = t + L.off_levels;
+      if (d.pa && fin_a) { t[L.off_knot[d.fa] + d.ik] = va; lev[d.fa * NK + d.ik] = (double)la; }
+      if (d.pb && fin_b) { t[L.off_knot[d.fb] + d.ik] = vb; lev[d.fb * NK + d.ik] = (double)lb; }
+      st[kDsA] = a;
+      st[kDsB] = b;
+      st[kDsDone] = fin_a ? 1.0 : 0.0;
+      st[kDsDone + 1] = fin_b ? 1.0 : 0.0;
+    }
+  }
+}
+
+// grid any, block 256: level `lev` (> kDeepHead) of every unfinished knot.
+__global__ __launch_bounds__(256) void k_halo_deep_level(
+    chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs,
+    const double* __restrict__ tab, const chomp_halo_par* __restrict__ profile,
+    const HodDev* __restrict__ hod, const SiCiTab* __restrict__ sici_g, int g0, int g1, int g2,
+    unsigned mask, int n_epoch, const int* __restrict__ pending,
+    const double* __restrict__ state, double* __restrict__ part, int pstride, int lev) {
+  extern __shared__ __align__(16) double sm[];
+  __shared__ Epoch E;
+  __shared__ SiCiTab S;
+  const int NK = L.NK;
+  const int count = pending[0];
+  const long numtosum = 1L << (lev - 1);
+  const int nchunk = (int)(numtosum / kDeepChunk);     // lev > kDeepHead: >= 1
+  const long total = (long)count * nchunk;
+  const long per = (total + gridDim.x - 1) / gridDim.x;   // consecutive items: one knot's
+  long w = (long)blockIdx.x * per;                        // staging serves several chunks
+  const long w_end = w + per < total ? w + per : total;
+  int staged = -1;
+  HaloLds H;
+  DeepItem d;
+  int flip = 0;
+  for (; w < w_end; ++w) {
+    const int p = (int)(w / nchunk), ch = (int)(w % nchunk);
+    const double* st = state + (size_t)p * kDeepState;
+    const bool da = st[kDsDone] != 0.0, db = st[kDsDone + 1] != 0.0;
+    if (da && db) { w += nchunk - 1 - ch; continue; }   // block-uniform: skip the knot
+    if (p != staged) {
+      __syncthreads();
+      d = deep_item(L, pending, p, n_epoch, g0, g1, g2, mask, tab);
+      H.stage(L, E, S, epochs, d.e, tab + (size_t)d.e * L.stride, profile, hod, sici_g, sm);
+      staged = p;
+      flip = 0;
+    }
+    const double a = st[kDsA], b = st[kDsB];
+    HaloCtx c{&E, &S, H.nu_knots, H.lnm_pp, L.NM,
+              linspace_at(log(cfg.k_min), log(cfg.k_max), NK, d.ik), (mask & kMaskExclusion) != 0};
+    const double h = (b - a) / (double)numtosum;
+    const double lox = a + 0.5 * h;
+    double s0 = 0.0, s1 = 0.0;
+    const long j0 = (long)ch * kDeepChunk + threadIdx.x;
+#pragma unroll 2
+    for (int i = 0; i < kDeepChunk / 256; ++i) {
+      double o[2];
+      deep_eval(d.group, c, d.pa && !da, lox + h * (double)(j0 + 256L * i), o);
+      s0 += o[0];
+      s1 += o[1];
+    }
+    const double t0 = group_sum<4>(s0, H.rest, flip);
+    const double t1 = group_sum<4>(s1, H.rest, flip);
+    if (threadIdx.x == 0) {
+      double* out = part + ((size_t)p * pstride + ch) * 2;   // pstride: chunks of level divmax
+      out[0] = t0;
+      out[1] = t1;
+    }
+  }
+}
+
+// grid ceil(max knots / 4), block 256: one wavefront per listed knot.
+__global__ __launch_bounds__(256) void k_halo_deep_advance(
+    chomp_config cfg, TabLayout L, double* __restrict__ tab, int g0, int g1, int g2,
+    unsigned mask, int n_epoch, const int* __restrict__ pending, double* __restrict__ state,
+    const double* __restrict__ part, int pstride, int lev) {
+  const int count = pending[0];
+  const int p = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  if (p >= count) return;
+  double* st = state + (size_t)p * kDeepState;
+  const bool done_a = st[kDsDone] != 0.0, done_b = st[kDsDone + 1] != 0.0;
+  if (done_a && done_b) return;
+  const DeepItem d = deep_item(L, pending, p, n_epoch, g0, g1, g2, mask, tab);
+  const int nchunk = (int)((1L << (lev - 1)) / kDeepChunk);
+  const double range = st[kDsB] - st[kDsA];
+  const double n = (double)(1L << lev);
+  const double c_il = CHOMP_ROMBERG_C[lev][lane & 31];
+  const bool last = lev >= cfg.divmax;
+  double* t = tab + (size_t)d.e * L.stride;
+  double* levs = t + L.off_levels;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    if (q == 0 ? done_a : done_b) continue;             // wave-uniform
+    double s = 0.0;                // chunk sums in chunk order: lane-strided, then the lanes
+    for (int ch = lane; ch < nchunk; ch += 64) s += part[((size_t)p * pstride + ch) * 2 + q];
+    const double S = wave_sum(s);
+    double* sq = st + q * kRombergDump;
+    const double ordsum = sq[32] + S;
+    const double Ti = range * ordsum / n;
+    double Tl = lane < 32 ? sq[lane] : 0.0;
+    if (lane == lev) Tl = Ti;
+    const double cur = wave_sum(lane < 32 ? c_il * Tl : 0.0);
+    const double err = fabs(cur - sq[33]);
+    const bool conv = err < cfg.global_precision || err < cfg.halo_precision * fabs(cur);
+    if (lane == lev) sq[lane] = Ti;
+    if (lane == 0) {
+      sq[32] = ordsum;
+      sq[33] = cur;
+      if (conv || last) {
+        const int fam = q == 0 ? d.fa : d.fb;
+        t[L.off_knot[fam] + d.ik] = cur;
+        levs[fam * L.NK + d.ik] = (double)lev;
+        st[kDsDone + q] = 1.0;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // k_halo_finalize: grid n_epoch, block 384 (6 wavefronts).  Wavefront f < 5
 // normalises family f and builds its not-a-knot spline over ln k (the five builds
 // run in lockstep, parallel cyclic reduction); lane 0 of wavefront 5 writes the

@@ -111,10 +111,16 @@ __device__ __forceinline__ void call_f(const F& f, double x, double (&o)[NF], in
 // stops at level <= L0 still returns exactly that level's value.
 // UNROLL: node evaluations issued together in the level loop (their table loads overlap);
 // the partial sums are still added in node order, so the result does not depend on it.
+// dump (optional, global or LDS memory, kRombergDump * NF doubles): the state the
+// integral stopped in -- per integrand the 32 trapezoid estimates T_m, then the running
+// node sum and the last row's value -- so that another kernel can carry it on to deeper
+// levels (k_halo_deep_level / k_halo_deep_advance).
+constexpr int kRombergDump = 34;
 template <int NW, int NF, class F, int UNROLL = 1>
 __device__ __forceinline__ RombergOut<NF> romberg_group(const F& f, double a, double b,
                                                         double tol, double rtol,
-                                                        int divmax, double* red) {
+                                                        int divmax, double* red,
+                                                        double* dump = nullptr) {
   constexpr int NT = 64 * NW;
   const int lane = threadIdx.x & 63;
   const int gt = (NW == 1) ? lane : (int)threadIdx.x;
@@ -301,6 +307,16 @@ __device__ __forceinline__ RombergOut<NF> romberg_group(const F& f, double a, do
   }
 #pragma unroll
   for (int q = 0; q < NF; ++q) out.converged[q] = done[q];
+  if (dump != nullptr && (NW == 1 || threadIdx.x < 64)) {
+#pragma unroll
+    for (int q = 0; q < NF; ++q) {
+      if (lane < 32) dump[q * kRombergDump + lane] = Tl[q];
+      if (lane == 0) {
+        dump[q * kRombergDump + 32] = ordsum[q];
+        dump[q * kRombergDump + 33] = prev[q];
+      }
+    }
+  }
   return out;
 }
 
