@@ -120,15 +120,19 @@ __global__ __launch_bounds__(256) void k_halofit_sigma(chomp_config cfg, TabLayo
   if (threadIdx.x == 0) tab[(size_t)e * L.stride + L.off_hf_lns2 + i] = log(s2);
 }
 
-// grid 1, block 64 (one lane works): k_sigma, n_eff, C and the Takahashi et al.
-// coefficients (halo.py:1285-1317) of epoch `src` stored into epoch `dst`.
+// grid 1, block 64 (one lane works, on LDS copies: the serial spline and quintic solves
+// are chains of dependent loads): k_sigma, n_eff, C and the Takahashi et al. coefficients
+// (halo.py:1285-1317) of epoch `src` stored into epoch `dst`.  Dynamic LDS: 25 NK + 64 doubles.
 __global__ void k_halofit_finalize(TabLayout L, Epoch* __restrict__ epochs, int dst, int src,
                                    const double* __restrict__ tab, double f1, double f2,
-                                   double f3, double omega_l, double w,
-                                   double* __restrict__ work) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+                                   double f3, double omega_l, double w) {
+  extern __shared__ __align__(16) double work[];
   const int n = L.NK;
-  const double* lns2 = tab + (size_t)src * L.stride + L.off_hf_lns2;
+  double* lns2 = work + 24 * n + 64;
+  for (int i = threadIdx.x; i < n; i += blockDim.x)
+    lns2[i] = tab[(size_t)src * L.stride + L.off_hf_lns2 + i];
+  __syncthreads();
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double* xr = work;             // reversed ln sigma^2 (increasing)
   double* yr = xr + n;           // reversed ln R
   double* lnR = yr + n;
@@ -230,22 +234,36 @@ __device__ __forceinline__ MEView me_view(const ProjLayout& L, const ProjDev& pd
                 tab + L.me_pp_g[m], L.NC, pd.me_z_min[m], pd.me_z_max[m]};
 }
 
+// Not-a-knot build of one spline per wavefront, in LDS: the lanes copy the knots in, the
+// wavefronts run the parallel cyclic reduction of chomp_mass_kernels.h in lockstep and copy
+// their coefficients out.  Every thread of the block calls it (block barriers); `mine`:
+// this wavefront has a system.  lds: 11 n doubles per wavefront.
+__device__ __forceinline__ void spline_build_staged(const double* x, const double* y, int n,
+                                                    double* c, double* lds, bool mine) {
+  const int lane = threadIdx.x & 63;
+  double* lx = lds;
+  double* ly = lx + n;
+  double* lw = ly + n;            // [9n]
+  if (mine)
+    for (int i = lane; i < n; i += 64) { lx[i] = x[i]; ly[i] = y[i]; }
+  __syncthreads();
+  spline_build_pcr(lx, ly, n, c, lw, lane, 64, mine);
+  __threadfence_block();
+  __syncthreads();
+}
+
 // grid 3, block 192.  Splines of MultiEpoch m; blocks 1/2 then lay out window
 // (m-1)'s chi grid (kernel.py:298-304, 438-441).
 __global__ __launch_bounds__(192) void k_proj_me_splines(chomp_config cfg, ProjLayout L,
                                                          ProjDev* __restrict__ pd,
-                                                         double* __restrict__ tab,
-                                                         double* __restrict__ work) {
+                                                         double* __restrict__ tab) {
+  extern __shared__ __align__(16) double sm_me[];      // 3 x 11 NC doubles
   const int m = blockIdx.x, NC = L.NC;
-  double* wk = work + (size_t)m * 6 * NC;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane == 0) {
-    if (wave == 0) spline_build(tab + L.me_z[m], tab + L.me_chi[m], NC, tab + L.me_pp_chi[m], wk);
-    if (wave == 1) spline_build(tab + L.me_chi[m], tab + L.me_z[m], NC, tab + L.me_pp_z[m], wk + 2 * NC);
-    if (wave == 2) spline_build(tab + L.me_z[m], tab + L.me_growth[m], NC, tab + L.me_pp_g[m], wk + 4 * NC);
-  }
-  __threadfence_block();
-  __syncthreads();
+  const int wave = threadIdx.x >> 6;
+  const double* sx = tab + (wave == 1 ? L.me_chi[m] : L.me_z[m]);
+  const double* sy = tab + (wave == 0 ? L.me_chi[m] : (wave == 1 ? L.me_z[m] : L.me_growth[m]));
+  double* sc = tab + (wave == 0 ? L.me_pp_chi[m] : (wave == 1 ? L.me_pp_z[m] : L.me_pp_g[m]));
+  spline_build_staged(sx, sy, NC, sc, sm_me + (size_t)wave * 11 * NC, true);
   if (m == 0) return;
   const int w = m - 1;
   __shared__ double lim[2];
@@ -329,38 +347,48 @@ struct WindowView {
 // grid 1, block 128: window splines, then Kernel.__init__ scalars + _find_z_bar.
 __global__ __launch_bounds__(128) void k_proj_window_splines(chomp_config cfg, ProjLayout L,
                                                              ProjDev* __restrict__ pd,
-                                                             double* __restrict__ tab,
-                                                             double* __restrict__ work) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane == 0)
-    spline_build(tab + L.w_chi[wave], tab + L.w_wf[wave], L.NWp, tab + L.w_pp[wave],
-                 work + (size_t)wave * 2 * L.NWp);
-  __threadfence_block();
-  __syncthreads();
-  if (threadIdx.x != 0) return;
+                                                             double* __restrict__ tab) {
+  extern __shared__ __align__(16) double sm_w[];       // 2 x 11 NWp doubles
+  const int wave = threadIdx.x >> 6;
+  spline_build_staged(tab + L.w_chi[wave], tab + L.w_wf[wave], L.NWp, tab + L.w_pp[wave],
+                      sm_w + (size_t)wave * 11 * L.NWp, true);
   const MEView me = me_view(L, *pd, tab, 0);
   const WindowView wa{tab + L.w_pp[0], L.NWp, pd->w_chi_min[0], pd->w_chi_max[0]};
   const WindowView wb{tab + L.w_pp[1], L.NWp, pd->w_chi_min[1], pd->w_chi_max[1]};
   const double z_min = pd->w_z_min[0] > pd->w_z_min[1] ? pd->w_z_min[0] : pd->w_z_min[1];
   const double z_max = pd->w_z_max[0] < pd->w_z_max[1] ? pd->w_z_max[0] : pd->w_z_max[1];
+  for (int i = threadIdx.x; i < L.NKT; i += blockDim.x)
+    tab[L.k_ln + i] = linspace_at(pd->ln_kt_min, pd->ln_kt_max, L.NKT, i);
+  // _find_z_bar (:635-639): argmax over linspace(z_min, z_max, NKT) of W_a W_b D^2 --
+  // numpy.argmax: the first of equal maxima.  One candidate per thread, then thread 0 scans
+  // the values in order.
+  __shared__ double cand_v[128];
+  for (int base = 0; base < L.NKT; base += 128) {        // (NKT <= 128 in any sensible set-up)
+    const int i = base + (int)threadIdx.x;
+    if (i < L.NKT && i < base + 128) {
+      const double z = linspace_at(z_min, z_max, L.NKT, i);
+      const double chi = me.comoving_distance(z);
+      const double D = me.growth_factor(me.redshift(chi));
+      cand_v[threadIdx.x] = wa(chi) * wb(chi) * D * D;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double best = base == 0 ? -INFINITY : pd->D_zbar;  // (D_zbar: scratch for the running maximum)
+      double zb = base == 0 ? z_min : pd->z_bar;
+      for (int q = 0; q < 128 && base + q < L.NKT; ++q)
+        if (cand_v[q] > best) { best = cand_v[q]; zb = linspace_at(z_min, z_max, L.NKT, base + q); }
+      pd->z_bar = zb;
+      pd->D_zbar = best;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
   pd->z_min = z_min;                                               // kernel.py:595-598
   pd->z_max = z_max;
   const double c0 = me.comoving_distance(z_min);
   pd->chi_min = cfg.window_precision > c0 ? cfg.window_precision : c0;   // :610-612
   pd->chi_max = me.comoving_distance(z_max);
-  for (int i = 0; i < L.NKT; ++i)
-    tab[L.k_ln + i] = linspace_at(pd->ln_kt_min, pd->ln_kt_max, L.NKT, i);
-  // _find_z_bar (:635-639): argmax over linspace(z_min, z_max, NKT) of W_a W_b D^2
-  double best = -INFINITY, zb = z_min;
-  for (int i = 0; i < L.NKT; ++i) {
-    const double z = linspace_at(z_min, z_max, L.NKT, i);
-    const double chi = me.comoving_distance(z);
-    const double D = me.growth_factor(me.redshift(chi));
-    const double v = wa(chi) * wb(chi) * D * D;
-    if (v > best) { best = v; zb = z; }
-  }
-  pd->z_bar = zb;
-  pd->D_zbar = me.growth_factor(zb);                               // correlation.py:94
+  pd->D_zbar = me.growth_factor(pd->z_bar);                        // correlation.py:94
 }
 
 // LDS-resident view of everything a projection integrand needs.
@@ -449,10 +477,9 @@ __global__ __launch_bounds__(256) void k_proj_kernel_knots(chomp_config cfg, Pro
   }
 }
 
-__global__ void k_proj_kernel_spline(ProjLayout L, double* __restrict__ tab,
-                                     double* __restrict__ work) {
-  if (threadIdx.x == 0 && blockIdx.x == 0)
-    spline_build(tab + L.k_ln, tab + L.k_arr, L.NKT, tab + L.k_pp, work);
+__global__ void k_proj_kernel_spline(ProjLayout L, double* __restrict__ tab) {
+  extern __shared__ __align__(16) double sm_k[];       // 11 NKT doubles
+  spline_build_staged(tab + L.k_ln, tab + L.k_arr, L.NKT, tab + L.k_pp, sm_k, threadIdx.x < 64);
 }
 
 // Kernel.kernel(ln_ktheta), kernel.py:714-729 (uniform ln(k theta) knots).
