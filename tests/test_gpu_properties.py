@@ -331,3 +331,27 @@ def test_stage_e_timing_facility():
     hg.power("power_mm", k[:4096].contiguous())               # small grid: row-walking shape
     with pytest.raises(_lib.ChompError):
         hg.ctx.get_timing()
+
+
+def test_deep_knot_paths_agree():
+    """The HOD knots that run beyond the node tables take two routes: one block per knot
+    from a work list (a batch of epochs) or one launch per Romberg level over the whole grid
+    (a single Halo).  Same nodes, rows and stopping rule: the spectra agree to rounding and
+    the stopping levels exactly."""
+    from chomp_amd import grid
+    z = numpy.linspace(0.1, 1.2, 6)
+    k = numpy.logspace(-3, 2, 200)
+    batch = grid.HaloGrid(z)
+    for which in ("power_gm", "power_gg"):
+        pb = batch.power(which, k)
+        for i in (0, 3, 5):
+            single = grid.HaloGrid(z[i:i + 1])
+            ps = single.power(which, k)
+            assert numpy.max(numpy.abs(ps[0] / pb[i] - 1)) < 1e-12, (which, i)
+            lev_b = batch.ctx.table("levels", epoch=i)
+            lev_s = single.ctx.table("levels", epoch=0)
+            nk = lev_s.size // 5          # levels: [h_m, pp_mm, h_g, pp_gm, pp_gg][halo_npoints]
+            for fam in ((0, 2, 3) if which == "power_gm" else (2, 4)):
+                a, b = lev_b[fam * nk:(fam + 1) * nk], lev_s[fam * nk:(fam + 1) * nk]
+                assert numpy.array_equal(a, b), (which, i, fam)
+            assert lev_s[(3 if which == "power_gm" else 4) * nk:][:nk].max() > 10
