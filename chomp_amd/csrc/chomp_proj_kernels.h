@@ -173,6 +173,7 @@ __global__ void k_halofit_finalize(TabLayout L, Epoch* __restrict__ epochs, int 
 __device__ __forceinline__ double dndz_raw(const DndzDev& d, double z) {
   if (d.kind == CHOMP_DNDZ_MAGLIM)          // z^a exp(-(z/z0)^b), p = {a, z0, b}
     return pow(z, d.p[0]) * exp(-1.0 * pow(z / d.p[1], d.p[2]));
+  if (d.kind == CHOMP_DNDZ_BOXCAR) return 1.0;   // the base class (kernel.py:56-65)
   const double t = z - d.p[0];              // Gaussian, p = {z0, sigma_z}
   return exp(-1.0 * t * t / (2.0 * d.p[1] * d.p[1]));
 }

@@ -15,10 +15,16 @@ from . import defaults
 
 
 class dNdz(object):
-    """Base redshift distribution (kernel.py:26-86).  The normalisation integral is
-    done on the device as part of a Kernel / window set-up; ``norm`` is filled in
-    from there."""
-    _kind = None
+    """Base redshift distribution (kernel.py:26-86): a boxcar between z_min and z_max.  The
+    normalisation integral is done on the device as part of a Kernel / window set-up;
+    ``norm`` is filled in from there."""
+    _kind = _lib.DNDZ_BOXCAR
+
+    def raw_dndz(self, redshift):
+        return 1.0 + 0.0 * numpy.asarray(redshift, dtype=numpy.float64)
+
+    def _params(self):
+        return ()
 
     def __init__(self, z_min, z_max):
         self.z_min = z_min
@@ -44,9 +50,10 @@ class dNdz(object):
                                self.norm * self.raw_dndz(z), 0.0)
 
     def _struct(self):
-        if self._kind is None:
+        if self._kind is None or (self._kind == _lib.DNDZ_BOXCAR and type(self).raw_dndz
+                                  is not dNdz.raw_dndz):
             raise _lib.ChompScopeError(
-                "%s is outside the accelerated scope (dNdzMagLim and dNdzGaussian "
+                "%s is outside the accelerated scope (dNdz, dNdzMagLim and dNdzGaussian "
                 "are)" % type(self).__name__)
         d = _lib.Dndz()
         d.kind = self._kind

@@ -245,10 +245,12 @@ int chomp_get_table(chomp_ctx* ctx, size_t epoch, int table, double* out,
  * One projection set-up per context. */
 
 /* kernel.dNdz family (kernel.py:26-179). kind: CHOMP_DNDZ_*; p[] per kind:
- * MAGLIM {a, z0, b}; GAUSSIAN {z0, sigma_z}.  z_min/z_max are the values AFTER
- * the constructor's clipping (kernel.py:101-104, 164-173), done by the caller. */
+ * MAGLIM {a, z0, b}; GAUSSIAN {z0, sigma_z}; BOXCAR {} -- the base class dNdz, whose
+ * raw_dndz is 1 (kernel.py:56-65).  z_min/z_max are the values AFTER the constructor's
+ * clipping (kernel.py:101-104, 164-173), done by the caller. */
 #define CHOMP_DNDZ_MAGLIM 0
 #define CHOMP_DNDZ_GAUSSIAN 1
+#define CHOMP_DNDZ_BOXCAR 2
 typedef struct chomp_dndz {
   int kind;
   int pad_;

@@ -857,7 +857,17 @@ def dndz_gaussian(z_min, z_max, z0, sigma_z, prec=None):
     return d
 
 
+def dndz_boxcar(z_min, z_max, prec=None):
+    """The base class dNdz (kernel.py:26-65): raw_dndz = 1 between z_min and z_max."""
+    prec = default_precision if prec is None else prec
+    d = Table(kind="boxcar", z_min=z_min, z_max=z_max, prec=prec, norm=1.0)
+    dndz_normalize(d)
+    return d
+
+
 def dndz_raw(d, z):
+    if d.kind == "boxcar":
+        return 1.0 + 0.0 * numpy.asarray(z, dtype=float)
     if d.kind == "maglim":
         return numpy.power(z, d.a) * numpy.exp(-1.0 * numpy.power(z / d.z0, d.b))
     if d.kind == "gaussian":

@@ -424,6 +424,21 @@ def g13(ns):
     save("g13_bao_projections", **out)
 
 
+def g14(ns):
+    """The base-class (boxcar) dNdz (kernel.py:26-86) through a galaxy and a convergence
+    window, the J0 kernel and w(theta)."""
+    cm = ns.cosmology.MultiEpoch(0.0, 5.0)
+    wa = ns.kernel.WindowFunctionGalaxy(ns.kernel.dNdz(0.2, 0.6), cm)
+    wb = ns.kernel.WindowFunctionConvergence(ns.kernel.dNdz(0.8, 1.2), cm)
+    kern = ns.kernel.Kernel(1e-6 * deg_to_rad, 100.0 * deg_to_rad, wa, wb, cm)
+    out = _kernel_tables(kern)
+    theta = numpy.logspace(-2.5, 0, 9) * deg_to_rad
+    corr = ns.correlation.Correlation(0.001, 1.0, kern, input_halo=ns.halo.Halo(0.0),
+                                      power_spec="power_mm")
+    out.update(theta=theta, w_mm=corr.correlation(theta), D_z=corr.D_z)
+    save("g14_boxcar_dndz", **out)
+
+
 def pins():
     """Known-answer literals held by the reference's own tests (unit_test.py),
     restricted to the classes that pass against the shipped code."""
@@ -456,7 +471,7 @@ def pins():
 
 
 def main():
-    names = sys.argv[1:] or ["pins", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    names = sys.argv[1:] or ["pins", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
     ns = ref_loader.load()
     cwd = os.getcwd()
     with tempfile.TemporaryDirectory() as tmp:

@@ -382,3 +382,36 @@ def test_bao_projections():
     assert numpy.max(numpy.abs(xi - g["xi_raw"])) < 1e-6 * scale
     big = numpy.abs(g["xi_raw"]) > 1e-4 * scale
     assert rel_err(xi[big], g["xi_raw"][big]) < RTOL
+
+
+def test_boxcar_dndz():
+    """The base class dNdz (raw_dndz = 1 between z_min and z_max, kernel.py:26-86) through a
+    galaxy and a convergence window, the J0 kernel and w(theta), against the reference (G14)."""
+    from chomp_amd import correlation, cosmology, halo, kernel
+    g = load_golden("g14_boxcar_dndz")
+    d2r = numpy.pi / 180.0
+    cm = cosmology.MultiEpoch(0.0, 5.0)
+    da = kernel.dNdz(0.2, 0.6)
+    assert numpy.array_equal(da.dndz(numpy.array([0.1, 0.3, 0.7])) > 0, [False, True, False])
+    assert abs(da.norm - 2.5) < 1e-12
+    wa = kernel.WindowFunctionGalaxy(da, cm)
+    wb = kernel.WindowFunctionConvergence(kernel.dNdz(0.8, 1.2), cm)
+    kern = kernel.Kernel(1e-6 * d2r, 100.0 * d2r, wa, wb, cm)
+    assert kern.z_bar == float(g["z_bar"])
+    ctx = kern._dev()
+    info = ctx.kernel_info()
+    assert abs(info["norm_a"] / float(g["wa_norm"]) - 1) < 1e-7
+    assert abs(info["norm_b"] / float(g["wb_norm"]) - 1) < 1e-7
+    assert numpy.allclose(ctx.kernel_table("wa"), g["wa"], rtol=2e-6, atol=1e-16)
+    assert numpy.allclose(ctx.kernel_table("wb"), g["wb"], rtol=5e-6, atol=1e-16)
+    scale = numpy.max(numpy.abs(g["kernel"]))
+    assert numpy.allclose(ctx.kernel_table("kernel"), g["kernel"], rtol=2e-5, atol=2e-6 * scale)
+    corr = correlation.Correlation(0.001, 1.0, kern, input_halo=halo.Halo(0.0),
+                                   power_spec="power_mm")
+    assert rel_err(corr.correlation(g["theta"]), g["w_mm"]) < RTOL
+
+    class Other(kernel.dNdz):              # a user-defined raw_dndz cannot run on the device
+        def raw_dndz(self, redshift):
+            return redshift
+    with pytest.raises(Exception):
+        kernel.WindowFunctionGalaxy(Other(0.1, 0.5), cm)._dev()

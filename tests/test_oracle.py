@@ -281,3 +281,19 @@ def test_g12_gaussian_covariance():
     P = numpy.array([o.covariance_P(c, d, area, 1e10, 1e10, 1.0) for c, d in zip(center, delta)])
     assert rel_err(P, g["mag_P"]) < 1e-14
     assert rel_err(G + numpy.diag(P), g["mag_cov"]) < 1e-12
+
+
+def test_g14_boxcar_dndz():
+    """The base-class dNdz through both windows and the J0 kernel against the reference."""
+    g = load_golden("g14_boxcar_dndz")
+    d2r = numpy.pi / 180.0
+    me = o.multi_epoch(0.0, 5.0)
+    wa = o.window_table("galaxy", o.dndz_boxcar(0.2, 0.6), me)
+    wb = o.window_table("convergence", o.dndz_boxcar(0.8, 1.2), me)
+    assert abs(wa.dist.norm / float(g["wa_norm"]) - 1) < 1e-12
+    kt = o.kernel_table(1e-6 * d2r, 100 * d2r, wa, wb, me)
+    assert kt.z_bar == float(g["z_bar"])
+    assert numpy.allclose(kt.wa.wf_arr, g["wa"], rtol=1e-10, atol=1e-18)
+    assert numpy.allclose(kt.wb.wf_arr, g["wb"], rtol=1e-10, atol=1e-18)
+    scale = numpy.max(numpy.abs(g["kernel"]))
+    assert numpy.max(numpy.abs(kt.k_arr - g["kernel"])) < 1e-10 * scale
