@@ -23,7 +23,7 @@ T_EXCLUSION = 64
 FAM_MM, FAM_GM, FAM_GG = T_H_M | T_PP_MM, T_H_M | T_H_G | T_PP_GM, T_H_G | T_PP_GG
 P_LIN, P_MM, P_GM, P_GG, P_HALOFIT, P_EXTRAPOLATE = 0, 1, 2, 3, 16, 32
 PREC_F64, PREC_F32_EVAL, PREC_F32_TABLES, PREC_F32_ALL = 0, 1, 2, 3
-DNDZ_MAGLIM, DNDZ_GAUSSIAN, DNDZ_BOXCAR = 0, 1, 2
+DNDZ_MAGLIM, DNDZ_GAUSSIAN, DNDZ_BOXCAR, DNDZ_PPOLY = 0, 1, 2, 3
 WINDOW_GALAXY, WINDOW_CONVERGENCE = 0, 1
 
 SC = {name: i for i, name in enumerate([
@@ -80,7 +80,10 @@ class Config(ctypes.Structure):
 class Dndz(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int), ("pad_", ctypes.c_int),
                 ("z_min", ctypes.c_double), ("z_max", ctypes.c_double),
-                ("p", ctypes.c_double * 4)]
+                ("p", ctypes.c_double * 4),
+                ("pp_breaks", ctypes.POINTER(ctypes.c_double)),
+                ("pp_coef", ctypes.POINTER(ctypes.c_double)),
+                ("pp_n", ctypes.c_int), ("pp_order", ctypes.c_int)]
 
 
 class Window(ctypes.Structure):

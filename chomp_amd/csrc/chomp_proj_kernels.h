@@ -27,8 +27,10 @@
 namespace chomp {
 
 struct DndzDev {
-  int kind, pad;
+  int kind, pp_n;
   double z_min, z_max, p[4], norm;
+  const double* pp;          // CHOMP_DNDZ_PPOLY: breaks[pp_n + 1], then coef[pp_n][pp_order + 1]
+  int pp_order, pad;
 };
 
 // Scalars of one projection set-up (host fills the inputs, kernels fill the rest).
@@ -174,6 +176,19 @@ __device__ __forceinline__ double dndz_raw(const DndzDev& d, double z) {
   if (d.kind == CHOMP_DNDZ_MAGLIM)          // z^a exp(-(z/z0)^b), p = {a, z0, b}
     return pow(z, d.p[0]) * exp(-1.0 * pow(z / d.p[1], d.p[2]));
   if (d.kind == CHOMP_DNDZ_BOXCAR) return 1.0;   // the base class (kernel.py:56-65)
+  if (d.kind == CHOMP_DNDZ_PPOLY) {              // dNdzInterpolation: the caller's spline
+    const double* br = d.pp;
+    int lo = 0, hi = d.pp_n - 1;                 // last piece with br[i] <= z (ends extrapolate)
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (z >= br[mid]) lo = mid; else hi = mid - 1;
+    }
+    const double* cf = br + d.pp_n + 1 + (size_t)lo * (d.pp_order + 1);
+    const double t = z - br[lo];
+    double v = cf[d.pp_order];
+    for (int m = d.pp_order - 1; m >= 0; --m) v = fma(v, t, cf[m]);
+    return v;
+  }
   const double t = z - d.p[0];              // Gaussian, p = {z0, sigma_z}
   return exp(-1.0 * t * t / (2.0 * d.p[1] * d.p[1]));
 }

@@ -53,8 +53,8 @@ class dNdz(object):
         if self._kind is None or (self._kind == _lib.DNDZ_BOXCAR and type(self).raw_dndz
                                   is not dNdz.raw_dndz):
             raise _lib.ChompScopeError(
-                "%s is outside the accelerated scope (dNdz, dNdzMagLim and dNdzGaussian "
-                "are)" % type(self).__name__)
+                "%s is outside the accelerated scope (dNdz, dNdzMagLim, dNdzGaussian and "
+                "dNdzInterpolation are)" % type(self).__name__)
         d = _lib.Dndz()
         d.kind = self._kind
         d.z_min, d.z_max = float(self.z_min), float(self.z_max)
@@ -108,6 +108,48 @@ class dNdzMagLim(dNdz):
     def raw_dndz(self, redshift):
         return (numpy.power(redshift, self.a) *
                 numpy.exp(-1.0 * numpy.power(redshift / self.z0, self.b)))
+
+
+class dNdzInterpolation(dNdz):
+    """p(z) tabulated by the caller (kernel.py:181-208).  The constructor fits the same FITPACK
+    spline as the reference (order 2 through the points, or a smoothing spline) -- host work,
+    done once; the device evaluates it as a piecewise polynomial."""
+    _kind = _lib.DNDZ_PPOLY
+
+    def __init__(self, z_array, p_array, weights=None, interpolation_order=2,
+                 smoothing=None):
+        from scipy.interpolate import (InterpolatedUnivariateSpline, PPoly,
+                                       UnivariateSpline)
+        if smoothing is None:
+            self._p_of_z = InterpolatedUnivariateSpline(z_array, p_array, w=weights,
+                                                        k=interpolation_order)
+        else:
+            self._p_of_z = UnivariateSpline(z_array, p_array, w=weights,
+                                            k=interpolation_order, s=smoothing)
+        dNdz.__init__(self, z_array[0], z_array[-1])
+        pp = PPoly.from_spline(self._p_of_z._eval_args)
+        keep = numpy.diff(pp.x) > 0.0                 # (the repeated end knots: empty pieces)
+        self._breaks = numpy.ascontiguousarray(
+            numpy.concatenate([pp.x[:-1][keep], pp.x[-1:]]), dtype=numpy.float64)
+        # PPoly: c[m, i] multiplies (z - x_i)^(k - m); the ABI wants ascending powers per piece
+        self._coef = numpy.ascontiguousarray(pp.c[::-1, keep].T, dtype=numpy.float64)
+
+    def raw_dndz(self, redshift):
+        return self._p_of_z(redshift)
+
+    def _params(self):
+        return (self._breaks.tobytes(), self._coef.tobytes())
+
+    def _struct(self):
+        import ctypes
+        d = _lib.Dndz()
+        d.kind = self._kind
+        d.z_min, d.z_max = float(self.z_min), float(self.z_max)
+        d.pp_breaks = self._breaks.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        d.pp_coef = self._coef.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        d.pp_n = int(self._coef.shape[0])
+        d.pp_order = int(self._coef.shape[1] - 1)
+        return d
 
 
 def _norm_of(dist):

@@ -247,15 +247,25 @@ int chomp_get_table(chomp_ctx* ctx, size_t epoch, int table, double* out,
 /* kernel.dNdz family (kernel.py:26-179). kind: CHOMP_DNDZ_*; p[] per kind:
  * MAGLIM {a, z0, b}; GAUSSIAN {z0, sigma_z}; BOXCAR {} -- the base class dNdz, whose
  * raw_dndz is 1 (kernel.py:56-65).  z_min/z_max are the values AFTER the constructor's
- * clipping (kernel.py:101-104, 164-173), done by the caller. */
+ * clipping (kernel.py:101-104, 164-173), done by the caller.
+ * PPOLY: dNdzInterpolation (kernel.py:181-208), a p(z) tabulated by the caller.  The
+ * reference fits a FITPACK spline of order 2 (or a smoothing spline) to the table in its
+ * constructor; the caller does the same and hands the spline over as a piecewise
+ * polynomial: pp_n pieces, piece i on [pp_breaks[i], pp_breaks[i + 1]] with value
+ * sum_m pp_coef[i (pp_order + 1) + m] (z - pp_breaks[i])^m (host pointers, copied by
+ * chomp_kernel_setup; pp_order <= 5); z_min / z_max = the table's first / last z. */
 #define CHOMP_DNDZ_MAGLIM 0
 #define CHOMP_DNDZ_GAUSSIAN 1
 #define CHOMP_DNDZ_BOXCAR 2
+#define CHOMP_DNDZ_PPOLY 3
 typedef struct chomp_dndz {
   int kind;
   int pad_;
   double z_min, z_max;
   double p[4];
+  const double* pp_breaks;   /* [pp_n + 1] */
+  const double* pp_coef;     /* [pp_n][pp_order + 1] */
+  int pp_n, pp_order;
 } chomp_dndz;
 
 /* kernel.WindowFunctionGalaxy (kernel.py:358-387) / WindowFunctionConvergence

@@ -439,6 +439,33 @@ def g14(ns):
     save("g14_boxcar_dndz", **out)
 
 
+def g15(ns):
+    """dNdzInterpolation (kernel.py:181-208): a tabulated p(z) -- a lumpy photometric-style
+    distribution on 41 points -- through both windows, the J0 kernel and w(theta); plus a
+    smoothing-spline variant of the same table (window only)."""
+    z_tab = numpy.linspace(0.05, 1.45, 41)
+    p_tab = (z_tab ** 2 * numpy.exp(-(z_tab / 0.5) ** 1.5) *
+             (1.0 + 0.3 * numpy.sin(9.0 * z_tab)) + 0.02 * numpy.cos(23.0 * z_tab) ** 2)
+    cm = ns.cosmology.MultiEpoch(0.0, 5.0)
+    dist = ns.kernel.dNdzInterpolation(z_tab, p_tab)
+    wa = ns.kernel.WindowFunctionGalaxy(dist, cm)
+    wb = ns.kernel.WindowFunctionConvergence(ns.kernel.dNdzInterpolation(z_tab, p_tab), cm)
+    kern = ns.kernel.Kernel(1e-6 * deg_to_rad, 100.0 * deg_to_rad, wa, wb, cm)
+    out = _kernel_tables(kern)
+    theta = numpy.logspace(-2.5, 0, 9) * deg_to_rad
+    corr = ns.correlation.Correlation(0.001, 1.0, kern, input_halo=ns.halo.Halo(0.0),
+                                      power_spec="power_mm")
+    z_probe = numpy.linspace(0.0, 1.5, 61)
+    out.update(z_tab=z_tab, p_tab=p_tab, theta=theta, w_mm=corr.correlation(theta),
+               D_z=corr.D_z, z_probe=z_probe, dndz_probe=dist.dndz(z_probe))
+    sm = ns.kernel.dNdzInterpolation(z_tab, p_tab, interpolation_order=3, smoothing=1e-4)
+    ws = ns.kernel.WindowFunctionGalaxy(sm, ns.cosmology.MultiEpoch(0.0, 5.0))
+    ws.window_function(1.0)
+    out.update(smooth_chi=ws._chi_array, smooth_wf=numpy.asarray(ws._wf_array, dtype=float),
+               smooth_norm=sm.norm)
+    save("g15_dndz_interpolation", **out)
+
+
 def pins():
     """Known-answer literals held by the reference's own tests (unit_test.py),
     restricted to the classes that pass against the shipped code."""
@@ -471,7 +498,7 @@ def pins():
 
 
 def main():
-    names = sys.argv[1:] or ["pins", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
+    names = sys.argv[1:] or ["pins", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
     ns = ref_loader.load()
     cwd = os.getcwd()
     with tempfile.TemporaryDirectory() as tmp:

@@ -32,7 +32,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.HaloPar) == 48
     assert ctypes.sizeof(_lib.HodPar) == 40
     assert ctypes.sizeof(_lib.Config) == 12 * 8 + 8 * 4
-    assert ctypes.sizeof(_lib.Dndz) == 8 + 16 + 32
+    assert ctypes.sizeof(_lib.Dndz) == 8 + 16 + 32 + 2 * 8 + 8   # + the dNdzInterpolation spline
     assert ctypes.sizeof(_lib.Window) == 8 + ctypes.sizeof(_lib.Dndz)
     c = _lib.Config()
     _lib.lib().chomp_default_config(ctypes.byref(c))

@@ -415,3 +415,36 @@ def test_boxcar_dndz():
             return redshift
     with pytest.raises(Exception):
         kernel.WindowFunctionGalaxy(Other(0.1, 0.5), cm)._dev()
+
+
+def test_dndz_interpolation():
+    """dNdzInterpolation (kernel.py:181-208): a tabulated p(z) through both windows, the J0
+    kernel and w(theta) against the reference (G15); the same table through a smoothing
+    spline."""
+    from chomp_amd import correlation, cosmology, halo, kernel
+    g = load_golden("g15_dndz_interpolation")
+    d2r = numpy.pi / 180.0
+    cm = cosmology.MultiEpoch(0.0, 5.0)
+    dist = kernel.dNdzInterpolation(g["z_tab"], g["p_tab"])
+    assert dist.z_min == g["z_tab"][0] and dist.z_max == g["z_tab"][-1]
+    assert numpy.allclose(dist.dndz(g["z_probe"]), g["dndz_probe"], rtol=1e-7, atol=1e-12)
+    wa = kernel.WindowFunctionGalaxy(dist, cm)
+    wb = kernel.WindowFunctionConvergence(kernel.dNdzInterpolation(g["z_tab"], g["p_tab"]), cm)
+    kern = kernel.Kernel(1e-6 * d2r, 100.0 * d2r, wa, wb, cm)
+    assert kern.z_bar == float(g["z_bar"])
+    ctx = kern._dev()
+    info = ctx.kernel_info()
+    assert abs(info["norm_a"] / float(g["wa_norm"]) - 1) < 1e-7
+    assert numpy.allclose(ctx.kernel_table("wa"), g["wa"], rtol=2e-6, atol=1e-12 * g["wa"].max())
+    assert numpy.allclose(ctx.kernel_table("wb"), g["wb"], rtol=5e-6, atol=1e-12 * g["wb"].max())
+    scale = numpy.max(numpy.abs(g["kernel"]))
+    assert numpy.allclose(ctx.kernel_table("kernel"), g["kernel"], rtol=2e-5, atol=2e-6 * scale)
+    corr = correlation.Correlation(0.001, 1.0, kern, input_halo=halo.Halo(0.0),
+                                   power_spec="power_mm")
+    assert rel_err(corr.correlation(g["theta"]), g["w_mm"]) < RTOL
+    sm = kernel.dNdzInterpolation(g["z_tab"], g["p_tab"], interpolation_order=3, smoothing=1e-4)
+    ws = kernel.WindowFunctionGalaxy(sm, cosmology.MultiEpoch(0.0, 5.0))
+    tab = ws._dev().kernel_table("wa")
+    assert numpy.allclose(tab, g["smooth_wf"], rtol=2e-6, atol=1e-12 * g["smooth_wf"].max())
+    sm.normalize()
+    assert abs(sm.norm / float(g["smooth_norm"]) - 1) < 1e-7
