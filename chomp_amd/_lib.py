@@ -24,7 +24,7 @@ FAM_MM, FAM_GM, FAM_GG = T_H_M | T_PP_MM, T_H_M | T_H_G | T_PP_GM, T_H_G | T_PP_
 P_LIN, P_MM, P_GM, P_GG, P_HALOFIT, P_EXTRAPOLATE = 0, 1, 2, 3, 16, 32
 PREC_F64, PREC_F32_EVAL, PREC_F32_TABLES, PREC_F32_ALL = 0, 1, 2, 3
 DNDZ_MAGLIM, DNDZ_GAUSSIAN, DNDZ_BOXCAR, DNDZ_PPOLY = 0, 1, 2, 3
-WINDOW_GALAXY, WINDOW_CONVERGENCE = 0, 1
+WINDOW_GALAXY, WINDOW_CONVERGENCE, WINDOW_FLAT_CONVERGENCE, WINDOW_CONVERGENCE_DELTA = 0, 1, 2, 3
 
 SC = {name: i for i, name in enumerate([
     "z", "chi", "growth", "omega_m", "omega_l", "delta_c", "delta_v", "rho_bar",

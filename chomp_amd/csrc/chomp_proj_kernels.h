@@ -333,6 +333,14 @@ __global__ __launch_bounds__(64) void k_proj_window(chomp_config cfg, ProjLayout
   double val;
   if (pd->wkind[w] == CHOMP_WINDOW_GALAXY) {                       // kernel.py:382-387
     val = pd->H0 * sqrt(E0_of(pd->om0, pd->ol0, pd->or0, z)) * dndz_eval(D, z);
+  } else if (pd->wkind[w] == CHOMP_WINDOW_FLAT_CONVERGENCE) {      // kernel.py:507-513
+    val = 3.0 / 2.0 * pd->om0 * (pd->H0 * pd->H0 * 1907.71);
+  } else if (pd->wkind[w] == CHOMP_WINDOW_CONVERGENCE_DELTA) {     // kernel.py:541-556
+    const double a = 1.0 / (1.0 + pd->w_z_max[w]);                 // (the source plane's a)
+    const double cmax = pd->w_chi_max[w];
+    double g = chi > cmax ? 0.0 : (cmax - chi) / cmax;
+    g *= pd->H0 * pd->H0 * chi;
+    val = 3.0 / 2.0 * pd->om0 * g / a;
   } else {                                                         // kernel.py:443-477
     const double a = 1.0 / (1.0 + z);
     double bound = chi;

@@ -244,6 +244,26 @@ class WindowFunctionConvergence(WindowFunction):
         WindowFunction.__init__(self, 0.0, redshift_dist.z_max, cosmo_multi_epoch, **kws)
 
 
+class WindowFunctionFlatConvergence(WindowFunction):
+    """Constant lensing window between z_min and z_max (kernel.py:487-513)."""
+    _kind = _lib.WINDOW_FLAT_CONVERGENCE
+
+    def __init__(self, z_min, z_max, cosmo_multi_epoch=None, **kws):
+        WindowFunction.__init__(self, z_min, z_max, cosmo_multi_epoch, **kws)
+        self._redshift_dist = dNdz(self.z_min, self.z_max)     # (carries the limits only)
+
+
+class WindowFunctionConvergenceDelta(WindowFunction):
+    """Lensing window of sources on one plane (kernel.py:516-556)."""
+    _kind = _lib.WINDOW_CONVERGENCE_DELTA
+
+    def __init__(self, redshift, cosmo_multi_epoch=None, **kws):
+        self._redshift = redshift
+        self._g_chi_min = 0.0
+        WindowFunction.__init__(self, 0.0, redshift, cosmo_multi_epoch, **kws)
+        self._redshift_dist = dNdz(0.0, redshift)              # (carries the limits only)
+
+
 class Kernel(object):
     """K(k theta) = int dchi W_a W_b D^2 J0(k theta chi) (kernel.py:559-781)."""
     _order = 0

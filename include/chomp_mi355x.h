@@ -272,6 +272,11 @@ typedef struct chomp_dndz {
  * (:410-484). */
 #define CHOMP_WINDOW_GALAXY 0
 #define CHOMP_WINDOW_CONVERGENCE 1
+/* WindowFunctionFlatConvergence (kernel.py:487-513): constant 3/2 Omega_m H0^2 1907.71
+ * between dist.z_min and dist.z_max; WindowFunctionConvergenceDelta (:516-556): sources on
+ * one plane at z = dist.z_max.  Both take only z_min / z_max from `dist`. */
+#define CHOMP_WINDOW_FLAT_CONVERGENCE 2
+#define CHOMP_WINDOW_CONVERGENCE_DELTA 3
 typedef struct chomp_window {
   int kind;
   int pad_;

@@ -202,7 +202,8 @@ def _kernel_tables(kern):
         kernel=numpy.asarray(kern._kernel_array, dtype=float),
         wa_chi=a._chi_array, wa=numpy.asarray(a._wf_array, dtype=float),
         wb_chi=b._chi_array, wb=numpy.asarray(b._wf_array, dtype=float),
-        wa_norm=a._redshift_dist.norm, wb_norm=b._redshift_dist.norm,
+        wa_norm=a._redshift_dist.norm,
+        wb_norm=b._redshift_dist.norm if hasattr(b, "_redshift_dist") else 1.0,
         wa_zmax=a.z_max, wb_zmax=b.z_max,
         me_z=kern.cosmo._z_array, me_chi=kern.cosmo._chi_array,
         me_growth=kern.cosmo._growth_array)
@@ -466,6 +467,26 @@ def g15(ns):
     save("g15_dndz_interpolation", **out)
 
 
+def g16(ns):
+    """WindowFunctionFlatConvergence and WindowFunctionConvergenceDelta (kernel.py:487-556),
+    each against a galaxy window in a J0 kernel, and w(theta) for the delta-plane case."""
+    out = {}
+    theta = numpy.logspace(-2.5, 0, 9) * deg_to_rad
+    for tag in ("flat", "delta"):
+        cm = ns.cosmology.MultiEpoch(0.0, 5.0)
+        wa = ns.kernel.WindowFunctionGalaxy(ns.kernel.dNdzGaussian(0.0, 2.0, 0.5, 0.1), cm)
+        wb = (ns.kernel.WindowFunctionFlatConvergence(0.3, 0.9, cm) if tag == "flat"
+              else ns.kernel.WindowFunctionConvergenceDelta(1.1, cm))
+        kern = ns.kernel.Kernel(1e-6 * deg_to_rad, 100.0 * deg_to_rad, wa, wb, cm)
+        for key, val in _kernel_tables(kern).items():
+            out[tag + "_" + key] = val
+        corr = ns.correlation.Correlation(0.001, 1.0, kern, input_halo=ns.halo.Halo(0.0),
+                                          power_spec="power_mm")
+        out[tag + "_w_mm"] = corr.correlation(theta)
+    out["theta"] = theta
+    save("g16_flat_delta_windows", **out)
+
+
 def pins():
     """Known-answer literals held by the reference's own tests (unit_test.py),
     restricted to the classes that pass against the shipped code."""
@@ -498,7 +519,7 @@ def pins():
 
 
 def main():
-    names = sys.argv[1:] or ["pins", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
+    names = sys.argv[1:] or ["pins", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
     ns = ref_loader.load()
     cwd = os.getcwd()
     with tempfile.TemporaryDirectory() as tmp:
