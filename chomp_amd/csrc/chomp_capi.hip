@@ -65,7 +65,6 @@ struct chomp_ctx {
   double* d_stage_in = nullptr;
   double* d_stage_in2 = nullptr;
   double* d_stage_out = nullptr;
-  double* d_work = nullptr;
   int* d_slow = nullptr;           // Stage E: 2 counters + list of k groups for the per-lane pass
   int* d_winfo = nullptr;          // Stage E: per k group knot interval / flags (k_power_prep)
   double* d_ktab = nullptr;        // Stage E: per-k (offset, shape) table (k_power_prep)
@@ -79,7 +78,7 @@ struct chomp_ctx {
   bool timing_valid = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<int> slot;           // host copy: epoch -> cosmology slot
-  size_t cap_in = 0, cap_in2 = 0, cap_out = 0, cap_work = 0;
+  size_t cap_in = 0, cap_in2 = 0, cap_out = 0;
 
   // projection
   ProjState proj;
@@ -291,7 +290,7 @@ void chomp_ctx_destroy(chomp_ctx* ctx) {
   void* ptrs[] = {ctx->d_sici, ctx->d_j0, ctx->d_j2, ctx->d_tinker, ctx->d_gl16,
                   ctx->d_cand, ctx->d_cosmo, ctx->d_z, ctx->d_epochs, ctx->d_search, ctx->d_probe, ctx->d_count, ctx->d_pending,
                   ctx->d_tab, ctx->d_mass_par, ctx->d_profile, ctx->d_hod, ctx->d_nodes, ctx->d_snodes, ctx->d_slot, ctx->d_first,
-                  ctx->d_stage_in, ctx->d_stage_in2, ctx->d_stage_out, ctx->d_work, ctx->d_slow, ctx->d_wnodes, ctx->d_deep,
+                  ctx->d_stage_in, ctx->d_stage_in2, ctx->d_stage_out, ctx->d_slow, ctx->d_wnodes, ctx->d_deep,
                   ctx->d_winfo, ctx->d_ktab};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
