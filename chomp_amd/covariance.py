@@ -7,8 +7,9 @@ examples/example_covariance_script.py: the projected spectrum over ln K
 (``_initialize_halo_splines``), ``covariance_G`` for every pair of bins in one launch,
 the Poisson term, ``get_covariance`` and ``write``.  Outside the scope (ChompScopeError):
 the trispectrum terms (``nongaussian_cov=True``, ``ssc_cov=True``: halo_trispectrum.py,
-perturbation_spectra.py), two different correlation objects, ``CovarianceMulti`` and
-``CovarianceFourier``.
+perturbation_spectra.py), ``CovarianceMulti`` and ``CovarianceFourier``.  Two different
+correlation objects cannot be given to the reference's Covariance either (its constructor
+raises ValueError comparing them), so that branch is not built.
 """
 import numpy
 from scipy import special
@@ -80,9 +81,16 @@ class Covariance(object):
                 "halo_trispectrum.py) are outside the accelerated scope: pass "
                 "nongaussian_cov=False, ssc_cov=False")
         if input_correlation_a is not input_correlation_b:
+            # The reference cannot get here either: covariance.py:60 compares the two
+            # correlations with Correlation.__eq__ (correlation.py:119-131), which compares
+            # their attribute dictionaries -- numpy arrays included -- and raises
+            # "ValueError: The truth value of an array ... is ambiguous" for two different
+            # objects.  The four-spectra branch (covariance.py:497-532) is dead code as shipped.
             raise _lib.ChompScopeError(
-                "Covariance of two different correlation objects (four projected spectra, "
-                "covariance.py:497-532) is outside the accelerated scope")
+                "Covariance of two different correlation objects: the reference raises "
+                "ValueError at covariance.py:60 for them (Correlation.__eq__ compares numpy "
+                "arrays); only Covariance(corr, corr) can run there, and that is what is "
+                "accelerated")
         self.annular_bins = []
         self.log_theta_min = input_correlation_a.log_theta_min
         self.log_theta_max = input_correlation_a.log_theta_max
