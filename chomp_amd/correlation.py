@@ -136,6 +136,14 @@ class Correlation(object):
                 f.write("%1.10g %1.10g\n" % (theta / deg_to_rad, wtheta))
 
 
+class CorrelationProjectedComoving(Correlation):
+    """Empty in the reference too (correlation.py:291-295)."""
+
+    def __init__(self, r_min_Mpc, r_max_Mpc, input_kernel,
+                 bins_per_decade=5.0, input_halo=None, power_spec=None, **kws):
+        pass
+
+
 class CorrelationFourier(Correlation):
     """Limber C_l (correlation.py:297-405)."""
 

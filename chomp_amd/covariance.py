@@ -271,3 +271,23 @@ class Covariance(object):
                     f.writelines('%1.16f %1.16f %1.16f\n' % (
                         bin_a.center * rad_to_deg, bin_b.center * rad_to_deg,
                         self.covar[idx_a, idx_b]))
+
+
+class FiniteAreaEffect(object):
+    """Fitting formula for the finite-survey-area correction of Sato et al. 2011, App. A
+    (covariance.py:1106-1139): two power laws in the source redshift; host arithmetic."""
+
+    def __init__(self):
+        self.alpha1 = 3.2952
+        self.alpha2 = -0.316369
+        self.beta1 = 0.170708
+        self.beta2 = -0.349913
+
+    def alpha(self, zs):
+        return self.alpha1 * zs ** self.alpha2
+
+    def beta(self, zs):
+        return self.beta1 * zs ** self.beta2
+
+    def area_scaling(self, area, zs):
+        return self.alpha(zs) / area ** self.beta(zs)

@@ -137,3 +137,17 @@ class HODZheng(HOD):
     def second_moment(self, mass, z=None):
         n_sat = self.satellite_first_moment(mass)
         return (2 + n_sat) * n_sat
+
+
+class HODPoisson(HOD):
+    """Empty in the reference too (hod.py:131-134)."""
+
+    def __init__(self):
+        pass
+
+
+class HODBinomial(HOD):
+    """Empty in the reference too (hod.py:136-139)."""
+
+    def __init__(self, n_max, min_mass, mass_max, p_m_spline):
+        pass
