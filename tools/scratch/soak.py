@@ -1,0 +1,42 @@
+"""Randomised parity soak: device P_mm / P_gm against the oracle for random cosmologies,
+HODs and redshifts (not part of the test suite: the oracle takes seconds per case)."""
+import os, sys, time, numpy
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
+from chomp_amd import grid
+from oracle import chomp_oracle as o
+rng = numpy.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 7)
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+k = numpy.logspace(-3, 2, 40)
+cos, zs, hods = [], [], []
+for i in range(n):
+    c = dict(o.default_cosmo_dict)
+    c["omega_m0"] = rng.uniform(0.2, 0.4) - c["omega_r0"]
+    c["omega_l0"] = 1.0 - c["omega_m0"] - c["omega_r0"]
+    c["omega_b0"] = rng.uniform(0.035, 0.055)
+    c["h"] = rng.uniform(0.6, 0.8)
+    c["sigma_8"] = rng.uniform(0.7, 0.9)
+    c["n_scalar"] = rng.uniform(0.92, 1.0)
+    cos.append(c); zs.append(rng.uniform(0.0, 1.5))
+    h = dict(o.default_hod_dict)
+    h["log_M_min"] = rng.uniform(11.8, 12.6); h["log_M_0"] = h["log_M_min"]
+    h["sigma"] = rng.uniform(0.1, 0.4); h["log_M_1p"] = h["log_M_min"] + rng.uniform(1.0, 1.5)
+    hods.append(h)
+t = time.time()
+g = grid.HaloGrid(numpy.array(zs), cosmo_dict=cos, hod_dict=hods)
+pm = g.power("power_mm", k)
+n_gm = min(n, 6)
+pg = g.power("power_gm", k)
+worst = 0.0
+for i in range(n):
+    e = o.epoch(cos[i], float(zs[i]))
+    fam = ("mm", "gm") if i < n_gm else ("mm",)
+    tb = o.halo_table(e, o.mass_table(e), o.zheng(hods[i]), families=fam)
+    err = numpy.max(numpy.abs(pm[i] / o.halo_power(tb, "mm", k) - 1))
+    msg = "case %2d z=%.3f  mm %.2e" % (i, zs[i], err)
+    if i < n_gm:
+        eg = numpy.max(numpy.abs(pg[i] / o.halo_power(tb, "gm", k) - 1))
+        msg += "  gm %.2e" % eg
+        err = max(err, eg)
+    worst = max(worst, err)
+    print(msg, flush=True)
+print("worst %.3e  (%.0f s)" % (worst, time.time() - t))
