@@ -153,8 +153,9 @@ def projection_bench(args, world, rank, local):
     corr = correlation.Correlation(0.001, 1.0, kern, input_halo=h, power_spec=spec)
     theta = torch.logspace(-3, 0, N_THETA, dtype=torch.float64, device=dev) * d2r
     ell = torch.logspace(1, 4, N_ELL, dtype=torch.float64, device=dev)
-    my_theta = theta[rank::world].contiguous()
-    my_ell = ell[rank::world].contiguous()
+    from chomp_amd import grid
+    my_theta = grid.shard_samples(theta, rank, world)
+    my_ell = grid.shard_samples(ell, rank, world)
 
     def step():
         # forget every table: the step rebuilds the projection and the halo model
@@ -167,19 +168,9 @@ def projection_bench(args, world, rank, local):
         ctx, code = corr._prepare()
         w = ctx.wtheta(code, 0, corr._k_lim[0], corr._k_lim[1], corr.D_z, my_theta)
         c = ctx.cell(code, 0, corr.D_z, my_ell)
-        if world > 1:
-            wf = torch.empty(world * w.numel(), dtype=torch.float64, device=w.device)
-            cf = torch.empty(world * c.numel(), dtype=torch.float64, device=c.device)
-            if args.rehearse:
-                wh, ch = wf.cpu(), cf.cpu()
-                dist.all_gather_into_tensor(wh, w.cpu())
-                dist.all_gather_into_tensor(ch, c.cpu())
-                wf, cf = wh.to(dev), ch.to(dev)
-            else:
-                dist.all_gather_into_tensor(wf, w)
-                dist.all_gather_into_tensor(cf, c)
-            w = wf.view(world, -1).t().reshape(-1)       # undo the interleaved sharding
-            c = cf.view(world, -1).t().reshape(-1)
+        if world > 1:                      # one all-gather per output array
+            w = grid.gather_samples(w, N_THETA, world, via_host=args.rehearse)
+            c = grid.gather_samples(c, N_ELL, world, via_host=args.rehearse)
         return w, c
 
     def fence():

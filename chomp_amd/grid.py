@@ -180,3 +180,36 @@ def gather_rows_async(local, n_all, world, out=None):
 def gather_rows(local, n_all, world):
     """All-gather the per-rank row blocks and put the rows back into epoch order."""
     return gather_rows_async(local, n_all, world).wait()
+
+
+# -- 1-D sample axes (theta, l): SURVEY 8(e) C4 / C5 -------------------------------------------
+def shard_samples(x, rank, world):
+    """This rank's share of a 1-D sample array (theta or l): every world-th sample starting at
+    `rank`, padded with its last sample to ceil(n / world) so that all ranks gather equal
+    counts (the tables the samples are evaluated against are replicated, not sharded)."""
+    mine = x[rank::world]
+    per = rows_per_rank(x.shape[0], world)
+    if mine.shape[0] < per:
+        import torch
+        pad = mine[-1:] if mine.shape[0] else x[-1:]
+        mine = torch.cat([mine, pad.expand(per - mine.shape[0])])
+    return mine.contiguous()
+
+
+def gather_samples(local, n_all, world, via_host=False):
+    """All-gather the per-rank results of shard_samples and undo the interleaving: the n_all
+    values in the caller's sample order on every rank.  via_host: stage through host memory
+    (gloo with device tensors: the one-GPU rehearsal)."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return local[:n_all]
+    per = local.shape[0]
+    if via_host:
+        host = torch.empty(world * per, dtype=local.dtype)
+        dist.all_gather_into_tensor(host, local.cpu().contiguous())
+        full = host.to(local.device)
+    else:
+        full = torch.empty(world * per, dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(full, local.contiguous())
+    return full.view(world, per).t().reshape(-1)[:n_all]

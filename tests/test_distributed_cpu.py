@@ -54,3 +54,36 @@ def test_shard_allgather_unshard(world, n_all):
         p.join(120)
         assert p.exitcode == 0
     assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+def _sample_worker(rank, world, port, n_all, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from chomp_amd import grid
+    x = torch.linspace(1.0, 2.0, n_all, dtype=torch.float64)
+    mine = grid.shard_samples(x, rank, world)
+    ok = mine.shape[0] == grid.rows_per_rank(n_all, world)
+    full = grid.gather_samples(mine * mine + rank * 0.0, n_all, world)     # "evaluate", gather
+    ok = ok and full.shape[0] == n_all and bool(torch.equal(full, x * x))
+    ret[rank] = ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_all", [(2, 1024), (2, 33), (3, 100)])
+def test_sample_axis_shard_and_gather(world, n_all):
+    """The theta / l axis of the projection workloads: interleaved
+    samples, equal counts per rank, one all-gather, caller's order restored."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_sample_worker, args=(r, world, port, n_all, ret))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(ret.get(r) for r in range(world)), dict(ret)
