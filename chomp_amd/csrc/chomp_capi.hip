@@ -563,8 +563,6 @@ static int check_power(chomp_ctx* ctx, int which, size_t epoch0, size_t n) {
   const bool hf = (which & CHOMP_P_HALOFIT) != 0;
   if (w < CHOMP_P_LIN || w > CHOMP_P_GG) return fail(ctx, CHOMP_ERR_ARG, "power: unknown spectrum");
   if (hf && w == CHOMP_P_LIN) return fail(ctx, CHOMP_ERR_ARG, "power: halofit|lin");
-  if (hf && ctx->with_bao)
-    return fail(ctx, CHOMP_ERR_SCOPE, "HaloFit on the wiggle transfer function is not accelerated");
   unsigned need = 0;
   if (w == CHOMP_P_MM && !hf) need = (1u << F_HM) | (1u << F_PPMM);
   if (w == CHOMP_P_GM) need = (1u << F_HM) | (1u << F_HG) | (1u << F_PPGM);

@@ -736,12 +736,13 @@ struct SigmaIntegrandT {
 typedef SigmaIntegrandT<false> SigmaIntegrand;
 
 // HaloFit sigma^2(R) with a Gaussian filter, halo.py:1321-1323.
+template <bool BAO>
 struct HalofitSigmaIntegrand {
   const Epoch* e;
   double R;
   CHOMP_HD double operator()(double ln_k) const {
     const double k = exp(ln_k);
-    return delta_k_ln_t<false>(*e, ln_k, k) * exp(-k * k * R * R);   // (HaloFit: no-wiggle only)
+    return delta_k_ln_t<BAO>(*e, ln_k, k) * exp(-k * k * R * R);
   }
 };
 

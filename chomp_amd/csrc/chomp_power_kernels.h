@@ -37,10 +37,11 @@ __device__ __forceinline__ double power_tail(const Epoch& E, const double* x, in
   return pow(kv / k_max, vs[1]) * vs[0];
 }
 
+template <bool BAO>
 __device__ __forceinline__ double halofit_mm(const Epoch& E, double k) {
   // halo.py:1339-1360
   const double lk = log(k);
-  const double dk = delta_k_ln_t<false>(E, lk, k);      // (HaloFit: no-wiggle contexts only)
+  const double dk = delta_k_ln_t<BAO>(E, lk, k);
   const double y = k / E.hf_k_s;
   const double d2q = dk * (pow(1.0 + dk, E.hf_beta_n) / (1.0 + E.hf_alpha_n * dk) *
                            exp(-(y / 4.0 + y * y / 8.0)));
@@ -53,9 +54,10 @@ __device__ __forceinline__ double halofit_mm(const Epoch& E, double k) {
 
 // halofit_mm for a caller that holds ln k as well: every power becomes one exp of a
 // linear form in ln k, the linear spectrum comes from power_shape (halo.py:1339-1360).
+template <bool BAO>
 __device__ __forceinline__ double halofit_mm_ln(const Epoch& E, double amp2, double lk, double k) {
   const double k3 = k * k * k;
-  const double dk = amp2 * power_shape_t<false>(E, lk, k) * k3 * (1.0 / (2.0 * kPi * kPi));
+  const double dk = amp2 * power_shape_t<BAO>(E, lk, k) * k3 * (1.0 / (2.0 * kPi * kPi));
   const double ln_y = lk - log(E.hf_k_s);               // (log of a per-epoch constant)
   const double y = exp(ln_y);
   const double d2q = dk * exp(E.hf_beta_n * fast_log(1.0 + dk) - (y * 0.25 + y * y * 0.125)) /
@@ -130,7 +132,7 @@ struct PowerEval {
   __device__ __forceinline__ double eval_t(double kv) const {
     if (w == CHOMP_P_LIN) return linear_power_t<BAO>(*E, kv);
     if (halofit) {
-      const double pmm = halofit_mm(*E, kv);
+      const double pmm = halofit_mm<BAO>(*E, kv);
       if (w == CHOMP_P_MM) return pmm;
       double ha = 0.0, hb = 0.0, pp = 0.0;               // halo.py:649-672 range rule
       if (kv >= k_min && kv <= k_max) {
@@ -163,7 +165,7 @@ struct PowerEval {
   __device__ __forceinline__ double at_ln(double lk, double kv) const {
     const bool in = kv >= k_min && kv <= k_max;
     if (HF) {
-      const double pmm = halofit_mm_ln(*E, amp2, lk, kv);
+      const double pmm = halofit_mm_ln<BAO>(*E, amp2, lk, kv);
       if (w == CHOMP_P_MM) return pmm;
       if (!in) return 0.0;                                // halo.py:649-672 range rule
       int i = (int)floor((lk - x0) * inv_dx);

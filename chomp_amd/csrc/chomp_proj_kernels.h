@@ -106,6 +106,7 @@ inline void proj_free(ProjState& p) {
 // HaloFit
 // ---------------------------------------------------------------------------
 // grid NK, block 256: ln sigma^2(R_i), R_i = exp(linspace(ln 0.1, ln 10, NK)).
+template <bool BAO>
 __global__ __launch_bounds__(256) void k_halofit_sigma(chomp_config cfg, TabLayout L,
                                                        const Epoch* __restrict__ epochs,
                                                        int e, double* __restrict__ tab) {
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256) void k_halofit_sigma(chomp_config cfg, TabLayo
   __syncthreads();
   const int i = blockIdx.x;
   const double R = exp(linspace_at(log(0.1), log(10.0), L.NK, i));
-  HalofitSigmaIntegrand f{&E, R};
+  HalofitSigmaIntegrand<BAO> f{&E, R};
   const double s2 = romberg1<4>(f, log(cfg.k_min), log(cfg.k_max), cfg.global_precision,
                                 cfg.halo_precision, cfg.divmax, red);
   if (threadIdx.x == 0) tab[(size_t)e * L.stride + L.off_hf_lns2 + i] = log(s2);
@@ -861,8 +862,8 @@ struct Xi3dIntegrand {
   double r;
   __device__ __forceinline__ double operator()(double ln_k) const {
     const double k = exp(ln_k);
-    const double p = (!BAO && P->halofit) ? P->template at_ln<true>(ln_k, k)
-                                          : P->template at_ln<false, BAO>(ln_k, k);
+    const double p = P->halofit ? P->template at_ln<true, BAO>(ln_k, k)
+                                : P->template at_ln<false, BAO>(ln_k, k);
     return k * k / (2.0 * kPi) * p * bessel_j<0>(k * r, *B);
   }
 };

@@ -487,6 +487,29 @@ def g16(ns):
     save("g16_flat_delta_windows", **out)
 
 
+def g17(ns):
+    """HaloFit on the wiggle transfer function: HaloFit(z, cosmo_single_epoch=SingleEpoch(z,
+    with_bao=True)) -- sigma table, fit parameters, P_mm / P_gm / P_gg, and w(theta) through
+    the J0 kernel with the HaloFit object built at the kernel's z_bar."""
+    k = numpy.logspace(-3, 2, 64)
+    z = 0.4
+    hf = ns.halo.HaloFit(z, cosmo_single_epoch=ns.cosmology.SingleEpoch(z, with_bao=True))
+    out = {"k": k, "z": numpy.array(z), "mm": hf.power_mm(k), "gm": hf.power_gm(k),
+           "gg": hf.power_gg(k),
+           "pars": numpy.array([hf._k_s, hf._n_eff, hf._C, hf._a_n, hf._b_n, hf._c_n,
+                                hf._gamma_n, hf._alpha_n, hf._beta_n, hf._nu_n]),
+           "ln_sigma2": hf._ln_sigma2_array}
+    plain = ns.halo.HaloFit(z)
+    out["mm_nowiggle"] = plain.power_mm(k)
+    cm, kern = _projection(ns, ggl=False)
+    zb = kern.z_bar
+    hz = ns.halo.HaloFit(zb, cosmo_single_epoch=ns.cosmology.SingleEpoch(zb, with_bao=True))
+    theta = numpy.logspace(-2.5, 0, 9) * deg_to_rad
+    corr = ns.correlation.Correlation(0.001, 1.0, kern, input_halo=hz, power_spec="power_mm")
+    out.update(theta=theta, w_mm=corr.correlation(theta), D_z=corr.D_z, z_bar=zb)
+    save("g17_halofit_bao", **out)
+
+
 def pins():
     """Known-answer literals held by the reference's own tests (unit_test.py),
     restricted to the classes that pass against the shipped code."""
@@ -519,7 +542,7 @@ def pins():
 
 
 def main():
-    names = sys.argv[1:] or ["pins", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
+    names = sys.argv[1:] or ["pins", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
     ns = ref_loader.load()
     cwd = os.getcwd()
     with tempfile.TemporaryDirectory() as tmp:

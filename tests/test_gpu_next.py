@@ -474,3 +474,31 @@ def test_flat_and_delta_convergence_windows():
         assert rel_err(corr.correlation(g["theta"]), g[tag + "_w_mm"]) < RTOL
         assert numpy.allclose(wb.window_function(g[tag + "_wb_chi"][5:8]), g[tag + "_wb"][5:8],
                               rtol=1e-9)
+
+
+def test_halofit_on_the_wiggle_transfer_function():
+    """HaloFit(z, cosmo_single_epoch=SingleEpoch(z, with_bao=True)): the sigma table, the fit,
+    the three spectra and w(theta) against the reference (G17)."""
+    from chomp_amd import correlation, cosmology, halo, kernel
+    g = load_golden("g17_halofit_bao")
+    z, k = float(g["z"]), g["k"]
+    hf = halo.HaloFit(z, cosmo_single_epoch=cosmology.SingleEpoch(z, with_bao=True))
+    assert rel_err(hf.power_mm(k), g["mm"]) < RTOL
+    inr = k <= 100.0
+    assert rel_err(hf.power_gm(k)[inr], g["gm"][inr]) < RTOL
+    assert rel_err(hf.power_gg(k)[inr], g["gg"][inr]) < RTOL
+    pars = numpy.array([hf._k_s, hf._n_eff, hf._C, hf._a_n, hf._b_n, hf._c_n, hf._gamma_n,
+                        hf._alpha_n, hf._beta_n, hf._nu_n])
+    assert rel_err(pars, g["pars"]) < 1e-6
+    assert numpy.max(numpy.abs(g["mm"] / g["mm_nowiggle"] - 1)) > 0.02      # wiggles are in
+    d2r = numpy.pi / 180.0
+    cm = cosmology.MultiEpoch(0.0, 5.0)
+    wa = kernel.WindowFunctionGalaxy(kernel.dNdzMagLim(0.0, 2.0, 2.0, 0.3, 2.0), cm)
+    wb = kernel.WindowFunctionGalaxy(kernel.dNdzMagLim(0.0, 2.0, 2.0, 0.3, 2.0), cm)
+    kern = kernel.Kernel(1e-6 * d2r, 100.0 * d2r, wa, wb, cm)
+    zb = kern.z_bar
+    assert abs(zb - float(g["z_bar"])) < 1e-12
+    hz = halo.HaloFit(zb, cosmo_single_epoch=cosmology.SingleEpoch(zb, with_bao=True))
+    corr = correlation.Correlation(0.001, 1.0, kern, input_halo=hz, power_spec="power_mm")
+    assert hz.cosmo._with_bao
+    assert rel_err(corr.correlation(g["theta"]), g["w_mm"]) < RTOL
