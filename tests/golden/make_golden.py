@@ -510,6 +510,21 @@ def g17(ns):
     save("g17_halofit_bao", **out)
 
 
+def g18(ns):
+    """dNdChiGaussian (kernel.py:114-145): a Gaussian in comoving distance as the lens
+    distribution of a galaxy x convergence J0 kernel."""
+    cm = ns.cosmology.MultiEpoch(0.0, 5.0)
+    dist = ns.kernel.dNdChiGaussian(600.0, 1800.0, 1200.0, 150.0, cm)
+    wa = ns.kernel.WindowFunctionGalaxy(dist, cm)
+    wb = ns.kernel.WindowFunctionConvergence(ns.kernel.dNdzGaussian(0.0, 2.0, 1.0, 0.2), cm)
+    kern = ns.kernel.Kernel(1e-6 * deg_to_rad, 100.0 * deg_to_rad, wa, wb, cm)
+    out = _kernel_tables(kern)
+    z_probe = numpy.linspace(0.1, 0.8, 29)
+    out.update(z_probe=z_probe, dndz_probe=dist.dndz(z_probe), z_min=dist.z_min,
+               z_max=dist.z_max)
+    save("g18_dndchi_gaussian", **out)
+
+
 def pins():
     """Known-answer literals held by the reference's own tests (unit_test.py),
     restricted to the classes that pass against the shipped code."""
@@ -542,7 +557,7 @@ def pins():
 
 
 def main():
-    names = sys.argv[1:] or ["pins", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
+    names = sys.argv[1:] or ["pins", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
     ns = ref_loader.load()
     cwd = os.getcwd()
     with tempfile.TemporaryDirectory() as tmp:

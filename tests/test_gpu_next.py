@@ -502,3 +502,28 @@ def test_halofit_on_the_wiggle_transfer_function():
     corr = correlation.Correlation(0.001, 1.0, kern, input_halo=hz, power_spec="power_mm")
     assert hz.cosmo._with_bao
     assert rel_err(corr.correlation(g["theta"]), g["w_mm"]) < RTOL
+
+
+def test_dndchi_gaussian():
+    """dNdChiGaussian (kernel.py:114-145) as a lens distribution, against the reference (G18)."""
+    from chomp_amd import cosmology, kernel
+    g = load_golden("g18_dndchi_gaussian")
+    d2r = numpy.pi / 180.0
+    cm = cosmology.MultiEpoch(0.0, 5.0)
+    dist = kernel.dNdChiGaussian(600.0, 1800.0, 1200.0, 150.0, cm)
+    assert abs(dist.z_min / float(g["z_min"]) - 1) < 1e-8
+    assert abs(dist.z_max / float(g["z_max"]) - 1) < 1e-8
+    assert numpy.allclose(dist.dndz(g["z_probe"]), g["dndz_probe"], rtol=1e-6, atol=1e-9)
+    wa = kernel.WindowFunctionGalaxy(dist, cm)
+    wb = kernel.WindowFunctionConvergence(kernel.dNdzGaussian(0.0, 2.0, 1.0, 0.2), cm)
+    kern = kernel.Kernel(1e-6 * d2r, 100.0 * d2r, wa, wb, cm)
+    assert abs(kern.z_bar / float(g["z_bar"]) - 1) < 1e-9      # (z limits come from a spline inverse)
+    ctx = kern._dev()
+    assert abs(ctx.kernel_info()["norm_a"] / float(g["wa_norm"]) - 1) < 1e-6
+    wa_tab = ctx.kernel_table("wa")
+    assert numpy.allclose(wa_tab[:-1], g["wa"][:-1], rtol=5e-6, atol=1e-9 * g["wa"].max())
+    # the last knot sits exactly on z_max = redshift(chi_max): whether redshift(chi(z_max)) <= z_max
+    # holds there is a matter of the last bit of two spline evaluations (4e-4 of the peak either way)
+    assert wa_tab[-1] == 0.0 or abs(wa_tab[-1] / g["wa"][-1] - 1) < 5e-6
+    scale = numpy.max(numpy.abs(g["kernel"]))
+    assert numpy.allclose(ctx.kernel_table("kernel"), g["kernel"], rtol=2e-4, atol=2e-5 * scale)
