@@ -72,6 +72,7 @@ struct chomp_ctx {
   double* d_deep = nullptr;        // k_halo_deep_*: Romberg state and chunk sums of the listed knots
   size_t cap_slow = 0, cap_winfo = 0, cap_ktab = 0, cap_wnodes = 0, cap_deep = 0;
   int slow_parity = 0;
+  bool slow_by_memset = false;     // set once a Stage E call has been captured into a HIP graph
   int precision = CHOMP_PREC_F64;  // chomp_set_precision
   int with_bao = 0;                // chomp_set_transfer
   int timing = 0;                  // chomp_set_timing: HIP events around the Stage E launches
@@ -625,8 +626,20 @@ int chomp_power_range(chomp_ctx* ctx, int which, size_t epoch0, size_t n, const 
     if (ctx->cap_slow != had) {                    // fresh buffer: clear both counters
       HIPCHK(hipMemsetAsync(ctx->d_slow, 0, 2 * sizeof(int), ctx->stream));
     }
-    const int parity = ctx->slow_parity;
-    ctx->slow_parity ^= 1;
+    // The list counters ping-pong on a host-side parity bit (a launch appends through one and
+    // clears the other for the next call).  A call captured into a HIP graph would replay ONE
+    // parity for ever and run its counter past the list, so under capture the call clears both
+    // counters itself (a memset node) and keeps the bit still.
+    int parity = ctx->slow_parity;
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    HIPCHK(hipStreamIsCapturing(ctx->stream, &capture));
+    if (capture == hipStreamCaptureStatusActive) ctx->slow_by_memset = true;
+    if (ctx->slow_by_memset) {       // (sticky: a graph may be replayed between any two calls)
+      HIPCHK(hipMemsetAsync(ctx->d_slow, 0, 2 * sizeof(int), ctx->stream));
+      parity = 0;
+    } else {
+      ctx->slow_parity ^= 1;
+    }
     bool one_cosmology = true;
     for (size_t i = 1; i < n; ++i) one_cosmology &= ctx->slot[epoch0 + i] == ctx->slot[epoch0];
     const int w = which & 15;

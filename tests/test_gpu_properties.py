@@ -355,3 +355,36 @@ def test_deep_knot_paths_agree():
                 a, b = lev_b[fam * nk:(fam + 1) * nk], lev_s[fam * nk:(fam + 1) * nk]
                 assert numpy.array_equal(a, b), (which, i, fam)
             assert lev_s[(3 if which == "power_gm" else 4) * nk:][:nk].max() > 10
+
+
+def test_step_replays_from_a_hip_graph():
+    """A whole step (Stage K + Stage E) captured into a HIP graph and replayed: same bits as
+    the eager calls, also when replays and eager calls alternate (the Stage E work-list
+    counters must not depend on host-side state that a replay does not see)."""
+    import torch
+    from chomp_amd import grid
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        z = numpy.linspace(0.0, 1.2, 16)
+        k = torch.logspace(-3.2, 2.2, 4096, dtype=torch.float64, device="cuda")   # some k out of range
+        out = torch.zeros((16, 4096), dtype=torch.float64, device="cuda")
+        hg = grid.HaloGrid(z, stream=s.cuda_stream)
+
+        def step():
+            hg.setup("power_mm")
+            hg.power("power_mm", k, out=out)
+        step()
+        step()
+        torch.cuda.synchronize()
+        ref = out.clone()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            step()
+        torch.cuda.synchronize()
+        for i in range(7):
+            out.zero_()
+            g.replay()
+            if i % 3 == 2:
+                step()                     # an eager call in between
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref), i
