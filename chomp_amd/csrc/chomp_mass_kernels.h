@@ -81,6 +81,15 @@ __device__ __forceinline__ bool same_cosmology(const Epoch& a, const Epoch& b) {
          a.tcmb == b.tcmb && a.h == b.h && a.ns == b.ns;
 }
 
+// Per-epoch status word (chomp_get_status): the device-side copies of the CHOMP_ST_* bits.
+constexpr unsigned kStMassMinSaturated = CHOMP_ST_MASS_MIN_SATURATED;
+constexpr unsigned kStMassMaxSaturated = CHOMP_ST_MASS_MAX_SATURATED;
+constexpr unsigned kStSearchExhausted = CHOMP_ST_MASS_SEARCH_EXHAUSTED;
+constexpr unsigned kStSigmaDivmax = CHOMP_ST_SIGMA_DIVMAX;
+constexpr unsigned kStHaloDivmax0 = CHOMP_ST_HALO_DIVMAX_H_M;       // << family index
+constexpr unsigned kStNonfinite = CHOMP_ST_NONFINITE;
+constexpr unsigned kStHaloBits = (31u * CHOMP_ST_HALO_DIVMAX_H_M) | CHOMP_ST_NONFINITE;
+
 // Cooperative copy of POD blocks as doubles.
 __device__ __forceinline__ void copy_doubles(double* dst, const double* src, int n) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
@@ -160,7 +169,8 @@ __global__ __launch_bounds__(256) void k_sigma_nodes(chomp_config cfg,
                                                      const int* __restrict__ first,
                                                      const int* __restrict__ slots, int n_slots,
                                                      int n_epoch, Epoch* __restrict__ epochs,
-                                                     double* __restrict__ snodes) {
+                                                     double* __restrict__ snodes,
+                                                     unsigned* __restrict__ status) {
   __shared__ Epoch E;
   __shared__ double red[romberg_scratch<4, 1>()];
   if ((int)blockIdx.y >= n_slots) {
@@ -176,6 +186,7 @@ __global__ __launch_bounds__(256) void k_sigma_nodes(chomp_config cfg,
     epoch_background(B, cfg.cosmo_precision, cfg.k_min, cfg.k_max, BAO ? 1 : 0);
     B.cosmo_slot = slots[e];
     epochs[e] = B;
+    status[e] = 0u;
     return;
   }
   const int slot = blockIdx.y, e = first[slot];
@@ -347,7 +358,7 @@ struct SigmaTabIntegrand {
 template <int NW, int UNROLL = 1, bool BAO = false>
 __device__ __forceinline__ double sigma2_block(const Epoch& E, const double* snode, double R,
                                                const chomp_config& cfg, double rtol,
-                                               double* red) {
+                                               double* red, bool* converged = nullptr) {
   double lo, hi;
   sigma_limits(E, R, &lo, &hi);
   const double need_min = 1.0 / R / 10.0, need_max = 1.0 / R * 14.0662;
@@ -357,10 +368,14 @@ __device__ __forceinline__ double sigma2_block(const Epoch& E, const double* sno
     SigmaTabIntegrand<BAO> f{&E, snode, R, 1.0 / amp2, 9.0 / (r3 * r3)};
     const RombergOut<1> r = romberg_group<NW, 1, SigmaTabIntegrand<BAO>, UNROLL>(
         f, lo, hi, cfg.global_precision, rtol, cfg.divmax, red);
+    if (converged) *converged = r.converged[0];
     return amp2 * r.value[0];
   }
   SigmaIntegrandT<BAO> f{&E, R};
-  return romberg1<NW>(f, lo, hi, cfg.global_precision, rtol, cfg.divmax, red);
+  Scalar1<SigmaIntegrandT<BAO>> w{f};
+  const RombergOut<1> r = romberg_group<NW, 1>(w, lo, hi, cfg.global_precision, rtol, cfg.divmax, red);
+  if (converged) *converged = r.converged[0];
+  return r.value[0];
 }
 
 // Not-a-knot spline build by parallel cyclic reduction.  Every thread of the block
@@ -398,8 +413,10 @@ __device__ __forceinline__ void spline_build_pcr(const double* x, const double* 
 template <int NW, int UNROLL = 1, bool BAO = false>
 __device__ __forceinline__ double nu_of_mass_block(const Epoch& E, const double* snode,
                                                    double mass, const chomp_config& cfg,
-                                                   double rtol, double* red) {
-  const double s2 = sigma2_block<NW, UNROLL, BAO>(E, snode, scale_of_mass(E, mass), cfg, rtol, red);
+                                                   double rtol, double* red,
+                                                   bool* converged = nullptr) {
+  const double s2 = sigma2_block<NW, UNROLL, BAO>(E, snode, scale_of_mass(E, mass), cfg, rtol, red,
+                                                  converged);
   const double sq = E.delta_c / sqrt(s2);
   return sq * sq;
 }
