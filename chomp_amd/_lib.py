@@ -102,8 +102,47 @@ EXPORTS = [
     "chomp_set_precision", "chomp_xi3d", "chomp_spline_eval", "chomp_hod_stats",
     "chomp_set_transfer", "chomp_kernel_raw",
     "chomp_covariance_table", "chomp_covariance_gaussian",
-    "chomp_set_timing", "chomp_get_timing",
+    "chomp_set_timing", "chomp_get_timing", "chomp_get_status", "chomp_set_tuning",
+    "chomp_get_deep_stats",
 ]
+
+# chomp_get_status bits (include/chomp_mi355x.h)
+ST_MASS_MIN_SATURATED, ST_MASS_MAX_SATURATED, ST_MASS_SEARCH_EXHAUSTED, ST_SIGMA_DIVMAX = 1, 2, 4, 8
+ST_HALO_DIVMAX = {"h_m": 0x100, "pp_mm": 0x200, "h_g": 0x400, "pp_gm": 0x800, "pp_gg": 0x1000}
+ST_NONFINITE = 0x10000
+ST_SATURATED = ST_MASS_MIN_SATURATED | ST_MASS_MAX_SATURATED
+TUNE_E_STREAM_MIN, TUNE_E_ROWS, TUNE_DEEP_LITERAL = 0, 1, 2
+
+
+class ChompAccuracyWarning(UserWarning):
+    """What scipy.integrate.romberg's AccuracyWarning (divmax exceeded) was in the reference."""
+
+
+class ChompParityWarning(UserWarning):
+    """The result is well defined but the reference's own answer for this input is decided by
+    rounding noise (saturated mass-limit search): the two may differ by percents."""
+
+
+def describe_status(word):
+    """Human-readable list of the bits of a chomp_get_status word."""
+    out = []
+    if word & ST_MASS_MIN_SATURATED:
+        out.append("mass_min search ended in the saturated regime of sigma_r (k R < 0.2 over "
+                   "its whole k range, cosmology.py:627-632): the reference's own limit is "
+                   "decided by rounding error there")
+    if word & ST_MASS_MAX_SATURATED:
+        out.append("mass_max search ended in the saturated regime of sigma_r "
+                   "(k range clamped at k_min / 100, cosmology.py:617-622)")
+    if word & ST_MASS_SEARCH_EXHAUSTED:
+        out.append("mass-limit search did not end within 2047 steps of 5 %")
+    if word & ST_SIGMA_DIVMAX:
+        out.append("a sigma(R) Romberg of the nu table exhausted divmax")
+    for name, bit in ST_HALO_DIVMAX.items():
+        if word & bit:
+            out.append("%s: Romberg exhausted divmax at some knots (last row kept)" % name)
+    if word & ST_NONFINITE:
+        out.append("a knot table holds NaN / infinity")
+    return out
 
 
 def sources():
@@ -112,19 +151,43 @@ def sources():
         os.path.join(HERE, "..", "include", "chomp_mi355x.h")]
 
 
+HASH_PATH = LIB_PATH + ".srchash"
+
+
+def source_hash():
+    """Content hash of everything the library is compiled from (mtimes do not survive a
+    copy of the tree to another box; contents do)."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sources():
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=False):
     """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a
-    GPU).  Rebuilds when a source is newer than the .so."""
+    GPU).  Rebuilds when the sources differ from the ones the .so was built from (their
+    hash is kept beside it)."""
+    want = source_hash()
     if not force and os.path.exists(LIB_PATH):
-        so_t = os.path.getmtime(LIB_PATH)
-        if all(os.path.getmtime(s) <= so_t for s in sources()):
-            return LIB_PATH
+        try:
+            with open(HASH_PATH) as f:
+                if f.read().strip() == want:
+                    return LIB_PATH
+        except OSError:
+            pass
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    tmp = LIB_PATH + ".tmp%d" % os.getpid()
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-o", LIB_PATH, os.path.join(CSRC, "chomp_capi.hip")]
+           "-o", tmp, os.path.join(CSRC, "chomp_capi.hip")]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
+    os.replace(tmp, LIB_PATH)
+    with open(HASH_PATH, "w") as f:
+        f.write(want + "\n")
     return LIB_PATH
 
 
@@ -161,14 +224,19 @@ def lib():
     with _lock:
         if _lib is not None:
             return _lib
-        if not os.path.exists(LIB_PATH):
-            try:
-                build()
-            except Exception as exc:   # noqa: BLE001
+        # build() is a no-op when the library is newer than every source; a box without
+        # hipcc (or a read-only tree) keeps the prebuilt library it was shipped
+        try:
+            build()
+        except Exception as exc:   # noqa: BLE001
+            if not os.path.exists(LIB_PATH):
                 raise ImportError(
                     "chomp_amd: libchomp_mi355x.so is missing and could not be "
                     "built with hipcc (%s). This package has no CPU fallback."
                     % exc) from exc
+            import warnings
+            warnings.warn("chomp_amd: sources are newer than libchomp_mi355x.so and the "
+                          "rebuild failed (%s); using the existing library" % exc)
         _preload_hip_runtime()
         L = ctypes.CDLL(LIB_PATH)
         for name in EXPORTS:
@@ -215,6 +283,9 @@ def lib():
         L.chomp_set_transfer.argtypes = [vp, i]
         L.chomp_set_timing.argtypes = [vp, i]
         L.chomp_get_timing.argtypes = [vp, c_double_p, sz]
+        L.chomp_get_status.argtypes = [vp, sz, sz, ctypes.POINTER(ctypes.c_uint)]
+        L.chomp_set_tuning.argtypes = [vp, i, ctypes.c_longlong]
+        L.chomp_get_deep_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_longlong)]
         L.chomp_covariance_table.argtypes = [vp, i, sz, d, c_double_p, c_double_p,
                                              c_double_p, sz]
         L.chomp_covariance_gaussian.argtypes = [vp, d, d, d, d, vp, sz, vp, i]
@@ -447,6 +518,43 @@ class Context(object):
 
     def sync(self):
         self._check(self._L.chomp_sync(self._h))
+
+    def status(self, epoch0=0, n=None):
+        """Per-epoch status words (uint32 array; bits ST_*, describe_status).  Synchronises."""
+        n = self.n_epoch - epoch0 if n is None else n
+        out = numpy.zeros(n, dtype=numpy.uint32)
+        if n:
+            self._check(self._L.chomp_get_status(
+                self._h, epoch0, n, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint))))
+        return out
+
+    def warn_status(self, epoch0=0, n=None, stacklevel=3):
+        """Turn the status words of the epochs into Python warnings, as the reference's
+        scipy.integrate.romberg did for an exhausted divmax (AccuracyWarning); a saturated
+        mass-limit search gets a ChompParityWarning.  Returns the words."""
+        import warnings
+        words = self.status(epoch0, n)
+        for i, w in enumerate(words):
+            w = int(w)
+            if not w:
+                continue
+            kind = (ChompParityWarning if w & (ST_SATURATED | ST_MASS_SEARCH_EXHAUSTED)
+                    else ChompAccuracyWarning)
+            warnings.warn("epoch %d: %s" % (epoch0 + i, "; ".join(describe_status(w))), kind,
+                          stacklevel=stacklevel)
+        return words
+
+    def deep_stats(self):
+        """(knots done by the fast deep-level sums, knots done by literal evaluation) so far."""
+        out = (ctypes.c_longlong * 6)()
+        self._check(self._L.chomp_get_deep_stats(self._h, out))
+        self.deep_detail = {"too_many_breaks": int(out[2]), "too_many_fine": int(out[3]),
+                            "self_check": int(out[4]), "worst_estimate": out[5] * 1e-15}
+        return int(out[0]), int(out[1])
+
+    def set_tuning(self, what, value):
+        """Test / tuning hook (chomp_set_tuning); value None or < 0 restores the default."""
+        self._check(self._L.chomp_set_tuning(self._h, int(what), -1 if value is None else int(value)))
 
     # -- projection ------------------------------------------------------------
     def kernel_setup(self, cosmo_dict, me_z_min, me_z_max, ktheta_min, ktheta_max,

@@ -21,6 +21,29 @@
 
 using namespace chomp;
 
+// A parameter block of the epoch batch on its way to the device: the host shadow says what
+// the device holds (an unchanged block is not uploaded again -- MCMC-style loops re-run the
+// set-up with mostly identical inputs); a changed block goes through one of two pinned
+// staging buffers, each guarded by an event, so the copy is a true asynchronous DMA and the
+// host never drains the stream (SimulationDesign / MCMC loops change a block on every call).
+struct StagedBlock {
+  std::vector<char> shadow;
+  void* pin[2] = {nullptr, nullptr};
+  hipEvent_t done[2] = {nullptr, nullptr};
+  bool used[2] = {false, false};
+  size_t cap = 0;
+  int turn = 0;
+  void reset() { shadow.clear(); }
+  void release() {
+    for (int i = 0; i < 2; ++i) {
+      if (pin[i]) (void)hipHostFree(pin[i]);
+      if (done[i]) (void)hipEventDestroy(done[i]);
+      pin[i] = nullptr; done[i] = nullptr; used[i] = false;
+    }
+    cap = 0;
+  }
+};
+
 struct chomp_ctx {
   chomp_config cfg;
   int device = 0;
@@ -54,12 +77,21 @@ struct chomp_ctx {
   double* d_snodes = nullptr;      // node tables of the sigma(R) integrals (per cosmology slot)
   int* d_slot = nullptr;           // epoch -> cosmology slot
   int* d_first = nullptr;          // slot -> an epoch with that cosmology
+  unsigned* d_status = nullptr;    // per-epoch status word (chomp_get_status)
+  long long tune[CHOMP_TUNE_COUNT] = {-1, -1, -1};   // chomp_set_tuning
   bool have_epochs = false, have_mass = false, have_halo = false;
   unsigned fam_mask = 0;          // families (F_* bits) with valid splines
   std::vector<char> have_halofit;
-  // host shadows of the uploaded parameter blocks: an unchanged block is not
-  // re-uploaded (MCMC-style loops re-run the set-up with mostly identical inputs)
-  std::vector<char> sh_cosmo, sh_z, sh_mass, sh_profile, sh_hod, sh_slot, sh_first;
+  StagedBlock sh_cosmo, sh_z, sh_mass, sh_profile, sh_hod, sh_slot, sh_first;
+  StagedBlock sh_proj, sh_pp[2];   // projection scalars, tabulated redshift distributions
+  // pinned host mirrors of the staging buffers of host-pointer calls (chomp_power)
+  double* h_stage_in = nullptr;
+  double* h_stage_out = nullptr;
+  size_t cap_hin = 0, cap_hout = 0;
+  // Buffers a captured HIP graph may still reference are never freed before the context
+  // is destroyed (graph_seen: a call of this context has been captured at least once).
+  bool graph_seen = false;
+  std::vector<void*> graveyard;
 
   // staging for host-pointer calls
   double* d_stage_in = nullptr;
@@ -69,8 +101,9 @@ struct chomp_ctx {
   int* d_winfo = nullptr;          // Stage E: per k group knot interval / flags (k_power_prep)
   double* d_ktab = nullptr;        // Stage E: per-k (offset, shape) table (k_power_prep)
   double* d_wnodes = nullptr;      // w(theta): theta-independent integrand factor on the Romberg nodes
-  double* d_deep = nullptr;        // k_halo_deep_*: Romberg state and chunk sums of the listed knots
-  size_t cap_slow = 0, cap_winfo = 0, cap_ktab = 0, cap_wnodes = 0, cap_deep = 0;
+  double* d_deepw = nullptr;       // k_halo_knots_fast: level weights (deep_weights_host)
+  int* d_deepstat = nullptr;       // k_halo_knots_fast: knots done by the fast / literal path
+  size_t cap_slow = 0, cap_winfo = 0, cap_ktab = 0, cap_wnodes = 0;
   int slow_parity = 0;
   bool slow_by_memset = false;     // set once a Stage E call has been captured into a HIP graph
   int precision = CHOMP_PREC_F64;  // chomp_set_precision
@@ -100,24 +133,77 @@ int fail(chomp_ctx* c, int code, const std::string& msg) {
                   std::string(#call) + ": " + hipGetErrorString(e_));             \
   } while (0)
 
+bool capturing(chomp_ctx* ctx) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(ctx->stream, &st) != hipSuccess) return false;
+  if (st == hipStreamCaptureStatusActive) ctx->graph_seen = true;
+  return st == hipStreamCaptureStatusActive;
+}
+
+// Free a device buffer, unless a captured graph may still hold its address.
+int release_device(chomp_ctx* ctx, void* p) {
+  if (!p) return CHOMP_OK;
+  if (ctx->graph_seen) { ctx->graveyard.push_back(p); return CHOMP_OK; }
+  HIPCHK(hipFree(p));
+  return CHOMP_OK;
+}
+
 // Upload `bytes` from `src` to `dst` unless the shadow says the device already holds
-// exactly these bytes.  A changed block is copied from the shadow (which outlives
-// the call) and the stream is drained so the shadow can be rewritten next time.
-int upload(chomp_ctx* ctx, void* dst, const void* src, size_t bytes, std::vector<char>& shadow) {
-  if (shadow.size() == bytes && std::memcmp(shadow.data(), src, bytes) == 0) return CHOMP_OK;
-  if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(ctx, CHOMP_ERR_HIP, "upload: sync");
-  shadow.assign(static_cast<const char*>(src), static_cast<const char*>(src) + bytes);
-  hipError_t e = hipMemcpyAsync(dst, shadow.data(), bytes, hipMemcpyHostToDevice, ctx->stream);
-  if (e != hipSuccess) return fail(ctx, CHOMP_ERR_HIP, std::string("upload: ") + hipGetErrorString(e));
+// exactly these bytes.  No host synchronisation with the stream (see StagedBlock).
+// Under stream capture a changed block is an error: the graph would bake in the staging
+// buffer's contents of capture time (include/chomp_mi355x.h, "HIP graphs").
+int upload(chomp_ctx* ctx, void* dst, const void* src, size_t bytes, StagedBlock& b) {
+  if (b.shadow.size() == bytes && std::memcmp(b.shadow.data(), src, bytes) == 0) return CHOMP_OK;
+  if (capturing(ctx))
+    return fail(ctx, CHOMP_ERR_STATE,
+                "a parameter block changed while the context's stream is being captured: run the "
+                "set-up once with these parameters before capturing (HIP graphs replay the "
+                "captured parameters)");
+  if (bytes > b.cap) {
+    // (buffers still in flight are drained by their events first)
+    for (int i = 0; i < 2; ++i)
+      if (b.used[i]) HIPCHK(hipEventSynchronize(b.done[i]));
+    const size_t cap = bytes + bytes / 2;
+    for (int i = 0; i < 2; ++i) {
+      if (b.pin[i]) HIPCHK(hipHostFree(b.pin[i]));
+      b.pin[i] = nullptr;
+      HIPCHK(hipHostMalloc(&b.pin[i], cap, hipHostMallocDefault));
+      if (!b.done[i]) HIPCHK(hipEventCreateWithFlags(&b.done[i], hipEventDisableTiming));
+      b.used[i] = false;
+    }
+    b.cap = cap;
+  }
+  const int t = b.turn;
+  if (b.used[t]) HIPCHK(hipEventSynchronize(b.done[t]));   // the copy of two uploads ago: long done
+  std::memcpy(b.pin[t], src, bytes);
+  HIPCHK(hipMemcpyAsync(dst, b.pin[t], bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipEventRecord(b.done[t], ctx->stream));
+  b.used[t] = true;
+  b.turn = t ^ 1;
+  b.shadow.assign(static_cast<const char*>(src), static_cast<const char*>(src) + bytes);
   return CHOMP_OK;
 }
 
 template <class T>
 int ensure(chomp_ctx* ctx, T** p, size_t* cap, size_t n) {
   if (n <= *cap && *p) return CHOMP_OK;
-  if (*p) HIPCHK(hipFree(*p));
+  if (capturing(ctx))
+    return fail(ctx, CHOMP_ERR_STATE,
+                "a work buffer would have to grow while the context's stream is being captured: "
+                "run the call once at this size before capturing");
+  if (*p) { const int rc = release_device(ctx, *p); if (rc) return rc; }
   *p = nullptr;
   HIPCHK(hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T)));
+  *cap = n;
+  return CHOMP_OK;
+}
+
+// Pinned host mirror of a staging buffer (host-pointer calls).
+int ensure_host(chomp_ctx* ctx, double** p, size_t* cap, size_t n) {
+  if (n <= *cap && *p) return CHOMP_OK;
+  if (*p) HIPCHK(hipHostFree(*p));
+  *p = nullptr;
+  HIPCHK(hipHostMalloc(reinterpret_cast<void**>(p), n * sizeof(double), hipHostMallocDefault));
   *cap = n;
   return CHOMP_OK;
 }
@@ -185,6 +271,15 @@ int setup_constants(chomp_ctx* ctx) {
       m = mul[t] ? m * 1.05 : m / 1.05;
     }
   }
+  {   // level weights of the fast deep-knot sums
+    const int top = ctx->cfg.divmax;
+    std::vector<double> w((size_t)(top > kDeepCoarse ? top - kDeepCoarse : 1) * kDeepWStride, 0.0);
+    if (top > kDeepCoarse) deep_weights_host(kDeepCoarse, top, w.data());
+    HIPCHK(hipMalloc(&ctx->d_deepw, w.size() * sizeof(double)));
+    HIPCHK(hipMemcpy(ctx->d_deepw, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&ctx->d_deepstat, 8 * sizeof(int)));
+    HIPCHK(hipMemset(ctx->d_deepstat, 0, 8 * sizeof(int)));
+  }
   HIPCHK(hipMalloc(&ctx->d_cand, cand.size() * sizeof(double)));
   HIPCHK(hipMemcpy(ctx->d_cand, cand.data(), cand.size() * sizeof(double),
                    hipMemcpyHostToDevice));
@@ -193,11 +288,16 @@ int setup_constants(chomp_ctx* ctx) {
 
 int alloc_epochs(chomp_ctx* ctx, size_t n) {
   if (n <= ctx->cap_epoch) return CHOMP_OK;
+  if (capturing(ctx))
+    return fail(ctx, CHOMP_ERR_STATE,
+                "the epoch batch would have to grow while the context's stream is being captured");
   void* old[] = {ctx->d_cosmo, ctx->d_z, ctx->d_epochs, ctx->d_search, ctx->d_probe, ctx->d_count, ctx->d_pending, ctx->d_tab,
                  ctx->d_mass_par, ctx->d_profile, ctx->d_hod, ctx->d_nodes, ctx->d_snodes,
-                 ctx->d_slot, ctx->d_first};
-  for (void* p : old)
-    if (p) HIPCHK(hipFree(p));
+                 ctx->d_slot, ctx->d_first, ctx->d_status};
+  for (void* p : old) {
+    const int rc = release_device(ctx, p);
+    if (rc) return rc;
+  }
   HIPCHK(hipMalloc(&ctx->d_cosmo, n * sizeof(chomp_cosmo)));
   HIPCHK(hipMalloc(&ctx->d_z, n * sizeof(double)));
   HIPCHK(hipMalloc(&ctx->d_epochs, n * sizeof(Epoch)));
@@ -217,9 +317,10 @@ int alloc_epochs(chomp_ctx* ctx, size_t n) {
   HIPCHK(hipMemsetAsync(ctx->d_snodes, 0, n * (size_t)kSigmaStride * sizeof(double), ctx->stream));
   HIPCHK(hipMalloc(&ctx->d_slot, n * sizeof(int)));
   HIPCHK(hipMalloc(&ctx->d_first, n * sizeof(int)));
+  HIPCHK(hipMalloc(&ctx->d_status, n * sizeof(unsigned)));
   ctx->cap_epoch = n;
-  ctx->sh_cosmo.clear(); ctx->sh_z.clear(); ctx->sh_mass.clear();
-  ctx->sh_profile.clear(); ctx->sh_hod.clear(); ctx->sh_slot.clear(); ctx->sh_first.clear();
+  ctx->sh_cosmo.reset(); ctx->sh_z.reset(); ctx->sh_mass.reset();
+  ctx->sh_profile.reset(); ctx->sh_hod.reset(); ctx->sh_slot.reset(); ctx->sh_first.reset();
   return CHOMP_OK;
 }
 
@@ -290,11 +391,18 @@ void chomp_ctx_destroy(chomp_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   void* ptrs[] = {ctx->d_sici, ctx->d_j0, ctx->d_j2, ctx->d_tinker, ctx->d_gl16,
                   ctx->d_cand, ctx->d_cosmo, ctx->d_z, ctx->d_epochs, ctx->d_search, ctx->d_probe, ctx->d_count, ctx->d_pending,
-                  ctx->d_tab, ctx->d_mass_par, ctx->d_profile, ctx->d_hod, ctx->d_nodes, ctx->d_snodes, ctx->d_slot, ctx->d_first,
-                  ctx->d_stage_in, ctx->d_stage_in2, ctx->d_stage_out, ctx->d_slow, ctx->d_wnodes, ctx->d_deep,
+                  ctx->d_tab, ctx->d_mass_par, ctx->d_profile, ctx->d_hod, ctx->d_nodes, ctx->d_snodes, ctx->d_slot, ctx->d_first, ctx->d_status,
+                  ctx->d_stage_in, ctx->d_stage_in2, ctx->d_stage_out, ctx->d_slow, ctx->d_wnodes, ctx->d_deepw, ctx->d_deepstat,
                   ctx->d_winfo, ctx->d_ktab};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  for (void* p : ctx->graveyard) (void)hipFree(p);
+  for (StagedBlock* b : {&ctx->sh_cosmo, &ctx->sh_z, &ctx->sh_mass, &ctx->sh_profile, &ctx->sh_hod,
+                         &ctx->sh_slot, &ctx->sh_first, &ctx->sh_proj, &ctx->sh_pp[0],
+                         &ctx->sh_pp[1]})
+    b->release();
+  if (ctx->h_stage_in) (void)hipHostFree(ctx->h_stage_in);
+  if (ctx->h_stage_out) (void)hipHostFree(ctx->h_stage_out);
   proj_free(ctx->proj);
   for (hipEvent_t e : ctx->ev)
     if (e) (void)hipEventDestroy(e);
@@ -333,6 +441,37 @@ int chomp_get_timing(chomp_ctx* ctx, double* us, size_t n) {
 int chomp_sync(chomp_ctx* ctx) {
   if (!ctx) return CHOMP_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return CHOMP_OK;
+}
+
+int chomp_set_tuning(chomp_ctx* ctx, int what, long long value) {
+  if (!ctx) return CHOMP_ERR_ARG;
+  if (what < 0 || what >= CHOMP_TUNE_COUNT) return fail(ctx, CHOMP_ERR_ARG, "set_tuning: unknown knob");
+  ctx->tune[what] = value < 0 ? -1 : value;
+  return CHOMP_OK;
+}
+
+int chomp_get_deep_stats(chomp_ctx* ctx, long long* out) {
+  if (!ctx || !out) return fail(ctx, CHOMP_ERR_ARG, "get_deep_stats: bad args");
+  HIPCHK(hipSetDevice(ctx->device));
+  int v[8] = {0};
+  HIPCHK(hipMemcpyAsync(v, ctx->d_deepstat, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < 5; ++i) out[i] = v[i];
+  float worst;
+  std::memcpy(&worst, &v[5], sizeof worst);
+  out[5] = (long long)((double)worst * 1e15);      // largest self-check estimate, in 1e-15
+  return CHOMP_OK;
+}
+
+int chomp_get_status(chomp_ctx* ctx, size_t epoch0, size_t n, unsigned* out) {
+  if (!ctx || !out || n == 0) return fail(ctx, CHOMP_ERR_ARG, "get_status: bad args");
+  if (!ctx->have_epochs) return fail(ctx, CHOMP_ERR_STATE, "get_status before epochs_set");
+  if (epoch0 + n > ctx->n_epoch) return fail(ctx, CHOMP_ERR_ARG, "get_status: epoch range");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipMemcpyAsync(out, ctx->d_status + epoch0, n * sizeof(unsigned), hipMemcpyDeviceToHost,
+                        ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return CHOMP_OK;
 }
@@ -381,17 +520,17 @@ int chomp_epochs_set(chomp_ctx* ctx, size_t n_epoch, const chomp_cosmo* cosmo,
   if (ctx->with_bao) {
     hipLaunchKernelGGL(k_sigma_nodes<true>, gs, dim3(256), 0, ctx->stream, ctx->cfg, ctx->d_cosmo,
                        ctx->d_z, ctx->d_first, ctx->d_slot, (int)n_slots, (int)n_epoch,
-                       ctx->d_epochs, ctx->d_snodes);
+                       ctx->d_epochs, ctx->d_snodes, ctx->d_status);
     hipLaunchKernelGGL(k_epoch_init<true>, gi, dim3(64 * kInitNW), 0, ctx->stream, ctx->cfg,
                        ctx->d_epochs, ctx->d_search, ctx->d_cand, ctx->d_snodes, ctx->d_probe,
-                       ctx->d_count);
+                       ctx->d_count, ctx->d_status);
   } else {
     hipLaunchKernelGGL(k_sigma_nodes<false>, gs, dim3(256), 0, ctx->stream, ctx->cfg, ctx->d_cosmo,
                        ctx->d_z, ctx->d_first, ctx->d_slot, (int)n_slots, (int)n_epoch,
-                       ctx->d_epochs, ctx->d_snodes);
+                       ctx->d_epochs, ctx->d_snodes, ctx->d_status);
     hipLaunchKernelGGL(k_epoch_init<false>, gi, dim3(64 * kInitNW), 0, ctx->stream, ctx->cfg,
                        ctx->d_epochs, ctx->d_search, ctx->d_cand, ctx->d_snodes, ctx->d_probe,
-                       ctx->d_count);
+                       ctx->d_count, ctx->d_status);
   }
   HIPCHK(hipGetLastError());
   ctx->have_epochs = true;
@@ -410,10 +549,10 @@ int chomp_mass_setup(chomp_ctx* ctx, const chomp_halo_par* par, int mf_kind) {
   if (rcu) return rcu;
   if (ctx->with_bao)
     hipLaunchKernelGGL(k_nu_table<true>, dim3(L.NM, (unsigned)n), dim3(64 * kNuNW), 0, ctx->stream,
-                       ctx->cfg, L, ctx->d_epochs, ctx->d_search, ctx->d_snodes, ctx->d_tab);
+                       ctx->cfg, L, ctx->d_epochs, ctx->d_search, ctx->d_snodes, ctx->d_tab, ctx->d_status);
   else
     hipLaunchKernelGGL(k_nu_table<false>, dim3(L.NM, (unsigned)n), dim3(64 * kNuNW), 0, ctx->stream,
-                       ctx->cfg, L, ctx->d_epochs, ctx->d_search, ctx->d_snodes, ctx->d_tab);
+                       ctx->cfg, L, ctx->d_epochs, ctx->d_search, ctx->d_snodes, ctx->d_tab, ctx->d_status);
   const size_t sh = (size_t)(2 * L.NM + 8 * (L.NM - 1) + 18 * L.NM + 32 + romberg_scratch<4, 1>()) *
                     sizeof(double);
   hipLaunchKernelGGL(k_mass_setup, dim3((unsigned)n), dim3(256), sh, ctx->stream, ctx->cfg, L,
@@ -468,57 +607,26 @@ int chomp_halo_setup(chomp_ctx* ctx, const chomp_halo_par* profile,
   hipLaunchKernelGGL(k_halo_nodes, dim3((kNodeCount + 255) / 256 + 1, (unsigned)n, ng), dim3(256),
                      sh, ctx->stream, ctx->cfg, L, ctx->d_epochs, ctx->d_tab, ctx->d_profile,
                      ctx->d_hod, ctx->d_sici, ctx->d_nodes, ctx->d_tab, groups[0], groups[1],
-                     groups[2]);
+                     groups[2], ctx->d_status);
   if (groups[0] != 3)
   hipLaunchKernelGGL(k_halo_knots, dim3(L.NK, (unsigned)n, ng), dim3(64 * kKnotNW), 0, ctx->stream,
                      ctx->cfg, L, ctx->d_tab, ctx->d_sici, ctx->d_nodes, groups[0], groups[1],
-                     groups[2], kmask, ctx->d_pending);
+                     groups[2], kmask, ctx->d_pending, ctx->d_status);
   if (ctx->cfg.divmax > kNodeLevel && groups[0] != 3) {
     // blocks draw knots from the list k_halo_knots left: enough of them to fill the chip
     // when the list is long, cheap to launch when it is empty
     unsigned gd = (unsigned)(L.NK * n * ng);
     if (gd > 2048) gd = 2048;
-    const bool hod_groups = groups[0] > 0 || groups[1] > 0 || groups[2] > 0;
-    if (n * ng <= 4 && hod_groups) {   // (on a long list -- C3 -- one block per knot is faster: 20.8 vs 28.9 ms)
-      // few epochs, HOD integrands (the ones that run to 2^18..2^20 nodes): every level of
-      // the listed knots is spread over the whole grid -- head, then (level, advance) per
-      // level; finished knots cost a flag test, an empty list one load per block
-      const int top = ctx->cfg.divmax;
-      const size_t items = (size_t)L.NK * n * ng;
-      const int pstride = top > kDeepHead ? (int)(((size_t)1 << (top - 1)) / kDeepChunk) : 1;
-      const int rcd = ensure(ctx, &ctx->d_deep, &ctx->cap_deep,
-                             items * ((size_t)kDeepState + 2 * (size_t)pstride));
-      if (rcd) return rcd;
-      double* d_state = ctx->d_deep;
-      double* d_part = ctx->d_deep + items * kDeepState;
-      const size_t shw = (size_t)(L.NM + 8 * (L.NM - 1) + romberg_scratch<4, 2>()) * sizeof(double);
-      hipLaunchKernelGGL(k_halo_deep_head, dim3((unsigned)items), dim3(256), shw, ctx->stream,
-                         ctx->cfg, L, ctx->d_epochs, ctx->d_tab, ctx->d_profile, ctx->d_hod,
-                         ctx->d_sici, groups[0], groups[1], groups[2], kmask, (int)n,
-                         ctx->d_pending, d_state);
-      for (int lev = kDeepHead + 1; lev <= top; ++lev) {
-        hipLaunchKernelGGL(k_halo_deep_level, dim3(1024), dim3(256), shw, ctx->stream, ctx->cfg,
-                           L, ctx->d_epochs, ctx->d_tab, ctx->d_profile, ctx->d_hod, ctx->d_sici,
-                           groups[0], groups[1], groups[2], kmask, (int)n, ctx->d_pending,
-                           d_state, d_part, pstride, lev);
-        hipLaunchKernelGGL(k_halo_deep_advance, dim3((unsigned)((items + 3) / 4)), dim3(256), 0,
-                           ctx->stream, ctx->cfg, L, ctx->d_tab, groups[0], groups[1], groups[2],
-                           kmask, (int)n, ctx->d_pending, d_state, d_part, pstride, lev);
-      }
-    } else if (n * ng <= 4) {      // few epochs: wide groups, the deep knots set the duration
-      const size_t shw = (size_t)(L.NM + 8 * (L.NM - 1) + romberg_scratch<8, 2>()) * sizeof(double);
-      hipLaunchKernelGGL(k_halo_knots_deep<8>, dim3(gd), dim3(512), shw, ctx->stream, ctx->cfg,
-                         L, ctx->d_epochs, ctx->d_tab, ctx->d_profile, ctx->d_hod, ctx->d_sici,
-                         groups[0], groups[1], groups[2], kmask, (int)n, ctx->d_pending);
-    } else {
-      hipLaunchKernelGGL(k_halo_knots_deep<4>, dim3(gd), dim3(256), sh, ctx->stream, ctx->cfg, L,
-                         ctx->d_epochs, ctx->d_tab, ctx->d_profile, ctx->d_hod, ctx->d_sici,
-                         groups[0], groups[1], groups[2], kmask, (int)n, ctx->d_pending);
-    }
+    hipLaunchKernelGGL(k_halo_knots_fast<kDeepCoarse>, dim3(gd), dim3(256),
+                       deep_fast_lds<kDeepCoarse>(L.NM), ctx->stream, ctx->cfg, L, ctx->d_epochs,
+                       ctx->d_tab, ctx->d_profile, ctx->d_hod, ctx->d_sici, groups[0], groups[1],
+                       groups[2], kmask, (int)n, ctx->d_pending, ctx->d_status, ctx->d_deepw,
+                       ctx->tune[CHOMP_TUNE_DEEP_LITERAL] > 0 ? 1 : 0, ctx->d_deepstat);
   }
   const size_t sh2 = (size_t)(51 * L.NK) * sizeof(double);
   hipLaunchKernelGGL(k_halo_finalize, dim3((unsigned)n), dim3(384), sh2, ctx->stream, ctx->cfg,
-                     L, ctx->d_epochs, ctx->d_tab, ctx->d_profile, ctx->d_hod, fam, ctx->d_pending);
+                     L, ctx->d_epochs, ctx->d_tab, ctx->d_profile, ctx->d_hod, fam, ctx->d_pending,
+                     ctx->d_status);
   HIPCHK(hipGetLastError());
   ctx->have_halo = true;
   ctx->fam_mask |= fam;
@@ -610,8 +718,15 @@ int chomp_power_range(chomp_ctx* ctx, int which, size_t epoch0, size_t n, const 
     if (rc) return rc;
     rc = ensure(ctx, &ctx->d_stage_out, &ctx->cap_out, nk * n);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(ctx->d_stage_in, k, nk * sizeof(double), hipMemcpyHostToDevice,
-                          ctx->stream));
+    // through pinned mirrors: a pageable buffer would be staged by the runtime in small
+    // synchronous pieces
+    rc = ensure_host(ctx, &ctx->h_stage_in, &ctx->cap_hin, nk);
+    if (rc) return rc;
+    rc = ensure_host(ctx, &ctx->h_stage_out, &ctx->cap_hout, nk * n);
+    if (rc) return rc;
+    std::memcpy(ctx->h_stage_in, k, nk * sizeof(double));
+    HIPCHK(hipMemcpyAsync(ctx->d_stage_in, ctx->h_stage_in, nk * sizeof(double),
+                          hipMemcpyHostToDevice, ctx->stream));
     dk = ctx->d_stage_in;
     dout = ctx->d_stage_out;
   }
@@ -631,9 +746,7 @@ int chomp_power_range(chomp_ctx* ctx, int which, size_t epoch0, size_t n, const 
     // parity for ever and run its counter past the list, so under capture the call clears both
     // counters itself (a memset node) and keeps the bit still.
     int parity = ctx->slow_parity;
-    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
-    HIPCHK(hipStreamIsCapturing(ctx->stream, &capture));
-    if (capture == hipStreamCaptureStatusActive) ctx->slow_by_memset = true;
+    if (capturing(ctx)) ctx->slow_by_memset = true;
     if (ctx->slow_by_memset) {       // (sticky: a graph may be replayed between any two calls)
       HIPCHK(hipMemsetAsync(ctx->d_slow, 0, 2 * sizeof(int), ctx->stream));
       parity = 0;
@@ -644,8 +757,8 @@ int chomp_power_range(chomp_ctx* ctx, int which, size_t epoch0, size_t n, const 
     for (size_t i = 1; i < n; ++i) one_cosmology &= ctx->slot[epoch0 + i] == ctx->slot[epoch0];
     const int w = which & 15;
     size_t stream_min = (size_t)1 << 22;           // samples; below this the launches dominate
-    // (test hook: tests/test_gpu_properties.py forces either launch shape on small grids)
-    if (const char* ev = getenv("CHOMP_E_STREAM_MIN")) stream_min = (size_t)atoll(ev);
+    // (chomp_set_tuning: the tests force either launch shape on small grids)
+    if (ctx->tune[CHOMP_TUNE_E_STREAM_MIN] >= 0) stream_min = (size_t)ctx->tune[CHOMP_TUNE_E_STREAM_MIN];
     if (one_cosmology && w != CHOMP_P_LIN && nk % 2 == 0 && nk * n >= stream_min) {
       const unsigned gx8 = (gx + 7) / 8 * 8;
       rc = ensure(ctx, &ctx->d_winfo, &ctx->cap_winfo, (size_t)gx8 * 4);
@@ -665,8 +778,11 @@ int chomp_power_range(chomp_ctx* ctx, int which, size_t epoch0, size_t n, const 
                            ctx->d_slow, parity);
       if (timed) HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
       int per = n % 2 == 0 ? 2 : 1;
-      // (tuning hook: rows per block of the streaming kernel; 2 measured best on MI355X)
-      if (const char* ev = getenv("CHOMP_E_PER")) { int v = atoi(ev); if ((v == 1 || v == 2 || v == 4) && n % v == 0) per = v; }
+      // (chomp_set_tuning: rows per block of the streaming kernel; 2 measured best on MI355X)
+      {
+        const long long v = ctx->tune[CHOMP_TUNE_E_ROWS];
+        if ((v == 1 || v == 2 || v == 4) && n % (size_t)v == 0) per = (int)v;
+      }
       const unsigned gy = (unsigned)(n / per);
 #define CHOMP_STREAM(P)                                                                   \
       hipLaunchKernelGGL(k_power_stream<P>, dim3(gx8, gy), dim3(256), 0, ctx->stream, L,  \
@@ -719,9 +835,10 @@ int chomp_power_range(chomp_ctx* ctx, int which, size_t epoch0, size_t n, const 
   }
   HIPCHK(hipGetLastError());
   if (mem == CHOMP_HOST) {
-    HIPCHK(hipMemcpyAsync(out, dout, nk * n * sizeof(double), hipMemcpyDeviceToHost,
+    HIPCHK(hipMemcpyAsync(ctx->h_stage_out, dout, nk * n * sizeof(double), hipMemcpyDeviceToHost,
                           ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    std::memcpy(out, ctx->h_stage_out, nk * n * sizeof(double));
   }
   return CHOMP_OK;
 }
@@ -865,18 +982,27 @@ int chomp_get_table(chomp_ctx* ctx, size_t epoch, int table, double* out, size_t
   const TabLayout& L = ctx->L;
   int off = -1;
   size_t len = 0;
+  unsigned need = 0;                 // knot family that must have been built
+  bool need_hf = false;
   switch (table) {
     case CHOMP_TAB_LN_MASS: off = L.off_ln_mass; len = L.NM; break;
     case CHOMP_TAB_NU: off = L.off_nu; len = L.NM; break;
-    case CHOMP_TAB_H_M: off = L.off_knot[F_HM]; len = L.NK; break;
-    case CHOMP_TAB_PP_MM: off = L.off_knot[F_PPMM]; len = L.NK; break;
-    case CHOMP_TAB_H_G: off = L.off_knot[F_HG]; len = L.NK; break;
-    case CHOMP_TAB_PP_GM: off = L.off_knot[F_PPGM]; len = L.NK; break;
-    case CHOMP_TAB_PP_GG: off = L.off_knot[F_PPGG]; len = L.NK; break;
-    case CHOMP_TAB_LEVELS: off = L.off_levels; len = 5 * (size_t)L.NK; break;
-    case CHOMP_TAB_HF_LN_SIGMA2: off = L.off_hf_lns2; len = L.NK; break;
+    case CHOMP_TAB_H_M: off = L.off_knot[F_HM]; len = L.NK; need = 1u << F_HM; break;
+    case CHOMP_TAB_PP_MM: off = L.off_knot[F_PPMM]; len = L.NK; need = 1u << F_PPMM; break;
+    case CHOMP_TAB_H_G: off = L.off_knot[F_HG]; len = L.NK; need = 1u << F_HG; break;
+    case CHOMP_TAB_PP_GM: off = L.off_knot[F_PPGM]; len = L.NK; need = 1u << F_PPGM; break;
+    case CHOMP_TAB_PP_GG: off = L.off_knot[F_PPGG]; len = L.NK; need = 1u << F_PPGG; break;
+    case CHOMP_TAB_LEVELS:
+      off = L.off_levels; len = 5 * (size_t)L.NK;
+      if (!ctx->fam_mask) return fail(ctx, CHOMP_ERR_STATE, "get_table: no knot table built yet");
+      break;
+    case CHOMP_TAB_HF_LN_SIGMA2: off = L.off_hf_lns2; len = L.NK; need_hf = true; break;
     default: return fail(ctx, CHOMP_ERR_ARG, "get_table: unknown table");
   }
+  if ((ctx->fam_mask & need) != need)
+    return fail(ctx, CHOMP_ERR_STATE, "get_table: this knot table was not built (chomp_halo_setup)");
+  if (need_hf && !ctx->have_halofit[epoch])
+    return fail(ctx, CHOMP_ERR_STATE, "get_table: chomp_halofit_setup not called for this epoch");
   if (n != len) return fail(ctx, CHOMP_ERR_ARG, "get_table: length mismatch");
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipStreamSynchronize(ctx->stream));

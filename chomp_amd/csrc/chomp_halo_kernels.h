@@ -177,13 +177,16 @@ __global__ __launch_bounds__(256) void k_halo_nodes(
     chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs,
     const double* __restrict__ tab, const chomp_halo_par* __restrict__ profile,
     const HodDev* __restrict__ hod, const SiCiTab* __restrict__ sici_g,
-    double* __restrict__ nodes, double* __restrict__ tab_out, int g0, int g1, int g2) {
+    double* __restrict__ nodes, double* __restrict__ tab_out, int g0, int g1, int g2,
+    unsigned* __restrict__ status) {
   extern __shared__ __align__(16) double sm[];
   __shared__ Epoch E;
   __shared__ SiCiTab S;
   const int e = blockIdx.y;
   const int group = blockIdx.z == 0 ? g0 : (blockIdx.z == 1 ? g1 : g2);
   const bool nbar_block = blockIdx.x == gridDim.x - 1;
+  // a new build of the knot tables: forget what the previous one reported
+  if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0) atomicAnd(&status[e], ~kStHaloBits);
   if (nbar_block && blockIdx.z != 0) return;
   if (!nbar_block && (group < 0 || group > 2)) return;
   HaloLds H;
@@ -308,7 +311,7 @@ constexpr int kKnotNW = 2;
 __global__ __launch_bounds__(64 * kKnotNW) void k_halo_knots(
     chomp_config cfg, TabLayout L, double* __restrict__ tab,
     const SiCiTab* __restrict__ sici_g, const double* __restrict__ nodes, int g0, int g1,
-    int g2, unsigned mask, int* __restrict__ pending) {
+    int g2, unsigned mask, int* __restrict__ pending, unsigned* __restrict__ status) {
   __shared__ SiCiTab S;
   __shared__ double red[kKnotScratch];
   const int NK = L.NK;
@@ -341,311 +344,460 @@ __global__ __launch_bounds__(64 * kKnotNW) void k_halo_knots(
       lev[fb * NK + ik] = (!r.converged[1] && more) ? kPendingLevel : (double)r.level[1];
       any = any || (!r.converged[1] && more);
     }
+    // divmax within the node tables: scipy returns the last row with an AccuracyWarning
+    if (!more) {
+      unsigned st = 0u;
+      if (group != 2 && (mask & (1u << fa)) && !r.converged[0]) st |= kStHaloDivmax0 << fa;
+      if ((mask & (1u << fb)) && !r.converged[1]) st |= kStHaloDivmax0 << fb;
+      if (st) atomicOr(&status[e], st);
+    }
     // work list of k_halo_knots_deep: [0] items, [1] next item to hand out, [2...] items
     if (any) pending[2 + atomicAdd(&pending[0], 1)] = (int)((blockIdx.z * gridDim.y + e) * NK + ik);
   }
 }
 
 // ---------------------------------------------------------------------------
-// k_halo_knots_deep: the knots k_halo_knots listed as not converged at the depth of the
-// node tables, redone by direct evaluation up to divmax (the discontinuous HOD integrands
-// run to 2^18..2^20 nodes, halo.py:1038-1041, 1084-1086).  1-D grid of any size; blocks
-// draw items from the list until it is empty (an empty list costs one load per block).
-// k_halo_finalize clears the list.
+// The knots k_halo_knots listed as not converged at the depth of the node tables.  The
+// discontinuous HOD integrands (halo.py:1038-1041, 1084-1086) make the reference's Romberg
+// run to 2^18..2^20 nodes or exhaust divmax, and the value it stops at is part of the answer
+// (DESIGN.md section 2), so scipy's rows and stopping test are kept.  What is NOT kept is the
+// evaluation of every node:
+//
+// k_halo_knots_fast.  A Romberg level only enters through the SUM of the integrand over
+// its 2^(L-1) new mid-points.  Away from a handful of break points -- the jump where <N> or
+// <N(N-1)> crosses 1, the kink where the satellites switch on at M_0, a step-function central
+// occupation -- the integrand is a smooth function of ln nu, sampled by the level-LC grid
+// (2^LC + 1 points, one evaluation each) far more finely than it varies.  On every coarse
+// interval the new nodes of a deeper level are therefore read off the degree-7 Lagrange
+// interpolant through 8 neighbouring coarse samples, and since the level only needs their
+// sum, the interpolant is never evaluated: sum_r p(t_r) = sum_m W_m f_(i+m) with weights
+// W_m = sum_r l_m(t_r) that depend on the level alone (tabulated by deep_weights_host).
+// Coarse intervals that contain a break point (the discrete state of the integrand differs
+// at their ends) are evaluated node by node, with scipy's node formula, so that every node
+// falls on the same side of a discontinuity as in the reference; stencils never reach across
+// such an interval (they shift towards the interior of their smooth segment instead).
+// A level of 2^19 nodes then costs ~16 k multiply-adds and <= ~2 k evaluations.
+// The scheme checks itself: every odd coarse sample is predicted from its even neighbours
+// (the same interpolation at twice the spacing, whose error is 2^8 times larger); if that
+// says the level sums could be off by more than kDeepTol relative, or if there are more
+// break points than expected, the block falls back to the literal evaluation.
 // ---------------------------------------------------------------------------
-// NW wavefronts per integral: 4 when the list can be long (a batch of epochs keeps the chip
-// busy with one block per knot), 8 for a single epoch (at most 150 knots: the deep
-// integrals set the duration; 16 would cap the registers at 128 and spill).
+constexpr int kDeepCoarse = 11;                            // LC: 2049 coarse samples per knot
+constexpr int kDeepStencil = 8;
+constexpr int kDeepOffsets = kDeepStencil - 1;             // interval o..o+1 of the stencil
+constexpr int kDeepWStride = kDeepOffsets * kDeepStencil;  // weights per level
+constexpr int kDeepMaxRough = 8;                           // break-point intervals
+constexpr int kDeepMaxFine = 64;                           // node-by-node intervals
+constexpr int kDeepKinkMargin = 16;                        // extra ones above M_0 (see kernel)
+constexpr double kDeepTol = 1e-9;
+
+// W[L - LC - 1][o][m] = sum_(r < n) l_m(o + (r + 1/2) / n), n = 2^(L - 1 - LC), with l_m the
+// Lagrange basis polynomial on the stencil nodes 0..7.  Host, once per context.
+inline void deep_weights_host(int LC, int top, double* w) {
+  for (int L = LC + 1; L <= top; ++L) {
+    const long n = 1L << (L - 1 - LC);
+    double* wl = w + (size_t)(L - LC - 1) * kDeepWStride;
+    for (int o = 0; o < kDeepOffsets; ++o)
+      for (int m = 0; m < kDeepStencil; ++m) {
+        long double den = 1.0L;
+        for (int j = 0; j < kDeepStencil; ++j)
+          if (j != m) den *= (long double)(m - j);
+        long double sum = 0.0L, comp = 0.0L;       // Kahan in long double
+        for (long r = 0; r < n; ++r) {
+          const long double t = (long double)o + ((long double)r + 0.5L) / (long double)n;
+          long double num = 1.0L;
+          for (int j = 0; j < kDeepStencil; ++j)
+            if (j != m) num *= t - (long double)j;
+          const long double y = num / den - comp;
+          const long double s2 = sum + y;
+          comp = (s2 - sum) - y;
+          sum = s2;
+        }
+        wl[o * kDeepStencil + m] = (double)sum;
+      }
+  }
+}
+
+// One node of a knot's integrand pair together with the discrete state of the integrand
+// there (which branch of every `if` of halo.py:1038-1041, 1084-1086 and hod.py:189-230 is
+// taken): the integrand is smooth wherever the state does not change.  Same arithmetic as
+// IntegrandMM / GM / GG; group 2 has one integrand (out[0] = 0).
+__device__ __forceinline__ void halo_eval_coded(int group, const HaloCtx& c, double ln_nu,
+                                                double (&out)[2], int* code) {
+  const Epoch& E = *c.e;
+  const double nu = exp(ln_nu);
+  const double lnm = spline_eval(c.nu_knots, c.lnm_pp, c.NM, nu);
+  const double y = y_nfw(E, *c.sici, c.ln_k, lnm);
+  double nf, b = 0.0;
+  mf_node(E, nu, ln_nu, group != 2, &nf, &b);
+  if (group == 0) {
+    out[0] = nf * b * y * c.window(lnm);
+    out[1] = nf * exp(lnm) * y * y;
+    *code = 0;
+    return;
+  }
+  const double mass = exp(lnm);
+  double n1, n2;
+  zheng_node(E, mass, lnm, &n1, &n2);
+  int st = (mass - E.hod_M0 > 0.0) ? 2 : 0;                    // satellites on
+  if (E.hod_sigma <= 0.0 && lnm * 0.43429448190325182765 > E.hod_log_M_min) st |= 4;
+  if (group == 1) {
+    out[0] = nf * b * y * n1 / mass * c.window(lnm);
+    out[1] = (n1 < 1.0) ? nf * n1 * y : nf * n1 * y * y;
+    st |= (n1 < 1.0) ? 1 : 0;
+  } else {
+    out[0] = 0.0;
+    out[1] = (n2 < 1.0) ? nf * n2 * y / mass : nf * n2 * y * y / mass;
+    st |= (n2 < 1.0) ? 1 : 0;
+  }
+  *code = st;
+}
+
+// scipy.integrate.romberg's rows and stopping test on level sums (the replay of
+// chomp_romberg.h): every lane of every wavefront holds the same state.
+struct RombergRows2 {
+  double ordsum[2], Tl[2], prev[2], value[2], range, n, tol, rtol;
+  int level[2];
+  bool done[2];
+  __device__ __forceinline__ void start(double range_, double tol_, double rtol_, double s0,
+                                        double s1, bool want0, bool want1) {
+    range = range_; tol = tol_; rtol = rtol_; n = 1.0;
+    const int lane = threadIdx.x & 63;
+    const double s[2] = {s0, s1};
+    const bool want[2] = {want0, want1};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      ordsum[q] = s[q];
+      value[q] = range * s[q];
+      prev[q] = value[q];
+      Tl[q] = lane == 0 ? value[q] : 0.0;
+      level[q] = 0;
+      done[q] = !want[q];
+    }
+  }
+  __device__ __forceinline__ bool all_done() const { return done[0] && done[1]; }
+  // level i with the sums of its new nodes
+  __device__ __forceinline__ void advance(int i, double s0, double s1) {
+    const int lane = threadIdx.x & 63;
+    const double c_il = CHOMP_ROMBERG_C[i][lane & 31];
+    n *= 2.0;
+    const double s[2] = {s0, s1};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (done[q]) continue;                                   // block-uniform
+      ordsum[q] += s[q];
+      const double Ti = range * ordsum[q] / n;
+      if (lane == i) Tl[q] = Ti;
+      const double cur = wave_sum(lane < 32 ? c_il * Tl[q] : 0.0);
+      const double err = fabs(cur - prev[q]);
+      prev[q] = cur;
+      value[q] = cur;
+      level[q] = i;
+      if (err < tol || err < rtol * fabs(cur)) done[q] = true;
+    }
+  }
+};
+
+// Literal evaluation of one listed knot (every Romberg node): the checker of the fast path
+// and its fallback.  Whole block (64 NW threads); E, S, H staged by the caller.
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void k_halo_knots_deep(
-    chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs,
-    double* __restrict__ tab, const chomp_halo_par* __restrict__ profile,
-    const HodDev* __restrict__ hod, const SiCiTab* __restrict__ sici_g, int g0, int g1,
-    int g2, unsigned mask, int n_epoch, int* __restrict__ pending) {
-  extern __shared__ __align__(16) double sm[];
-  __shared__ Epoch E;
-  __shared__ SiCiTab S;
-  __shared__ int item_sh;
-  const int NK = L.NK;
-  const int count = pending[0];
-  if (count == 0) return;          // nothing listed: no traffic on the queue head
-  for (;;) {
-  __syncthreads();                 // (previous item done with E, S, sm)
-  if (threadIdx.x == 0) item_sh = atomicAdd(&pending[1], 1);
-  __syncthreads();
-  if (item_sh >= count) return;    // block-uniform
-  const int item = pending[2 + item_sh];
-  const int ik = item % NK, e = (item / NK) % n_epoch, zg = item / (NK * n_epoch);
-  const int group = zg == 0 ? g0 : (zg == 1 ? g1 : g2);
-  if (group < 0 || group > 2) continue;
-  double* t = tab + (size_t)e * L.stride;
-  double* lev = t + L.off_levels;
-  const int fa = group_fa(group), fb = group_fb(group);
-  const bool pa = group != 2 && (mask & (1u << fa)) && lev[fa * NK + ik] == kPendingLevel;
-  const bool pb = (mask & (1u << fb)) && lev[fb * NK + ik] == kPendingLevel;
-  if (!pa && !pb) continue;
-  HaloLds H;
-  H.stage(L, E, S, epochs, e, t, profile, hod, sici_g, sm);
-  double* red = H.rest;
+__device__ __forceinline__ void deep_literal(const chomp_config& cfg, const HaloCtx& c,
+                                             const Epoch& E, int group, bool pa, double* red,
+                                             double (&val)[2], int (&lev)[2], bool (&conv)[2]) {
   const double ln_nu_max = log(E.nu_max);
-  HaloCtx c{&E, &S, H.nu_knots, H.lnm_pp, L.NM,
-            linspace_at(log(cfg.k_min), log(cfg.k_max), NK, ik), (mask & kMaskExclusion) != 0};
-  double va = 0.0, vb = 0.0;
-  int la = 0, lb = 0;
+  val[0] = val[1] = 0.0; lev[0] = lev[1] = 0; conv[0] = conv[1] = true;
   if (group == 0) {
     IntegrandMM f{c};
     const RombergOut<2> r = romberg_group<NW, 2>(f, group_lower(E, 0), ln_nu_max,
                                                 cfg.global_precision, cfg.halo_precision,
                                                 cfg.divmax, red);
-    va = r.value[0]; vb = r.value[1]; la = r.level[0]; lb = r.level[1];
+    val[0] = r.value[0]; val[1] = r.value[1]; lev[0] = r.level[0]; lev[1] = r.level[1];
+    conv[0] = r.converged[0]; conv[1] = r.converged[1];
   } else if (group == 1) {
     IntegrandGM f{c, pa};
     const RombergOut<2> r = romberg_group<NW, 2>(f, group_lower(E, 1), ln_nu_max,
                                                 cfg.global_precision, cfg.halo_precision,
                                                 cfg.divmax, red);
-    va = r.value[0]; vb = r.value[1]; la = r.level[0]; lb = r.level[1];
+    val[0] = r.value[0]; val[1] = r.value[1]; lev[0] = r.level[0]; lev[1] = r.level[1];
+    conv[0] = r.converged[0]; conv[1] = r.converged[1];
   } else {
     IntegrandGG f{c};
     const RombergOut<1> r = romberg_group<NW, 1>(f, group_lower(E, 2), ln_nu_max,
                                                 cfg.global_precision, cfg.halo_precision,
                                                 cfg.divmax, red);
-    vb = r.value[0]; lb = r.level[0];
-  }
-  if (threadIdx.x == 0) {
-    if (pa) { t[L.off_knot[fa] + ik] = va; lev[fa * NK + ik] = (double)la; }
-    if (pb) { t[L.off_knot[fb] + ik] = vb; lev[fb * NK + ik] = (double)lb; }
-  }
-  }   // next item
-}
-
-// ---------------------------------------------------------------------------
-// The deep knots of a FEW epochs (a single Halo object: at most 150 knots): with one block
-// per knot the handful of integrals that run to 2^20 nodes would set the duration on a
-// mostly idle chip, so each Romberg level is spread over the whole grid instead.
-//   k_halo_deep_head     one block per listed knot: levels <= kDeepHead by direct
-//                        evaluation; knots that stop there are final, the others leave
-//                        their Romberg state (chomp_romberg.h `dump`) in `state`
-//   k_halo_deep_level    level i: the 2^(i-1) new nodes of every unfinished knot in chunks
-//                        of kDeepChunk nodes over all blocks; partial sums per chunk
-//   k_halo_deep_advance  level i: one wavefront per knot adds the chunk sums in order and
-//                        does the row / stopping test of scipy.integrate.romberg
-// The host queues head, then (level, advance) for every level up to divmax; finished knots
-// cost a flag test.  Same nodes, same rows and stopping rule as k_halo_knots_deep -- only
-// the order in which a level's node values are added differs.
-// ---------------------------------------------------------------------------
-constexpr int kDeepHead = 11;                 // levels of the head pass (2049 nodes)
-constexpr int kDeepChunk = 2048;              // nodes per work item of a level pass
-// per knot: 2 x kRombergDump state, a, b, done[2], level[2], value[2]
-constexpr int kDeepState = 2 * kRombergDump + 8;
-constexpr int kDsA = 2 * kRombergDump, kDsB = kDsA + 1, kDsDone = kDsA + 2, kDsLevel = kDsA + 4,
-              kDsValue = kDsA + 6;
-
-struct DeepItem {
-  int ik, e, group, fa, fb;
-  bool pa, pb;
-};
-__device__ __forceinline__ DeepItem deep_item(const TabLayout& L, const int* pending, int p,
-                                              int n_epoch, int g0, int g1, int g2,
-                                              unsigned mask, const double* tab) {
-  DeepItem d;
-  const int item = pending[2 + p], NK = L.NK;
-  d.ik = item % NK;
-  d.e = (item / NK) % n_epoch;
-  const int zg = item / (NK * n_epoch);
-  d.group = zg == 0 ? g0 : (zg == 1 ? g1 : g2);
-  d.fa = group_fa(d.group);
-  d.fb = group_fb(d.group);
-  const double* lev = tab + (size_t)d.e * L.stride + L.off_levels;
-  d.pa = d.group != 2 && (mask & (1u << d.fa)) && lev[d.fa * NK + d.ik] == kPendingLevel;
-  d.pb = (mask & (1u << d.fb)) && lev[d.fb * NK + d.ik] == kPendingLevel;
-  return d;
-}
-
-// One node of a knot's integrand pair (group 2 has one integrand: out[0] = 0).
-__device__ __forceinline__ void deep_eval(int group, const HaloCtx& c, bool pa, double x,
-                                          double (&out)[2]) {
-  if (group == 0) {
-    IntegrandMM f{c};
-    f(x, out);
-  } else if (group == 1) {
-    IntegrandGM f{c, pa};
-    f(x, out);
-  } else {
-    IntegrandGG f{c};
-    double o1[1];
-    f(x, o1);
-    out[0] = 0.0;
-    out[1] = o1[0];
+    val[1] = r.value[0]; lev[1] = r.level[0]; conv[1] = r.converged[0];
   }
 }
 
-// grid any (blocks stride over the list), block 256.
-__global__ __launch_bounds__(256) void k_halo_deep_head(
+// x of coarse node q of the level-LC grid over [a, b], by scipy's formula for the level the
+// node first appears in (so a coarse sample is the value the literal evaluation sees).
+template <int LC>
+__device__ __forceinline__ double deep_coarse_x(double a, double b, int q) {
+  constexpr int NC = 1 << LC;
+  if (q == 0) return a;
+  if (q == NC) return b;
+  const int tz = __builtin_ctz((unsigned)q);
+  const int lev = LC - tz;
+  const long j = (long)(((q >> tz) - 1) >> 1);
+  const double h = (b - a) / (double)(1L << (lev - 1));
+  return (a + 0.5 * h) + h * (double)j;
+}
+
+// Dynamic LDS of k_halo_knots_fast (bytes).
+template <int LC>
+inline size_t deep_fast_lds(int NM) {
+  constexpr int NC = 1 << LC;
+  return (size_t)(NM + 8 * (NM - 1) + kKnotScratch + 2 * (NC + 1) + kDeepWStride) * sizeof(double) +
+         (size_t)((NC + 1 + 15) & ~15);
+}
+
+// grid any (blocks draw knots from the list k_halo_knots left; an empty list costs one load
+// per block), block 256.  deepw: deep_weights_host(LC, divmax).  force_literal: evaluate
+// every node (chomp_set_tuning CHOMP_TUNE_DEEP_LITERAL: the checker).  stats (optional):
+// [0] knots done by the fast path, [1] by the literal one; why literal: [2] too many break
+// points, [3] too many node-by-node intervals, [4] self-check; [5] largest self-check
+// estimate seen (float bits).
+template <int LC>
+__global__ __launch_bounds__(256) void k_halo_knots_fast(
     chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs, double* __restrict__ tab,
     const chomp_halo_par* __restrict__ profile, const HodDev* __restrict__ hod,
     const SiCiTab* __restrict__ sici_g, int g0, int g1, int g2, unsigned mask, int n_epoch,
-    const int* __restrict__ pending, double* __restrict__ state) {
+    int* __restrict__ pending, unsigned* __restrict__ status, const double* __restrict__ deepw,
+    int force_literal, int* __restrict__ stats) {
+  constexpr int NC = 1 << LC;
   extern __shared__ __align__(16) double sm[];
   __shared__ Epoch E;
   __shared__ SiCiTab S;
+  __shared__ int item_sh, n_rough_sh, n_fine_sh, n_seg_sh;
+  __shared__ int rough_sh[kDeepMaxRough], fine_sh[kDeepMaxFine];
+  __shared__ int seg_lo[kDeepMaxRough + 1], seg_hi[kDeepMaxRough + 1];
   const int NK = L.NK;
   const int count = pending[0];
-  for (int p = blockIdx.x; p < count; p += gridDim.x) {
-    __syncthreads();               // (previous knot done with E, S, sm)
-    const DeepItem d = deep_item(L, pending, p, n_epoch, g0, g1, g2, mask, tab);
-    double* st = state + (size_t)p * kDeepState;
-    if (d.group < 0 || d.group > 2 || (!d.pa && !d.pb)) {
-      if (threadIdx.x == 0) { st[kDsDone] = 1.0; st[kDsDone + 1] = 1.0; }
-      continue;
-    }
-    double* t = tab + (size_t)d.e * L.stride;
+  if (count == 0) return;          // nothing listed: no traffic on the queue head
+  const int tid = threadIdx.x;
+  for (;;) {
+    __syncthreads();               // (previous item done with E, S, sm)
+    if (tid == 0) item_sh = atomicAdd(&pending[1], 1);
+    __syncthreads();
+    if (item_sh >= count) return;  // block-uniform
+    const int item = pending[2 + item_sh];
+    const int ik = item % NK, e = (item / NK) % n_epoch, zg = item / (NK * n_epoch);
+    const int group = zg == 0 ? g0 : (zg == 1 ? g1 : g2);
+    if (group < 0 || group > 2) continue;
+    double* t = tab + (size_t)e * L.stride;
+    double* levs = t + L.off_levels;
+    const int fa = group_fa(group), fb = group_fb(group);
+    const bool pa = group != 2 && (mask & (1u << fa)) && levs[fa * NK + ik] == kPendingLevel;
+    const bool pb = (mask & (1u << fb)) && levs[fb * NK + ik] == kPendingLevel;
+    if (!pa && !pb) continue;
     HaloLds H;
-    H.stage(L, E, S, epochs, d.e, t, profile, hod, sici_g, sm);
+    H.stage(L, E, S, epochs, e, t, profile, hod, sici_g, sm);
     double* red = H.rest;
-    const double a = group_lower(E, d.group), b = log(E.nu_max);
+    double* F0 = red + kKnotScratch;
+    double* F1 = F0 + (NC + 1);
+    double* W = F1 + (NC + 1);
+    unsigned char* code = reinterpret_cast<unsigned char*>(W + kDeepWStride);
+    const double a = group_lower(E, group), b = log(E.nu_max);
     HaloCtx c{&E, &S, H.nu_knots, H.lnm_pp, L.NM,
-              linspace_at(log(cfg.k_min), log(cfg.k_max), NK, d.ik), (mask & kMaskExclusion) != 0};
-    const int top = cfg.divmax < kDeepHead ? cfg.divmax : kDeepHead;
-    double va, vb;
-    int la, lb;
-    bool ca, cb;
-    if (d.group == 0) {
-      IntegrandMM f{c};
-      const RombergOut<2> r = romberg_group<4, 2>(f, a, b, cfg.global_precision,
-                                                  cfg.halo_precision, top, red, st);
-      va = r.value[0]; vb = r.value[1]; la = r.level[0]; lb = r.level[1];
-      ca = r.converged[0]; cb = r.converged[1];
-    } else if (d.group == 1) {
-      IntegrandGM f{c, d.pa};
-      const RombergOut<2> r = romberg_group<4, 2>(f, a, b, cfg.global_precision,
-                                                  cfg.halo_precision, top, red, st);
-      va = r.value[0]; vb = r.value[1]; la = r.level[0]; lb = r.level[1];
-      ca = r.converged[0]; cb = r.converged[1];
-    } else {
-      IntegrandGG f{c};
-      const RombergOut<1> r = romberg_group<4, 1>(f, a, b, cfg.global_precision,
-                                                  cfg.halo_precision, top, red,
-                                                  st + kRombergDump);
-      va = 0.0; vb = r.value[0]; la = 0; lb = r.level[0];
-      ca = true; cb = r.converged[0];
-    }
-    if (threadIdx.x == 0) {
-      const bool last = cfg.divmax <= kDeepHead;       // scipy returns the last row then
-      const bool fin_a = !d.pa || ca || last, fin_b = !d.pb || cb || last;
-      double* lev = t + L.off_levels;
-      if (d.pa && fin_a) { t[L.off_knot[d.fa] + d.ik] = va; lev[d.fa * NK + d.ik] = (double)la; }
-      if (d.pb && fin_b) { t[L.off_knot[d.fb] + d.ik] = vb; lev[d.fb * NK + d.ik] = (double)lb; }
-      st[kDsA] = a;
-      st[kDsB] = b;
-      st[kDsDone] = fin_a ? 1.0 : 0.0;
-      st[kDsDone + 1] = fin_b ? 1.0 : 0.0;
-    }
-  }
-}
-
-// grid any, block 256: level `lev` (> kDeepHead) of every unfinished knot.
-__global__ __launch_bounds__(256) void k_halo_deep_level(
-    chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs,
-    const double* __restrict__ tab, const chomp_halo_par* __restrict__ profile,
-    const HodDev* __restrict__ hod, const SiCiTab* __restrict__ sici_g, int g0, int g1, int g2,
-    unsigned mask, int n_epoch, const int* __restrict__ pending,
-    const double* __restrict__ state, double* __restrict__ part, int pstride, int lev) {
-  extern __shared__ __align__(16) double sm[];
-  __shared__ Epoch E;
-  __shared__ SiCiTab S;
-  const int NK = L.NK;
-  const int count = pending[0];
-  const long numtosum = 1L << (lev - 1);
-  const int nchunk = (int)(numtosum / kDeepChunk);     // lev > kDeepHead: >= 1
-  const long total = (long)count * nchunk;
-  const long per = (total + gridDim.x - 1) / gridDim.x;   // consecutive items: one knot's
-  long w = (long)blockIdx.x * per;                        // staging serves several chunks
-  const long w_end = w + per < total ? w + per : total;
-  int staged = -1;
-  HaloLds H;
-  DeepItem d;
-  int flip = 0;
-  for (; w < w_end; ++w) {
-    const int p = (int)(w / nchunk), ch = (int)(w % nchunk);
-    const double* st = state + (size_t)p * kDeepState;
-    const bool da = st[kDsDone] != 0.0, db = st[kDsDone + 1] != 0.0;
-    if (da && db) { w += nchunk - 1 - ch; continue; }   // block-uniform: skip the knot
-    if (p != staged) {
+              linspace_at(log(cfg.k_min), log(cfg.k_max), NK, ik), (mask & kMaskExclusion) != 0};
+    double val[2] = {0.0, 0.0};
+    int lev[2] = {0, 0};
+    bool conv[2] = {true, true};
+    bool literal = force_literal != 0 || cfg.divmax <= LC;
+    int flip = 0;
+    RombergRows2 R;
+    if (!literal) {
+      // ---- coarse samples
+      for (int q = tid; q <= NC; q += 256) {
+        double o[2];
+        int st;
+        halo_eval_coded(group, c, deep_coarse_x<LC>(a, b, q), o, &st);
+        F0[q] = o[0];
+        F1[q] = o[1];
+        code[q] = (unsigned char)st;
+      }
+      if (tid == 0) { n_rough_sh = 0; n_fine_sh = 0; n_seg_sh = 0; }
       __syncthreads();
-      d = deep_item(L, pending, p, n_epoch, g0, g1, g2, mask, tab);
-      H.stage(L, E, S, epochs, d.e, tab + (size_t)d.e * L.stride, profile, hod, sici_g, sm);
-      staged = p;
-      flip = 0;
-    }
-    const double a = st[kDsA], b = st[kDsB];
-    HaloCtx c{&E, &S, H.nu_knots, H.lnm_pp, L.NM,
-              linspace_at(log(cfg.k_min), log(cfg.k_max), NK, d.ik), (mask & kMaskExclusion) != 0};
-    const double h = (b - a) / (double)numtosum;
-    const double lox = a + 0.5 * h;
-    double s0 = 0.0, s1 = 0.0;
-    const long j0 = (long)ch * kDeepChunk + threadIdx.x;
-#pragma unroll 2
-    for (int i = 0; i < kDeepChunk / 256; ++i) {
-      double o[2];
-      deep_eval(d.group, c, d.pa && !da, lox + h * (double)(j0 + 256L * i), o);
-      s0 += o[0];
-      s1 += o[1];
-    }
-    const double t0 = group_sum<4>(s0, H.rest, flip);
-    const double t1 = group_sum<4>(s1, H.rest, flip);
-    if (threadIdx.x == 0) {
-      double* out = part + ((size_t)p * pstride + ch) * 2;   // pstride: chunks of level divmax
-      out[0] = t0;
-      out[1] = t1;
-    }
-  }
-}
-
-// grid ceil(max knots / 4), block 256: one wavefront per listed knot.
-__global__ __launch_bounds__(256) void k_halo_deep_advance(
-    chomp_config cfg, TabLayout L, double* __restrict__ tab, int g0, int g1, int g2,
-    unsigned mask, int n_epoch, const int* __restrict__ pending, double* __restrict__ state,
-    const double* __restrict__ part, int pstride, int lev) {
-  const int count = pending[0];
-  const int p = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
-  if (p >= count) return;
-  double* st = state + (size_t)p * kDeepState;
-  const bool done_a = st[kDsDone] != 0.0, done_b = st[kDsDone + 1] != 0.0;
-  if (done_a && done_b) return;
-  const DeepItem d = deep_item(L, pending, p, n_epoch, g0, g1, g2, mask, tab);
-  const int nchunk = (int)((1L << (lev - 1)) / kDeepChunk);
-  const double range = st[kDsB] - st[kDsA];
-  const double n = (double)(1L << lev);
-  const double c_il = CHOMP_ROMBERG_C[lev][lane & 31];
-  const bool last = lev >= cfg.divmax;
-  double* t = tab + (size_t)d.e * L.stride;
-  double* levs = t + L.off_levels;
+      // ---- levels 0..LC from the samples
+      R.start(b - a, cfg.global_precision, cfg.halo_precision, 0.5 * (F0[0] + F0[NC]),
+              0.5 * (F1[0] + F1[NC]), pa, pb);
+      for (int l = 1; l <= LC && !R.all_done(); ++l) {
+        const int stride = NC >> l, cnt = 1 << (l - 1);
+        double s0 = 0.0, s1 = 0.0;
+        for (int j = tid; j < cnt; j += 256) {
+          const int q = stride * (2 * j + 1);
+          s0 += F0[q];
+          s1 += F1[q];
+        }
+        s0 = group_sum<4>(s0, red, flip);
+        s1 = group_sum<4>(s1, red, flip);
+        R.advance(l, s0, s1);
+      }
+      if (!R.all_done()) {
+        // ---- break points: coarse intervals whose ends are in different states
+        for (int i = tid; i < NC; i += 256)
+          if (code[i] != code[i + 1]) {
+            const int at = atomicAdd(&n_rough_sh, 1);
+            if (at < kDeepMaxRough) rough_sh[at] = i;
+          }
+        __syncthreads();
+        const int nr = n_rough_sh;
+        if (nr > kDeepMaxRough) {
+          literal = true;                                      // block-uniform
+          if (stats && tid == 0) atomicAdd(&stats[2], 1);
+        } else {
+          if (tid == 0) {
+            // node-by-node intervals: the break points, and above one where the satellites
+            // switch on a margin in which (M - M_0)^alpha is still too singular to interpolate
+            int nf = 0;
+            bool over = false;
+            // (pp_gg starts AT M_0 when that lies inside the mass range, halo.py:1002-1006:
+            //  the same singular onset, with no change of state to announce it)
+            if (group == 2 && E.ln_nu_lo_second > log(E.nu_min))
+              for (int d = 0; d <= kDeepKinkMargin; ++d) fine_sh[nf++] = d;
+            for (int x = 0; x < nr; ++x) {
+              const int i = rough_sh[x];
+              const int span = ((code[i] ^ code[i + 1]) & 2) ? kDeepKinkMargin : 0;
+              for (int d = 0; d <= span && i + d < NC; ++d) {
+                if (nf < kDeepMaxFine) fine_sh[nf++] = i + d; else over = true;
+              }
+            }
+            for (int x = 1; x < nf; ++x) {                     // insertion sort
+              const int v = fine_sh[x];
+              int y = x - 1;
+              while (y >= 0 && fine_sh[y] > v) { fine_sh[y + 1] = fine_sh[y]; --y; }
+              fine_sh[y + 1] = v;
+            }
+            int nu = 0;                                        // unique
+            for (int x = 0; x < nf; ++x)
+              if (x == 0 || fine_sh[x] != fine_sh[x - 1]) fine_sh[nu++] = fine_sh[x];
+            // smooth segments between them (node ranges); one shorter than a stencil is
+            // evaluated node by node as well
+            int ns = 0, lo = 0, extra = nu;
+            for (int x = 0; x <= nu; ++x) {
+              const int hi = x < nu ? fine_sh[x] : NC;         // last node of the segment
+              if (hi - lo + 1 >= kDeepStencil) {
+                if (ns <= kDeepMaxRough) { seg_lo[ns] = lo; seg_hi[ns] = hi; ++ns; } else over = true;
+              } else {
+                for (int i = lo; i < hi; ++i) {
+                  if (extra < kDeepMaxFine) fine_sh[extra++] = i; else over = true;
+                }
+              }
+              lo = hi + 1;
+            }
+            n_fine_sh = over ? kDeepMaxFine + 1 : extra;
+            n_seg_sh = ns;
+          }
+          __syncthreads();
+          const int ns = n_seg_sh;
+          if (n_fine_sh > kDeepMaxFine) {
+            literal = true;
+            if (stats && tid == 0) atomicAdd(&stats[3], 1);
+          } else {
+            // interval -> 1 + its segment (0: node by node); the states are no longer needed
+            for (int i = tid; i < NC; i += 256) {
+              int sg = 0;
+              for (int x = 0; x < ns; ++x)
+                if (i >= seg_lo[x] && i < seg_hi[x]) sg = x + 1;
+              code[i] = (unsigned char)sg;
+            }
+            if (tid < kDeepWStride) W[tid] = deepw[tid];       // weights of n = 1 (level LC + 1)
+            __syncthreads();
+            // ---- self-check: the same machinery one level up.  Every odd sample is predicted
+            // from the even ones (stencils of twice the spacing, shifted at segment ends
+            // exactly as below) and compared with its true value; at the spacing actually
+            // used the interpolation error is 2^8 times smaller.
+            double e0 = 0.0, e1 = 0.0, m0 = 0.0, m1 = 0.0;
+            for (int ep = tid; ep < NC / 2; ep += 256) {
+              const int sg = code[2 * ep];
+              if (!sg || code[2 * ep + 1] != sg) continue;     // node by node
+              const int lo_e = (seg_lo[sg - 1] + 1) >> 1, hi_e = seg_hi[sg - 1] >> 1;   // even nodes / 2
+              if (hi_e - lo_e + 1 < kDeepStencil) continue;
+              int st = ep - 3;
+              st = st < lo_e ? lo_e : (st > hi_e - 7 ? hi_e - 7 : st);
+              const double* w = W + (ep - st) * kDeepStencil;
+              double p0 = 0.0, p1 = 0.0;
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    if (q == 0 ? done_a : done_b) continue;             // wave-uniform
-    double s = 0.0;                // chunk sums in chunk order: lane-strided, then the lanes
-    for (int ch = lane; ch < nchunk; ch += 64) s += part[((size_t)p * pstride + ch) * 2 + q];
-    const double S = wave_sum(s);
-    double* sq = st + q * kRombergDump;
-    const double ordsum = sq[32] + S;
-    const double Ti = range * ordsum / n;
-    double Tl = lane < 32 ? sq[lane] : 0.0;
-    if (lane == lev) Tl = Ti;
-    const double cur = wave_sum(lane < 32 ? c_il * Tl : 0.0);
-    const double err = fabs(cur - sq[33]);
-    const bool conv = err < cfg.global_precision || err < cfg.halo_precision * fabs(cur);
-    if (lane == lev) sq[lane] = Ti;
-    if (lane == 0) {
-      sq[32] = ordsum;
-      sq[33] = cur;
-      if (conv || last) {
-        const int fam = q == 0 ? d.fa : d.fb;
-        t[L.off_knot[fam] + d.ik] = cur;
-        levs[fam * L.NK + d.ik] = (double)lev;
-        st[kDsDone + q] = 1.0;
+              for (int m = 0; m < kDeepStencil; ++m) {
+                p0 = fma(w[m], F0[2 * (st + m)], p0);
+                p1 = fma(w[m], F1[2 * (st + m)], p1);
+              }
+              e0 += fabs(p0 - F0[2 * ep + 1]);
+              e1 += fabs(p1 - F1[2 * ep + 1]);
+            }
+            for (int q = tid; q <= NC; q += 256) { m0 += F0[q]; m1 += F1[q]; }
+            e0 = group_sum<4>(e0, red, flip);
+            e1 = group_sum<4>(e1, red, flip);
+            m0 = group_sum<4>(m0, red, flip);
+            m1 = group_sum<4>(m1, red, flip);
+            const bool bad0 = !R.done[0] && !(e0 * (1.0 / 256.0) <= kDeepTol * fabs(m0));
+            const bool bad1 = !R.done[1] && !(e1 * (1.0 / 256.0) <= kDeepTol * fabs(m1));
+            if (bad0 || bad1) literal = true;
+            if (stats && tid == 0) {
+              if (literal) atomicAdd(&stats[4], 1);
+              const float r0 = R.done[0] ? 0.0f : (float)(e0 * (1.0 / 256.0) / fabs(m0));
+              const float r1 = R.done[1] ? 0.0f : (float)(e1 * (1.0 / 256.0) / fabs(m1));
+              atomicMax(&stats[5], __float_as_int(fmaxf(r0, r1)));   // (positive floats order as ints)
+            }
+          }
+        }
+      }
+      if (!literal) {
+        // ---- deeper levels: weighted sums of the samples + the break-point intervals
+        const int nf = n_fine_sh;
+        for (int lv = LC + 1; lv <= cfg.divmax && !R.all_done(); ++lv) {
+          __syncthreads();                                     // (previous level done with W)
+          if (tid < kDeepWStride) W[tid] = deepw[(size_t)(lv - LC - 1) * kDeepWStride + tid];
+          __syncthreads();
+          const int n = 1 << (lv - 1 - LC);
+          double s0 = 0.0, s1 = 0.0;
+          for (int i = tid; i < NC; i += 256) {
+            const int sg = code[i];
+            if (!sg) continue;                                 // node by node below
+            const int lo = seg_lo[sg - 1], hi = seg_hi[sg - 1];
+            int st = i - 3;
+            st = st < lo ? lo : (st > hi - 7 ? hi - 7 : st);
+            const double* w = W + (i - st) * kDeepStencil;
+#pragma unroll
+            for (int m = 0; m < kDeepStencil; ++m) {
+              s0 = fma(w[m], F0[st + m], s0);
+              s1 = fma(w[m], F1[st + m], s1);
+            }
+          }
+          const long numtosum = 1L << (lv - 1);
+          const double h = (b - a) / (double)numtosum;
+          const double lox = a + 0.5 * h;
+          for (int idx = tid; idx < nf * n; idx += 256) {
+            const long j = (long)fine_sh[idx / n] * n + (idx % n);
+            double o[2];
+            int st;
+            halo_eval_coded(group, c, lox + h * (double)j, o, &st);
+            s0 += o[0];
+            s1 += o[1];
+          }
+          s0 = group_sum<4>(s0, red, flip);
+          s1 = group_sum<4>(s1, red, flip);
+          R.advance(lv, s0, s1);
+        }
+        val[0] = R.value[0]; val[1] = R.value[1];
+        lev[0] = R.level[0]; lev[1] = R.level[1];
+        conv[0] = R.done[0]; conv[1] = R.done[1];
       }
     }
-  }
+    if (literal) {
+      __syncthreads();
+      deep_literal<4>(cfg, c, E, group, pa, red, val, lev, conv);
+    }
+    if (tid == 0) {
+      if (pa) { t[L.off_knot[fa] + ik] = val[0]; levs[fa * NK + ik] = (double)lev[0]; }
+      if (pb) { t[L.off_knot[fb] + ik] = val[1]; levs[fb * NK + ik] = (double)lev[1]; }
+      unsigned st = 0u;              // divmax exhausted (halo.py:1065-1071 and alike)
+      if (pa && !conv[0]) st |= kStHaloDivmax0 << fa;
+      if (pb && !conv[1]) st |= kStHaloDivmax0 << fb;
+      if (st) atomicOr(&status[e], st);
+      if (stats) atomicAdd(&stats[literal ? 1 : 0], 1);
+    }
+  }   // next item
 }
 
 // ---------------------------------------------------------------------------
@@ -657,7 +809,7 @@ __global__ __launch_bounds__(256) void k_halo_deep_advance(
 __global__ __launch_bounds__(384) void k_halo_finalize(
     chomp_config cfg, TabLayout L, Epoch* __restrict__ epochs, double* __restrict__ tab,
     const chomp_halo_par* __restrict__ profile, const HodDev* __restrict__ hod,
-    unsigned fam_mask, int* __restrict__ pending) {
+    unsigned fam_mask, int* __restrict__ pending, unsigned* __restrict__ status) {
   extern __shared__ __align__(16) double sm[];
   const int NK = L.NK;
   if (blockIdx.x == 0 && threadIdx.x == 0) { pending[0] = 0; pending[1] = 0; }
@@ -679,11 +831,14 @@ __global__ __launch_bounds__(384) void k_halo_finalize(
     else if (f == F_HG) scale = 1.0 / nbr;                        // :959
     else if (f == F_PPGM) scale = 1.0 / n_bar;                    // :1072
     else if (f == F_PPGG) scale = rho_bar / (n_bar * n_bar);      // :1026
+    bool bad = false;
     for (int i = lane; i < NK; i += 64) {
       const double v = t[L.off_knot[f] + i] * scale;
       yk[f * NK + i] = v;
       t[L.off_knot[f] + i] = v;
+      bad = bad || !(fabs(v) <= 1.79769313486231570815e308);   // NaN or infinity
     }
+    if (__any(bad) && lane == 0) atomicOr(&status[e], kStNonfinite);
   }
   if (f == 5 && lane == 1) {
     // Stage-E record: amplitude of Delta^2 and "same cosmology as the previous epoch"

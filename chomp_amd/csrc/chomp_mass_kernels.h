@@ -479,8 +479,9 @@ __device__ __forceinline__ double nu_probe(const Epoch& E, const double* snode, 
 template <int NW, bool BAO>
 __device__ double search_side_exact(const Epoch& E, const double* snode, int side,
                                     const chomp_config& cfg, const double* cand, double* red,
-                                    int* n_eval, int seed_dir = 0, int seed_jl = 0,
-                                    double nu_l = 0.0, int seed_jh = -1, double nu_h = 0.0) {
+                                    int* n_eval, bool* exhausted, int seed_dir = 0,
+                                    int seed_jl = 0, double nu_l = 0.0, int seed_jh = -1,
+                                    double nu_h = 0.0) {
   const SideThresholds T = side_thresholds(side, cand);
   double mass = T.down[0];
   int dir = seed_dir;
@@ -527,7 +528,7 @@ __device__ double search_side_exact(const Epoch& E, const double* snode, int sid
         }
         jl = jp;
         tl = tp;
-        if (jh < 0 && jp == kSearchJ - 1) { jh = jp; break; }   // table exhausted
+        if (jh < 0 && jp == kSearchJ - 1) { jh = jp; *exhausted = true; break; }   // table exhausted
       }
     }
     if (jh < 0) jh = jl;
@@ -629,7 +630,7 @@ template <bool BAO>
 __global__ __launch_bounds__(64 * kInitNW) void k_epoch_init(
     chomp_config cfg, Epoch* __restrict__ epochs, double* __restrict__ search,
     const double* __restrict__ cand, const double* __restrict__ snodes,
-    double* __restrict__ probe, int* __restrict__ count) {
+    double* __restrict__ probe, int* __restrict__ count, unsigned* __restrict__ status) {
   __shared__ Epoch E;
   __shared__ double red[romberg_scratch<kInitNW, 1>()];
   __shared__ double lns[kSGrid];   // the cosmology's coarse ln S(R) table
@@ -768,12 +769,28 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_init(
         }
       }
     }
+    bool exhausted = false;
     if (!certified)                // block-uniform: every thread read the same values
-      mass = search_side_exact<kInitNW, BAO>(E, snode, sd, cfg, cand, red, &n_eval, seed_dir, seed_jl,
-                                        nu_l, seed_jh, nu_h);
+      mass = search_side_exact<kInitNW, BAO>(E, snode, sd, cfg, cand, red, &n_eval, &exhausted,
+                                             seed_dir, seed_jl, nu_l, seed_jh, nu_h);
     if (threadIdx.x == 0) {
       search[(e * 2 + sd) * 2 + 0] = log(mass);
       search[(e * 2 + sd) * 2 + 1] = (double)n_eval;
+      // Where the walk ended.  mass_min: once k R < 0.2 over sigma_r's whole k range (clamped
+      // at 100 k_max, cosmology.py:627-632) the top-hat window is 1 to 4e-3, nu(M) has
+      // converged to a constant -- above the band, or the walk would have ended earlier --
+      // and only the rounding error of 3 (sin x / x^3 - cos x / x^2) at small x, whose
+      // variance biases sigma^2 upwards like eps^2 / x^4, ends the reference's walk: the step
+      // it stops at is a property of the libm in use (DESIGN.md "Known limit of parity").
+      // At k R = 0.2 a 5 % step still moves nu by 3e-5 against a rounding error of 1e-7; a
+      // factor two below that the two are equal.  The caller is told.  mass_max: the walk
+      // ended with sigma_r's range clamped at k_min / 100 (cosmology.py:617-622).
+      const double R = scale_of_mass(E, mass);
+      unsigned st = 0u;
+      if (sd == 0 && 100.0 * E.k_max * R < 0.2) st |= kStMassMinSaturated;
+      if (sd == 1 && 0.1 / R <= E.k_min / 100.0) st |= kStMassMaxSaturated;
+      if (exhausted) st |= kStSearchExhausted;
+      if (st) atomicOr(&status[e], st);
     }
   }
   __syncthreads();
@@ -795,7 +812,8 @@ __global__ __launch_bounds__(64 * kNuNW) void k_nu_table(chomp_config cfg, TabLa
                                                   const Epoch* __restrict__ epochs,
                                                   const double* __restrict__ search,
                                                   const double* __restrict__ snodes,
-                                                  double* __restrict__ tab) {
+                                                  double* __restrict__ tab,
+                                                  unsigned* __restrict__ status) {
   __shared__ Epoch E;
   __shared__ double red[romberg_scratch<4, 2>()];
   const int i = blockIdx.x, e = blockIdx.y;
@@ -804,12 +822,14 @@ __global__ __launch_bounds__(64 * kNuNW) void k_nu_table(chomp_config cfg, TabLa
   __syncthreads();
   const double ln_lo = search[(e * 2 + 0) * 2], ln_hi = search[(e * 2 + 1) * 2];
   const double lnm = linspace_at(ln_lo, ln_hi, L.NM, i);
+  bool conv = true;
   const double nu = nu_of_mass_block<kNuNW, 1, BAO>(E, snodes + (size_t)E.cosmo_slot * kSigmaStride, exp(lnm), cfg,
-                                            cfg.cosmo_precision, red);
+                                            cfg.cosmo_precision, red, &conv);
   if (threadIdx.x == 0) {
     double* t = tab + (size_t)e * L.stride;
     t[L.off_ln_mass + i] = lnm;
     t[L.off_nu + i] = nu;
+    if (!conv) atomicOr(&status[e], kStSigmaDivmax);     // scipy: AccuracyWarning, last row kept
   }
 }
 

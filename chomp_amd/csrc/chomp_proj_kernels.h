@@ -87,6 +87,7 @@ struct ProjState {
   ProjDev host;            // host copy of the scalars (refreshed by kernel_info)
   ProjDev* d_pd = nullptr;
   double* d_tab = nullptr;
+  size_t cap_tab = 0;      // doubles allocated at d_tab
   bool cov_ready = false;  // covariance table (chomp_covariance_table) valid
   double* d_cov = nullptr;
 };

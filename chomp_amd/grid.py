@@ -83,6 +83,15 @@ class HaloGrid(object):
         self.ctx.halo_setup(self._c_halo, self._c_hod, need)
         self._tables = need
 
+    def status(self, warn=False):
+        """Status words of this rank's epochs (chomp_get_status: saturated mass-limit search,
+        Romberg integrals that exhausted divmax, ...); synchronises.  warn=True also raises
+        them as Python warnings.  The batch path never checks by itself: a step stays
+        asynchronous."""
+        if len(self.idx) == 0:
+            return numpy.zeros(0, dtype=numpy.uint32)
+        return self.ctx.warn_status(0, len(self.idx)) if warn else self.ctx.status(0, len(self.idx))
+
     def power(self, which, k, out=None):
         """Stage E: [n_local, nk] for numpy or torch-cuda k."""
         code, need = _WHICH[which]

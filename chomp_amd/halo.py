@@ -112,6 +112,9 @@ class Halo(object):
                 if build & bit:
                     setattr(self, flag, True)
             self._nbar_valid = True
+            # what scipy's AccuracyWarning (divmax exceeded) told the reference's user, plus
+            # the saturated mass-limit search (include/chomp_mi355x.h, chomp_get_status)
+            self.status = int(ctx.warn_status(0, 1, stacklevel=5)[0])
         return ctx
 
     def _after_epochs_set(self):

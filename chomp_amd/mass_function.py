@@ -43,6 +43,7 @@ class MassFunction(object):
             self._ctx.mass_setup(self.halo_dict, self._kind)
             self._sc = self._ctx.scalars(0)
             self._sig = sig
+            self._ctx.warn_status(0, 1, stacklevel=4)   # saturated search, exhausted divmax
         return self._ctx
 
     def _scalar(self, name):

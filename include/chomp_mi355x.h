@@ -229,6 +229,56 @@ int chomp_halofit_put(chomp_ctx* ctx, size_t epoch, const double* in);
  * attributes: _chi, _growth, omega_m(), delta_c(), ..., f_norm, n_bar). */
 int chomp_get_scalars(chomp_ctx* ctx, size_t epoch, double* out);
 
+/* Per-epoch status word: what the reference would have told its user through a warning (or
+ * through never returning), reported instead of computed around.  Bits accumulate over the
+ * stages of an epoch; chomp_epochs_set clears the word, chomp_halo_setup the HALO / NONFINITE
+ * bits.  out[n] <- status of epochs [epoch0, epoch0 + n) (host buffer; synchronises).
+ *
+ * MASS_MIN_SATURATED: MassFunction._set_mass_limits' 5 % walk (mass_function.py:171-181) ended
+ *   at a mass so small that k R < 0.2 over the whole k range of sigma_r (clamped at 100 k_max,
+ *   cosmology.py:627-632).  There nu(M) has converged to a constant above the band -- in exact
+ *   arithmetic the walk would never end -- and what ends the reference's walk is the rounding
+ *   error of 3 (sin x / x^3 - cos x / x^2) at x << 1 (its variance biases sigma^2 upwards like
+ *   eps^2 / x^4): the step it stops at is a property of the libm in use, not of the model.
+ *   Results for such an epoch can differ from the reference's by percents (either answer is
+ *   equally arbitrary); low sigma_8 / Omega_m at z >~ 0.8, M_min ~ 1e-8 M_sun/h.
+ * MASS_MAX_SATURATED: the mass_max walk ended with sigma_r's k range clamped at k_min / 100
+ *   (cosmology.py:617-622, behind the reference's commented-out extrapolation warning).
+ * MASS_SEARCH_EXHAUSTED: the walk did not end within 2047 steps (the reference loops on).
+ * SIGMA_DIVMAX: a sigma(R) Romberg of the nu table exhausted divmax (scipy: AccuracyWarning).
+ * HALO_DIVMAX_*: some knot of that table exhausted divmax (halo.py:909-915, 951-957, 976-982,
+ *   1018-1024, 1065-1071; scipy returns the last row with an AccuracyWarning -- with the
+ *   default precision the discontinuous HOD integrands of pp_gm / pp_gg do this routinely).
+ * NONFINITE: a knot table holds a NaN or an infinity. */
+#define CHOMP_ST_MASS_MIN_SATURATED 1u
+#define CHOMP_ST_MASS_MAX_SATURATED 2u
+#define CHOMP_ST_MASS_SEARCH_EXHAUSTED 4u
+#define CHOMP_ST_SIGMA_DIVMAX 8u
+#define CHOMP_ST_HALO_DIVMAX_H_M 0x100u   /* << 0..4: H_M, PP_MM, H_G, PP_GM, PP_GG */
+#define CHOMP_ST_HALO_DIVMAX_PP_MM 0x200u
+#define CHOMP_ST_HALO_DIVMAX_H_G 0x400u
+#define CHOMP_ST_HALO_DIVMAX_PP_GM 0x800u
+#define CHOMP_ST_HALO_DIVMAX_PP_GG 0x1000u
+#define CHOMP_ST_NONFINITE 0x10000u
+int chomp_get_status(chomp_ctx* ctx, size_t epoch0, size_t n, unsigned* out);
+
+/* Test / tuning hooks (no counterpart in the reference; not needed by a caller): override a
+ * launch-shape decision of this context.  value < 0 restores the default.
+ *   CHOMP_TUNE_E_STREAM_MIN  samples from which chomp_power takes the streaming launch shape
+ *   CHOMP_TUNE_E_ROWS        rows per block of the streaming kernel (1, 2 or 4)
+ *   CHOMP_TUNE_DEEP_LITERAL  1: knots beyond the node tables by literal evaluation of every
+ *                            Romberg node (the checker of the fast deep-level sums) */
+#define CHOMP_TUNE_E_STREAM_MIN 0
+#define CHOMP_TUNE_E_ROWS 1
+#define CHOMP_TUNE_DEEP_LITERAL 2
+#define CHOMP_TUNE_COUNT 3
+int chomp_set_tuning(chomp_ctx* ctx, int what, long long value);
+/* Measurement aid: out[6] <- knots beyond the node tables done so far (since the context was
+ * created) by [0] the fast deep-level sums, [1] literal evaluation of every node; why literal:
+ * [2] too many break points, [3] too many node-by-node intervals, [4] the self-check of the
+ * interpolation; [5] the largest self-check error estimate seen, in units of 1e-15. */
+int chomp_get_deep_stats(chomp_ctx* ctx, long long* out);
+
 #define CHOMP_TAB_LN_MASS 0 /* MassFunction._ln_mass_array  [mass_npoints] */
 #define CHOMP_TAB_NU 1      /* MassFunction._nu_array       [mass_npoints] */
 #define CHOMP_TAB_H_M 2     /* knots of Halo._h_m_spline    [halo_npoints] */

@@ -66,12 +66,20 @@ class Table(object):
         self.__dict__.update(kw)
 
 
+# How often scipy.integrate.romberg would have raised its AccuracyWarning ("divmax exceeded")
+# since the counter was last cleared: the tests of the status word compare it with the
+# device's CHOMP_ST_*_DIVMAX bits.
+DIVMAX_EXCEEDED = [0]
+
+
 def _rom(f, a, b, rtol, prec, args=()):
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore", AccuracyWarning)
-        return romberg(f, a, b, args=args, vec_func=True,
-                       tol=prec["global_precision"], rtol=rtol,
-                       divmax=prec["divmax"])
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always", AccuracyWarning)
+        out = romberg(f, a, b, args=args, vec_func=True,
+                      tol=prec["global_precision"], rtol=rtol,
+                      divmax=prec["divmax"])
+    DIVMAX_EXCEEDED[0] += sum(1 for w in rec if issubclass(w.category, AccuracyWarning))
+    return out
 
 
 # ---------------------------------------------------------------------------
@@ -654,13 +662,14 @@ def _knots(t, integrand, ln_nu_lo, safe_norm):
             if safe_norm != -1:
                 inv = integrand(numpy.log(nu_of_mass(m, safe_norm)), t, ln_k, 1.0)
                 norm = 1.0 / inv if inv > 1e-16 else 1.0
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore", AccuracyWarning)
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always", AccuracyWarning)
             val, level = romberg(integrand, ln_nu_lo, numpy.log(m.nu_max),
                                  args=(t, ln_k, norm), vec_func=True,
                                  tol=prec["global_precision"],
                                  rtol=prec["halo_precision"],
                                  divmax=prec["divmax"], return_level=True)
+        DIVMAX_EXCEEDED[0] += sum(1 for w in rec if issubclass(w.category, AccuracyWarning))
         out[idx] = val / norm
         lev.append(level)
     t.levels[integrand.__name__] = lev

@@ -61,17 +61,17 @@ def test_c2_full_grid_properties(torch_mod):
         assert rel_err(pk[i], lin[i] * hm * hm + pp) < 1e-11
 
 
-def test_stage_e_launch_shapes_agree(torch_mod, monkeypatch):
+def test_stage_e_launch_shapes_agree(torch_mod):
     """Stage E has three launch shapes -- the row-major streaming pair (k_power_prep +
     k_power_stream, large grids of one cosmology), the row-walking kernel and the generic
     per-sample kernel -- plus the per-lane pass for k groups that are unsorted, ragged or
     out of range.  All must return the same numbers on the same input."""
     torch = torch_mod
-    from chomp_amd import grid
+    from chomp_amd import grid, _lib
     gen = torch.Generator("cuda").manual_seed(5)
 
     def run(hg, which, k, stream):
-        monkeypatch.setenv("CHOMP_E_STREAM_MIN", "0" if stream else str(1 << 62))
+        hg.ctx.set_tuning(_lib.TUNE_E_STREAM_MIN, 0 if stream else 1 << 62)
         out = hg.power(which, k).clone()
         torch.cuda.synchronize()
         return out
@@ -102,7 +102,7 @@ def test_stage_e_launch_shapes_agree(torch_mod, monkeypatch):
             assert err < 1e-12, (name, which, err)
     # odd number of rows (one row per block) and a sub-range of the epochs
     k = cases["sorted"]
-    monkeypatch.setenv("CHOMP_E_STREAM_MIN", "0")
+    hg.ctx.set_tuning(_lib.TUNE_E_STREAM_MIN, 0)
     part = torch.empty((3, k.numel()), dtype=torch.float64, device="cuda")
     hg.ctx.power(3, k, 2, 3, out=part)               # P_gg, epochs 2..4
     full = run(hg, "power_gg", k, False)
@@ -115,12 +115,17 @@ def test_mass_limit_search_matches_the_walk():
     well away from the fixtures: the ln M limits are compared bit for bit with the
     oracle's literal walk.
 
-    Not compared: walks that run below M = 1e3 M_sun/h (z ~ 1.7 with a low sigma_8; the
-    reference's search diverges near z ~ 1.9).  There R < 1e-5 Mpc/h, k R < 1e-1
-    over the whole integration range, and the top-hat window 3 (sin x - x cos x) / x^3 is
-    rounding noise of the libm in use: the step the reference stops at is then a property
-    of glibc's sin/cos, not of the algorithm (observed: 5 steps apart at M ~ 3e-8)."""
-    from chomp_amd import grid
+    The one regime where that cannot hold is REPORTED, not skipped: a walk that runs on until
+    k R < 0.2 over the whole (clamped, cosmology.py:627-632) k range of sigma_r (M <~ 0.1
+    M_sun/h; z >~ 0.8 with a low sigma_8 and Omega_m; the reference's search diverges near
+    z ~ 1.9).  There nu(M) has converged to a constant ABOVE the band in exact arithmetic --
+    the walk would never end -- and what ends it is the rounding error of the top-hat window
+    3 (sin x / x^3 - cos x / x^2) at x << 1, whose variance biases sigma^2 upwards like
+    eps^2 / x^4: the step the reference stops at is a property of the libm in use, not of the
+    model (observed: 5 steps apart at M ~ 3e-8).  Such an epoch carries
+    CHOMP_ST_MASS_MIN_SATURATED in its status word -- exactly when the oracle's walk ends in
+    that regime too -- and every epoch without the flag is bit-equal."""
+    from chomp_amd import grid, _lib
     from oracle import chomp_oracle as o
     rng = numpy.random.default_rng(20)
     base = o.default_cosmo_dict
@@ -134,18 +139,73 @@ def test_mass_limit_search_matches_the_walk():
                         else rng.uniform(0.0, 1.7)))
     hg = grid.HaloGrid(numpy.array(zs), cosmo_dict=cds)
     hg.setup("power_mm")
-    bad, n_checked = [], 0
+    status = hg.status()
+    bad, n_checked, n_flagged = [], 0, 0
     for i in range(24):
         e = o.epoch(cds[i], zs[i])
         lo, hi, _ = o.mass_limits(e)
         sc = hg.ctx.scalars(i)
         assert numpy.isfinite(sc["ln_mass_min"]) and sc["ln_mass_max"] == hi, (i, zs[i])
-        if lo >= numpy.log(1e3):
+        # did the oracle's walk end with k R < 0.2 over sigma_r's whole (clamped) k range?
+        R = (3.0 * numpy.exp(lo) / (4.0 * numpy.pi * o.rho_bar(e))) ** (1.0 / 3.0)
+        saturated = 100.0 * e.limits["k_max"] * R < 0.2
+        flagged = bool(status[i] & _lib.ST_MASS_MIN_SATURATED)
+        assert flagged == saturated, (i, zs[i], int(status[i]), float(lo), float(sc["ln_mass_min"]))
+        assert not status[i] & (_lib.ST_MASS_MAX_SATURATED | _lib.ST_MASS_SEARCH_EXHAUSTED)
+        if flagged:
+            n_flagged += 1
+            assert lo < numpy.log(1.0) and sc["ln_mass_min"] < numpy.log(1.0)
+        else:
             n_checked += 1
             if sc["ln_mass_min"] != lo:
                 bad.append((i, zs[i], float(sc["ln_mass_min"]), float(lo)))
     assert not bad, bad
-    assert n_checked >= 18
+    assert n_checked >= 18 and n_flagged >= 1, (n_checked, n_flagged)
+
+
+def test_status_word_reports_what_scipy_warned_about():
+    """chomp_get_status: an exhausted divmax (scipy's AccuracyWarning in the reference,
+    halo.py:1065-1071 and alike) and a saturated mass-limit search reach the caller -- per
+    epoch from the batch API, as Python warnings from the drop-in classes -- and a clean
+    epoch reports 0."""
+    import warnings
+    from chomp_amd import grid, halo, hod, _lib
+    from oracle import chomp_oracle as o
+    hg = grid.HaloGrid(numpy.array([0.0, 1.0]))
+    hg.setup("power_mm")
+    assert list(hg.status()) == [0, 0]
+    # P_gm at the default precision: the discontinuous HOD integrands exhaust divmax = 20
+    hg.setup("power_gm")
+    st = hg.status()
+    for i, z in enumerate((0.0, 1.0)):
+        e = o.epoch(None, z)
+        m = o.mass_table(e)
+        o.DIVMAX_EXCEEDED[0] = 0
+        o.halo_table(e, m, o.zheng(), families=("gm",))
+        oracle_warned = o.DIVMAX_EXCEEDED[0] > 0
+        lev = hg.ctx.table("levels", i).reshape(5, -1)
+        at_top = {name: bool((lev[f] == 20).any()) for f, name in
+                  enumerate(("h_m", "pp_mm", "h_g", "pp_gm", "pp_gg")) if name != "pp_gg"}
+        flagged = {name: bool(st[i] & bit) for name, bit in _lib.ST_HALO_DIVMAX.items()}
+        assert any(flagged.values()) == oracle_warned, (z, flagged, oracle_warned)
+        for name, f in flagged.items():
+            if f:
+                assert at_top[name], (z, name)       # a flag needs a knot that ran to divmax
+        assert not st[i] & (_lib.ST_SATURATED | _lib.ST_NONFINITE | _lib.ST_SIGMA_DIVMAX)
+    # the drop-in class warns like the reference did
+    h = halo.Halo(0.0, hod.HODZheng())
+    with pytest.warns(_lib.ChompAccuracyWarning, match="divmax"):
+        h.power_gm(numpy.array([0.1, 1.0]))
+    # a saturated search: low sigma_8 and Omega_m at z ~ 1.4 (one of the three cases a
+    # randomised soak of 40 cosmologies found 5 % away from the oracle)
+    cd = dict(o.default_cosmo_dict, omega_m0=0.22563, omega_b0=0.04499, omega_l0=0.77429,
+              h=0.7203, sigma_8=0.70574, n_scalar=0.93183)
+    hs = grid.HaloGrid(numpy.array([1.3923165344405541]), cosmo_dict=cd)
+    hs.setup("power_mm")
+    assert hs.status()[0] & _lib.ST_MASS_MIN_SATURATED
+    assert any("saturated" in m for m in _lib.describe_status(int(hs.status()[0])))
+    with pytest.warns(_lib.ChompParityWarning, match="saturated"):
+        hs.status(warn=True)
 
 
 def test_abi_error_codes_and_call_order():
@@ -334,27 +394,43 @@ def test_stage_e_timing_facility():
 
 
 def test_deep_knot_paths_agree():
-    """The HOD knots that run beyond the node tables take two routes: one block per knot
-    from a work list (a batch of epochs) or one launch per Romberg level over the whole grid
-    (a single Halo).  Same nodes, rows and stopping rule: the spectra agree to rounding and
-    the stopping levels exactly."""
-    from chomp_amd import grid
-    z = numpy.linspace(0.1, 1.2, 6)
+    """The HOD knots that run beyond the node tables (Romberg levels 11..20, up to 2^20 nodes
+    in the reference) are done by k_halo_knots_fast: level sums from 2049 coarse samples
+    (degree-7 Lagrange weights) plus node-by-node evaluation of the few coarse intervals that
+    hold a break point of the integrand.  Its checker evaluates every node literally
+    (CHOMP_TUNE_DEEP_LITERAL): the knot values must agree to 1e-9 -- four orders inside the
+    Romberg tolerance that decides the rows -- the stopping levels at every knot, and the
+    spectra to 1e-9; Sheth-Tormen and Tinker, three Zheng HODs, redshifts of configs[2]."""
+    from chomp_amd import grid, _lib
+    z = numpy.array([0.0, 0.1, 0.55, 1.2, 1.5])
     k = numpy.logspace(-3, 2, 200)
-    batch = grid.HaloGrid(z)
-    for which in ("power_gm", "power_gg"):
-        pb = batch.power(which, k)
-        for i in (0, 3, 5):
-            single = grid.HaloGrid(z[i:i + 1])
-            ps = single.power(which, k)
-            assert numpy.max(numpy.abs(ps[0] / pb[i] - 1)) < 1e-12, (which, i)
-            lev_b = batch.ctx.table("levels", epoch=i)
-            lev_s = single.ctx.table("levels", epoch=0)
-            nk = lev_s.size // 5          # levels: [h_m, pp_mm, h_g, pp_gm, pp_gg][halo_npoints]
-            for fam in ((0, 2, 3) if which == "power_gm" else (2, 4)):
-                a, b = lev_b[fam * nk:(fam + 1) * nk], lev_s[fam * nk:(fam + 1) * nk]
-                assert numpy.array_equal(a, b), (which, i, fam)
-            assert lev_s[(3 if which == "power_gm" else 4) * nk:][:nk].max() > 10
+    hods = [dict(log_M_min=12.14, sigma=0.15, log_M_0=12.14, log_M_1p=13.43, alpha=1.0),
+            dict(log_M_min=11.9, sigma=0.35, log_M_0=12.3, log_M_1p=13.1, alpha=0.8),
+            dict(log_M_min=12.5, sigma=0.0, log_M_0=12.0, log_M_1p=13.6, alpha=1.2)]
+    n_fast = 0
+    for mf in ("st", "tinker"):
+        for hd in hods:
+            fast = grid.HaloGrid(z, mass_function=mf, hod_dict=hd)
+            lit = grid.HaloGrid(z, mass_function=mf, hod_dict=hd)
+            lit.ctx = fast.ctx.__class__(fast.ctx.config, device=fast.ctx.device)
+            lit.ctx.set_tuning(_lib.TUNE_DEEP_LITERAL, 1)
+            for which in ("power_gm", "power_gg"):
+                pf, pl = fast.power(which, k), lit.power(which, k)
+                assert numpy.max(numpy.abs(pf / pl - 1)) < 1e-9, (mf, hd, which)
+                for i in range(z.size):
+                    for name in (("h_m", "h_g", "pp_gm") if which == "power_gm" else ("h_g", "pp_gg")):
+                        a, b = fast.ctx.table(name, i), lit.ctx.table(name, i)
+                        assert numpy.max(numpy.abs(a / b - 1)) < 1e-9, (mf, hd, which, i, name)
+                    la = fast.ctx.table("levels", i).reshape(5, -1)
+                    lb = lit.ctx.table("levels", i).reshape(5, -1)
+                    rows = (0, 2, 3) if which == "power_gm" else (2, 4)
+                    assert numpy.array_equal(la[list(rows)], lb[list(rows)]), (mf, hd, which, i)
+            f, l = fast.ctx.deep_stats()
+            assert f > 0 and l == 0, (f, l)       # no knot fell back to the literal route
+            n_fast += f
+            f, l = lit.ctx.deep_stats()
+            assert f == 0 and l > 0
+    assert n_fast > 500
 
 
 def test_step_replays_from_a_hip_graph():
@@ -388,3 +464,55 @@ def test_step_replays_from_a_hip_graph():
                 step()                     # an eager call in between
             torch.cuda.synchronize()
             assert torch.equal(out, ref), i
+
+
+def test_graph_capture_refuses_what_a_replay_cannot_honour():
+    """Under stream capture the library must not synchronise or reallocate: a parameter block
+    that differs from what the device holds, or a work buffer that would have to grow, is an
+    error (CHOMP_ERR_STATE) -- not a broken capture -- and buffers a captured graph references
+    stay alive when a later eager call outgrows them (include/chomp_mi355x.h, "HIP graphs")."""
+    import torch
+    from chomp_amd import grid, _lib
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        z = numpy.linspace(0.0, 1.0, 8)
+        k = torch.logspace(-3, 2, 2048, dtype=torch.float64, device="cuda")
+        out = torch.zeros((8, 2048), dtype=torch.float64, device="cuda")
+        hg = grid.HaloGrid(z, stream=s.cuda_stream)
+        hg.setup("power_mm")
+        hg.power("power_mm", k, out=out)
+        torch.cuda.synchronize()
+        ref = out.clone()
+        # (a) changed parameters while capturing
+        hg2 = grid.HaloGrid(z + 0.1, stream=s.cuda_stream)
+        hg2.ctx = hg.ctx                      # same context, other redshifts
+        g = torch.cuda.CUDAGraph()
+        with pytest.raises(_lib.ChompError, match="captur"):
+            with torch.cuda.graph(g, stream=s):
+                hg2.setup("power_mm")
+        torch.cuda.synchronize()
+        # (b) the same parameters capture fine ...
+        hg.setup("power_mm")
+        hg.power("power_mm", k, out=out)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            hg.setup("power_mm")
+            hg.power("power_mm", k, out=out)
+        torch.cuda.synchronize()
+        # ... (c) and a later, larger eager call must not free what the graph references
+        big = grid.HaloGrid(numpy.linspace(0.0, 1.0, 24), stream=s.cuda_stream)
+        big.ctx = hg.ctx
+        big.setup("power_mm")
+        kb = torch.logspace(-3, 2, 1 << 15, dtype=torch.float64, device="cuda")
+        big.power("power_mm", kb)
+        torch.cuda.synchronize()
+        out.zero_()
+        g.replay()                            # stale buffers, but alive: no fault
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all()
+        # eager again with the original batch: the original numbers
+        hg.setup("power_mm")
+        hg.power("power_mm", k, out=out)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)

@@ -1,5 +1,7 @@
 """Randomised parity soak: device P_mm / P_gm against the oracle for random cosmologies,
-HODs and redshifts (not part of the test suite: the oracle takes seconds per case)."""
+HODs and redshifts (not part of the test suite: the oracle takes seconds per case).
+    python tools/soak.py [seed] [n]
+Exit code 1 if any epoch that the status word does not flag differs by more than 1e-4."""
 import os, sys, time, numpy
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 from chomp_amd import grid
@@ -24,9 +26,11 @@ for i in range(n):
 t = time.time()
 g = grid.HaloGrid(numpy.array(zs), cosmo_dict=cos, hod_dict=hods)
 pm = g.power("power_mm", k)
+from chomp_amd import _lib
+status = g.status()
 n_gm = min(n, 6)
 pg = g.power("power_gm", k)
-worst = 0.0
+worst, n_flag, n_unflagged_bad = 0.0, 0, 0
 for i in range(n):
     e = o.epoch(cos[i], float(zs[i]))
     fam = ("mm", "gm") if i < n_gm else ("mm",)
@@ -37,6 +41,15 @@ for i in range(n):
         eg = numpy.max(numpy.abs(pg[i] / o.halo_power(tb, "gm", k) - 1))
         msg += "  gm %.2e" % eg
         err = max(err, eg)
-    worst = max(worst, err)
+    flagged = bool(status[i] & (_lib.ST_SATURATED | _lib.ST_MASS_SEARCH_EXHAUSTED))
+    if flagged:
+        msg += "  FLAGGED (status 0x%x: saturated mass-limit search)" % int(status[i])
+        n_flag += 1
+    else:
+        worst = max(worst, err)
+        if err > 1e-4:
+            n_unflagged_bad += 1
     print(msg, flush=True)
-print("worst %.3e  (%.0f s)" % (worst, time.time() - t))
+print("worst unflagged %.3e; %d flagged; %d UNFLAGGED mismatches > 1e-4  (%.0f s)" % (
+    worst, n_flag, n_unflagged_bad, time.time() - t))
+sys.exit(1 if n_unflagged_bad else 0)
