@@ -103,7 +103,7 @@ EXPORTS = [
     "chomp_set_transfer", "chomp_kernel_raw",
     "chomp_covariance_table", "chomp_covariance_gaussian",
     "chomp_set_timing", "chomp_get_timing", "chomp_get_status", "chomp_set_tuning",
-    "chomp_get_deep_stats",
+    "chomp_get_deep_stats", "chomp_stage_k",
 ]
 
 # chomp_get_status bits (include/chomp_mi355x.h)
@@ -238,7 +238,8 @@ def lib():
             warnings.warn("chomp_amd: sources are newer than libchomp_mi355x.so and the "
                           "rebuild failed (%s); using the existing library" % exc)
         _preload_hip_runtime()
-        L = ctypes.CDLL(LIB_PATH)
+        # (development aid: an experimental build of the same library, e.g. for A/B timing)
+        L = ctypes.CDLL(os.environ.get("CHOMP_LIB_OVERRIDE", LIB_PATH))
         for name in EXPORTS:
             if not hasattr(L, name):
                 raise ImportError("chomp_amd: %s lacks symbol %s" % (LIB_PATH, name))
@@ -256,6 +257,8 @@ def lib():
         L.chomp_mass_setup.argtypes = [vp, ctypes.POINTER(HaloPar), i]
         L.chomp_halo_setup.argtypes = [vp, ctypes.POINTER(HaloPar),
                                        ctypes.POINTER(HodPar), ctypes.c_uint]
+        L.chomp_stage_k.argtypes = [vp, ctypes.POINTER(HaloPar), i, ctypes.POINTER(HaloPar),
+                                    ctypes.POINTER(HodPar), ctypes.c_uint]
         L.chomp_halofit_setup.argtypes = [vp, sz, sz, d, d, d, d, d]
         L.chomp_power.argtypes = [vp, i, vp, sz, vp, i]
         L.chomp_power_range.argtypes = [vp, i, sz, sz, vp, sz, vp, i]
@@ -434,6 +437,15 @@ class Context(object):
         ha = hods if isinstance(hods, ctypes.Array) else self.pack_hod(hods, n)
         assert len(pa) == n and len(ha) == n
         self._check(self._L.chomp_halo_setup(self._h, pa, ha, int(tables)))
+
+    def stage_k(self, mass_halo, mf_kind, profile, hods, tables):
+        """mass_setup + halo_setup in one call (chomp_stage_k)."""
+        n = self.n_epoch
+        ma = mass_halo if isinstance(mass_halo, ctypes.Array) else self.pack_halo(mass_halo, n)
+        pa = profile if isinstance(profile, ctypes.Array) else self.pack_halo(profile, n)
+        ha = hods if isinstance(hods, ctypes.Array) else self.pack_hod(hods, n)
+        assert len(ma) == n and len(pa) == n and len(ha) == n
+        self._check(self._L.chomp_stage_k(self._h, ma, int(mf_kind), pa, ha, int(tables)))
 
     def halofit_setup(self, dst, src, f1, f2, f3, omega_l, w):
         self._check(self._L.chomp_halofit_setup(self._h, dst, src, f1, f2, f3,

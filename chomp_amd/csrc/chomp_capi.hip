@@ -78,6 +78,8 @@ struct chomp_ctx {
   int* d_slot = nullptr;           // epoch -> cosmology slot
   int* d_first = nullptr;          // slot -> an epoch with that cosmology
   unsigned* d_status = nullptr;    // per-epoch status word (chomp_get_status)
+  double* d_endp = nullptr;        // integrand pairs of the knots at the upper end point
+  int* d_npend = nullptr;          // per epoch: listed knots + 1 token (k_halo_knots_fast)
   long long tune[CHOMP_TUNE_COUNT] = {-1, -1, -1};   // chomp_set_tuning
   bool have_epochs = false, have_mass = false, have_halo = false;
   unsigned fam_mask = 0;          // families (F_* bits) with valid splines
@@ -293,7 +295,7 @@ int alloc_epochs(chomp_ctx* ctx, size_t n) {
                 "the epoch batch would have to grow while the context's stream is being captured");
   void* old[] = {ctx->d_cosmo, ctx->d_z, ctx->d_epochs, ctx->d_search, ctx->d_probe, ctx->d_count, ctx->d_pending, ctx->d_tab,
                  ctx->d_mass_par, ctx->d_profile, ctx->d_hod, ctx->d_nodes, ctx->d_snodes,
-                 ctx->d_slot, ctx->d_first, ctx->d_status};
+                 ctx->d_slot, ctx->d_first, ctx->d_status, ctx->d_endp, ctx->d_npend};
   for (void* p : old) {
     const int rc = release_device(ctx, p);
     if (rc) return rc;
@@ -305,8 +307,11 @@ int alloc_epochs(chomp_ctx* ctx, size_t n) {
   HIPCHK(hipMalloc(&ctx->d_probe, n * kProbeStride * sizeof(double)));
   HIPCHK(hipMalloc(&ctx->d_count, n * sizeof(int)));
   HIPCHK(hipMemsetAsync(ctx->d_count, 0, n * sizeof(int), ctx->stream));
-  HIPCHK(hipMalloc(&ctx->d_pending, (2 + 3 * n * (size_t)ctx->L.NK) * sizeof(int)));
-  HIPCHK(hipMemsetAsync(ctx->d_pending, 0, 2 * sizeof(int), ctx->stream));
+  HIPCHK(hipMalloc(&ctx->d_pending, (kPendingHead + 3 * n * (size_t)ctx->L.NK) * sizeof(int)));
+  HIPCHK(hipMemsetAsync(ctx->d_pending, 0, kPendingHead * sizeof(int), ctx->stream));
+  HIPCHK(hipMalloc(&ctx->d_endp, n * 3 * 2 * (size_t)ctx->L.NK * sizeof(double)));
+  HIPCHK(hipMalloc(&ctx->d_npend, n * sizeof(int)));
+  HIPCHK(hipMemsetAsync(ctx->d_npend, 0, n * sizeof(int), ctx->stream));
   HIPCHK(hipMalloc(&ctx->d_tab, n * (size_t)ctx->L.stride * sizeof(double)));
   HIPCHK(hipMalloc(&ctx->d_mass_par, n * sizeof(chomp_halo_par)));
   HIPCHK(hipMalloc(&ctx->d_profile, n * sizeof(chomp_halo_par)));
@@ -351,8 +356,8 @@ int chomp_ctx_create(const chomp_config* cfg, int device, void* hip_stream,
     fprintf(stderr, "chomp_ctx_create: %s\n", m);
     return CHOMP_ERR_ARG;
   };
-  if (c.mass_npoints < 4 || c.mass_npoints > 512) return bad("mass_npoints out of [4,512]");
-  if (c.halo_npoints < 6 || c.halo_npoints > 512) return bad("halo_npoints out of [6,512]");
+  if (c.mass_npoints < 8 || c.mass_npoints > 256) return bad("mass_npoints out of [8,256]");
+  if (c.halo_npoints < 6 || c.halo_npoints > 256) return bad("halo_npoints out of [6,256]");
   if (c.kernel_npoints < 4 || c.kernel_npoints > 512) return bad("kernel_npoints");
   if (c.window_npoints < 4 || c.window_npoints > 1024) return bad("window_npoints");
   if (c.cosmo_npoints < 4 || c.cosmo_npoints > 512) return bad("cosmo_npoints");
@@ -391,7 +396,7 @@ void chomp_ctx_destroy(chomp_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   void* ptrs[] = {ctx->d_sici, ctx->d_j0, ctx->d_j2, ctx->d_tinker, ctx->d_gl16,
                   ctx->d_cand, ctx->d_cosmo, ctx->d_z, ctx->d_epochs, ctx->d_search, ctx->d_probe, ctx->d_count, ctx->d_pending,
-                  ctx->d_tab, ctx->d_mass_par, ctx->d_profile, ctx->d_hod, ctx->d_nodes, ctx->d_snodes, ctx->d_slot, ctx->d_first, ctx->d_status,
+                  ctx->d_tab, ctx->d_mass_par, ctx->d_profile, ctx->d_hod, ctx->d_nodes, ctx->d_snodes, ctx->d_slot, ctx->d_first, ctx->d_status, ctx->d_endp, ctx->d_npend,
                   ctx->d_stage_in, ctx->d_stage_in2, ctx->d_stage_out, ctx->d_slow, ctx->d_wnodes, ctx->d_deepw, ctx->d_deepstat,
                   ctx->d_winfo, ctx->d_ktab};
   for (void* p : ptrs)
@@ -515,20 +520,20 @@ int chomp_epochs_set(chomp_ctx* ctx, size_t n_epoch, const chomp_cosmo* cosmo,
   if (rc) return rc;
   rc = upload(ctx, ctx->d_first, first.data(), n_epoch * sizeof(int), ctx->sh_first);
   if (rc) return rc;
-  const dim3 gs(kSigmaNodeBlocks + kSGrid, (unsigned)(n_slots + (n_epoch + 255) / 256));
+  const dim3 gs(kSigmaNodeBlocks + kSGrid + kGTabBlocks, (unsigned)(n_slots + (n_epoch + 255) / 256));
   const dim3 gi((unsigned)n_epoch, 2 * kProbes);
   if (ctx->with_bao) {
     hipLaunchKernelGGL(k_sigma_nodes<true>, gs, dim3(256), 0, ctx->stream, ctx->cfg, ctx->d_cosmo,
                        ctx->d_z, ctx->d_first, ctx->d_slot, (int)n_slots, (int)n_epoch,
                        ctx->d_epochs, ctx->d_snodes, ctx->d_status);
-    hipLaunchKernelGGL(k_epoch_init<true>, gi, dim3(64 * kInitNW), 0, ctx->stream, ctx->cfg,
+    hipLaunchKernelGGL(k_epoch_probe<true>, gi, dim3(64 * kInitNW), 0, ctx->stream, ctx->cfg,
                        ctx->d_epochs, ctx->d_search, ctx->d_cand, ctx->d_snodes, ctx->d_probe,
                        ctx->d_count, ctx->d_status);
   } else {
     hipLaunchKernelGGL(k_sigma_nodes<false>, gs, dim3(256), 0, ctx->stream, ctx->cfg, ctx->d_cosmo,
                        ctx->d_z, ctx->d_first, ctx->d_slot, (int)n_slots, (int)n_epoch,
                        ctx->d_epochs, ctx->d_snodes, ctx->d_status);
-    hipLaunchKernelGGL(k_epoch_init<false>, gi, dim3(64 * kInitNW), 0, ctx->stream, ctx->cfg,
+    hipLaunchKernelGGL(k_epoch_probe<false>, gi, dim3(64 * kInitNW), 0, ctx->stream, ctx->cfg,
                        ctx->d_epochs, ctx->d_search, ctx->d_cand, ctx->d_snodes, ctx->d_probe,
                        ctx->d_count, ctx->d_status);
   }
@@ -537,41 +542,18 @@ int chomp_epochs_set(chomp_ctx* ctx, size_t n_epoch, const chomp_cosmo* cosmo,
   return CHOMP_OK;
 }
 
-int chomp_mass_setup(chomp_ctx* ctx, const chomp_halo_par* par, int mf_kind) {
-  if (!ctx || !par) return fail(ctx, CHOMP_ERR_ARG, "mass_setup: bad args");
-  if (!ctx->have_epochs) return fail(ctx, CHOMP_ERR_STATE, "mass_setup before epochs_set");
-  if (mf_kind != CHOMP_MF_ST && mf_kind != CHOMP_MF_TINKER)
-    return fail(ctx, CHOMP_ERR_ARG, "mass_setup: unknown mass function kind");
-  HIPCHK(hipSetDevice(ctx->device));
+// Host half of a halo set-up: argument checks, the HOD-derived constants (hod.py:172-186; one
+// erfinv per epoch), the parameter uploads, and the integration groups the requested
+// families need.
+struct HaloPlan {
+  unsigned fam = 0, kmask = 0;
+  int groups[3] = {-1, -1, -1};
+  int ng = 0;
+  int want_nbar = 1;
+};
+static int halo_prepare(chomp_ctx* ctx, const chomp_halo_par* profile, const chomp_hod_par* hod,
+                        unsigned tables, HaloPlan* P) {
   const size_t n = ctx->n_epoch;
-  const TabLayout& L = ctx->L;
-  int rcu = upload(ctx, ctx->d_mass_par, par, n * sizeof(chomp_halo_par), ctx->sh_mass);
-  if (rcu) return rcu;
-  if (ctx->with_bao)
-    hipLaunchKernelGGL(k_nu_table<true>, dim3(L.NM, (unsigned)n), dim3(64 * kNuNW), 0, ctx->stream,
-                       ctx->cfg, L, ctx->d_epochs, ctx->d_search, ctx->d_snodes, ctx->d_tab, ctx->d_status);
-  else
-    hipLaunchKernelGGL(k_nu_table<false>, dim3(L.NM, (unsigned)n), dim3(64 * kNuNW), 0, ctx->stream,
-                       ctx->cfg, L, ctx->d_epochs, ctx->d_search, ctx->d_snodes, ctx->d_tab, ctx->d_status);
-  const size_t sh = (size_t)(2 * L.NM + 8 * (L.NM - 1) + 18 * L.NM + 32 + romberg_scratch<4, 1>()) *
-                    sizeof(double);
-  hipLaunchKernelGGL(k_mass_setup, dim3((unsigned)n), dim3(256), sh, ctx->stream, ctx->cfg, L,
-                     ctx->d_epochs, ctx->d_search, ctx->d_tab, ctx->d_mass_par, mf_kind,
-                     ctx->d_tinker, ctx->d_gl16);
-  HIPCHK(hipGetLastError());
-  ctx->have_mass = true;
-  // Knot tables already built stay as they are (the reference's MassFunction.set_halo
-  // does not reset Halo._initialized_h_m / _pp_mm, halo.py:220-235).
-  return CHOMP_OK;
-}
-
-int chomp_halo_setup(chomp_ctx* ctx, const chomp_halo_par* profile,
-                     const chomp_hod_par* hod, unsigned tables) {
-  if (!ctx || !profile || !hod) return fail(ctx, CHOMP_ERR_ARG, "halo_setup: bad args");
-  if (!ctx->have_mass) return fail(ctx, CHOMP_ERR_STATE, "halo_setup before mass_setup");
-  HIPCHK(hipSetDevice(ctx->device));
-  const size_t n = ctx->n_epoch;
-  const TabLayout& L = ctx->L;
   for (size_t i = 0; i < n; ++i)
     if (profile[i].alpha != -1.0)
       return fail(ctx, CHOMP_ERR_SCOPE,
@@ -595,42 +577,124 @@ int chomp_halo_setup(chomp_ctx* ctx, const chomp_halo_par* profile,
   rcu = upload(ctx, ctx->d_hod, hd.data(), n * sizeof(HodDev), ctx->sh_hod);
   if (rcu) return rcu;
   // header bits CHOMP_T_* are (1 << F_*) by construction
-  const unsigned fam = tables & 31u;
-  const unsigned kmask = fam | ((tables & CHOMP_T_EXCLUSION) ? kMaskExclusion : 0u);
-  int groups[3] = {-1, -1, -1};
-  int ng = 0;
-  if (fam & ((1u << F_HM) | (1u << F_PPMM))) groups[ng++] = 0;
-  if (fam & ((1u << F_HG) | (1u << F_PPGM))) groups[ng++] = 1;
-  if (fam & (1u << F_PPGG)) groups[ng++] = 2;
-  if (ng == 0) groups[ng++] = 3;     // n_bar only
-  const size_t sh = (size_t)(L.NM + 8 * (L.NM - 1) + kKnotScratch) * sizeof(double);
-  hipLaunchKernelGGL(k_halo_nodes, dim3((kNodeCount + 255) / 256 + 1, (unsigned)n, ng), dim3(256),
-                     sh, ctx->stream, ctx->cfg, L, ctx->d_epochs, ctx->d_tab, ctx->d_profile,
-                     ctx->d_hod, ctx->d_sici, ctx->d_nodes, ctx->d_tab, groups[0], groups[1],
-                     groups[2], ctx->d_status);
-  if (groups[0] != 3)
-  hipLaunchKernelGGL(k_halo_knots, dim3(L.NK, (unsigned)n, ng), dim3(64 * kKnotNW), 0, ctx->stream,
-                     ctx->cfg, L, ctx->d_tab, ctx->d_sici, ctx->d_nodes, groups[0], groups[1],
-                     groups[2], kmask, ctx->d_pending, ctx->d_status);
-  if (ctx->cfg.divmax > kNodeLevel && groups[0] != 3) {
-    // blocks draw knots from the list k_halo_knots left: enough of them to fill the chip
-    // when the list is long, cheap to launch when it is empty
-    unsigned gd = (unsigned)(L.NK * n * ng);
-    if (gd > 2048) gd = 2048;
-    hipLaunchKernelGGL(k_halo_knots_fast<kDeepCoarse>, dim3(gd), dim3(256),
-                       deep_fast_lds<kDeepCoarse>(L.NM), ctx->stream, ctx->cfg, L, ctx->d_epochs,
-                       ctx->d_tab, ctx->d_profile, ctx->d_hod, ctx->d_sici, groups[0], groups[1],
-                       groups[2], kmask, (int)n, ctx->d_pending, ctx->d_status, ctx->d_deepw,
-                       ctx->tune[CHOMP_TUNE_DEEP_LITERAL] > 0 ? 1 : 0, ctx->d_deepstat);
+  P->fam = tables & 31u;
+  P->kmask = P->fam | ((tables & CHOMP_T_EXCLUSION) ? kMaskExclusion : 0u);
+  P->ng = 0;
+  if (P->fam & ((1u << F_HM) | (1u << F_PPMM))) P->groups[P->ng++] = 0;
+  if (P->fam & ((1u << F_HG) | (1u << F_PPGM))) P->groups[P->ng++] = 1;
+  if (P->fam & (1u << F_PPGG)) P->groups[P->ng++] = 2;
+  return CHOMP_OK;
+}
+
+// k_nu_table, then k_mass_nodes; plan != nullptr: the halo node tables in the same launch.
+static int launch_nu_mass(chomp_ctx* ctx, int mf_kind, const HaloPlan* plan) {
+  const size_t n = ctx->n_epoch;
+  const TabLayout& L = ctx->L;
+  if (ctx->with_bao)
+    hipLaunchKernelGGL(k_nu_table<true>, dim3(L.NM, (unsigned)n), dim3(64), 0, ctx->stream, ctx->cfg,
+                       L, ctx->d_epochs, ctx->d_search, ctx->d_snodes, ctx->d_tab, ctx->d_status);
+  else
+    hipLaunchKernelGGL(k_nu_table<false>, dim3(L.NM, (unsigned)n), dim3(64), 0, ctx->stream, ctx->cfg,
+                       L, ctx->d_epochs, ctx->d_search, ctx->d_snodes, ctx->d_tab, ctx->d_status);
+  const size_t sh = (size_t)mass_lds_doubles(L.NM) * sizeof(double);
+  const int ng = plan && plan->ng > 0 ? plan->ng : 1;
+  hipLaunchKernelGGL(k_mass_nodes, dim3((unsigned)n, (unsigned)ng), dim3(256), sh, ctx->stream,
+                     ctx->cfg, L, ctx->d_epochs, ctx->d_search, ctx->d_tab, ctx->d_mass_par, mf_kind,
+                     ctx->d_tinker, ctx->d_gl16, plan ? 1 : 0, ctx->d_profile, ctx->d_hod,
+                     ctx->d_sici, ctx->d_nodes, ctx->d_endp, plan ? plan->groups[0] : -1,
+                     plan ? plan->groups[1] : -1, plan ? plan->groups[2] : -1,
+                     plan ? plan->kmask : 0u, ctx->d_status, ctx->d_npend, ctx->d_pending);
+  HIPCHK(hipGetLastError());
+  return CHOMP_OK;
+}
+
+// The knot integrals and everything after them (k_halo_knots, k_halo_knots_fast with the
+// per-epoch finalisation).
+static int launch_halo_knots(chomp_ctx* ctx, const HaloPlan& P) {
+  const size_t n = ctx->n_epoch;
+  const TabLayout& L = ctx->L;
+  const int ng = P.ng > 0 ? P.ng : 1;
+  const unsigned kb = (unsigned)((L.NK + 3) / 4);
+  const size_t shk = (size_t)(L.NM + 8 * (L.NM - 1) + kKnotScratch) * sizeof(double);
+  hipLaunchKernelGGL(k_halo_knots, dim3(kb + (P.want_nbar ? 1u : 0u), (unsigned)n, (unsigned)ng),
+                     dim3(256), shk, ctx->stream, ctx->cfg, L, ctx->d_epochs, ctx->d_tab,
+                     ctx->d_profile, ctx->d_hod, ctx->d_sici, ctx->d_nodes, ctx->d_endp,
+                     P.groups[0], P.groups[1], P.groups[2], P.kmask, P.want_nbar, ctx->d_pending,
+                     ctx->d_npend, ctx->d_status);
+  // blocks 0..n-1 take the epochs' tokens; with integrands that can run beyond the node
+  // tables (the HOD ones) enough further blocks to fill the chip draw from the list
+  unsigned gd = (unsigned)n;
+  const bool hod_groups = P.groups[0] > 0 || P.groups[1] > 0 || P.groups[2] > 0;
+  if (hod_groups && ctx->cfg.divmax > kNodeLevel) {
+    unsigned want = (unsigned)(L.NK * n * ng);
+    if (want > 2048) want = 2048;
+    if (want > gd) gd = want;
   }
-  const size_t sh2 = (size_t)(51 * L.NK) * sizeof(double);
-  hipLaunchKernelGGL(k_halo_finalize, dim3((unsigned)n), dim3(384), sh2, ctx->stream, ctx->cfg,
-                     L, ctx->d_epochs, ctx->d_tab, ctx->d_profile, ctx->d_hod, fam, ctx->d_pending,
-                     ctx->d_status);
+  size_t shf = deep_fast_lds<kDeepCoarse>(L.NM);
+  if (shf < (size_t)finalize_lds_doubles(L.NK) * sizeof(double))
+    shf = (size_t)finalize_lds_doubles(L.NK) * sizeof(double);
+  hipLaunchKernelGGL(k_halo_knots_fast<kDeepCoarse>, dim3(gd), dim3(256), shf, ctx->stream,
+                     ctx->cfg, L, ctx->d_epochs,
+                     ctx->d_tab, ctx->d_profile, ctx->d_hod, ctx->d_sici, P.groups[0],
+                     P.groups[1], P.groups[2], P.kmask, (int)n, ctx->d_pending, ctx->d_npend,
+                     ctx->d_epochs, P.fam, ctx->d_status, ctx->d_deepw,
+                     ctx->tune[CHOMP_TUNE_DEEP_LITERAL] > 0 ? 1 : 0, ctx->d_deepstat);
   HIPCHK(hipGetLastError());
   ctx->have_halo = true;
-  ctx->fam_mask |= fam;
+  ctx->fam_mask |= P.fam;
   return CHOMP_OK;
+}
+
+int chomp_mass_setup(chomp_ctx* ctx, const chomp_halo_par* par, int mf_kind) {
+  if (!ctx || !par) return fail(ctx, CHOMP_ERR_ARG, "mass_setup: bad args");
+  if (!ctx->have_epochs) return fail(ctx, CHOMP_ERR_STATE, "mass_setup before epochs_set");
+  if (mf_kind != CHOMP_MF_ST && mf_kind != CHOMP_MF_TINKER)
+    return fail(ctx, CHOMP_ERR_ARG, "mass_setup: unknown mass function kind");
+  HIPCHK(hipSetDevice(ctx->device));
+  int rc = upload(ctx, ctx->d_mass_par, par, ctx->n_epoch * sizeof(chomp_halo_par), ctx->sh_mass);
+  if (rc) return rc;
+  rc = launch_nu_mass(ctx, mf_kind, nullptr);
+  if (rc) return rc;
+  ctx->have_mass = true;
+  // Knot tables already built stay as they are (the reference's MassFunction.set_halo
+  // does not reset Halo._initialized_h_m / _pp_mm, halo.py:220-235).
+  return CHOMP_OK;
+}
+
+int chomp_halo_setup(chomp_ctx* ctx, const chomp_halo_par* profile,
+                     const chomp_hod_par* hod, unsigned tables) {
+  if (!ctx || !profile || !hod) return fail(ctx, CHOMP_ERR_ARG, "halo_setup: bad args");
+  if (!ctx->have_mass) return fail(ctx, CHOMP_ERR_STATE, "halo_setup before mass_setup");
+  HIPCHK(hipSetDevice(ctx->device));
+  HaloPlan P;
+  int rc = halo_prepare(ctx, profile, hod, tables, &P);
+  if (rc) return rc;
+  const size_t n = ctx->n_epoch;
+  const TabLayout& L = ctx->L;
+  const size_t sh = (size_t)(L.NM + 8 * (L.NM - 1) + kKnotScratch) * sizeof(double);
+  hipLaunchKernelGGL(k_halo_nodes, dim3((unsigned)n, (unsigned)(P.ng > 0 ? P.ng : 1)), dim3(256), sh,
+                     ctx->stream, ctx->cfg, L, ctx->d_epochs, ctx->d_tab, ctx->d_profile,
+                     ctx->d_hod, ctx->d_sici, ctx->d_nodes, ctx->d_endp, P.groups[0], P.groups[1],
+                     P.groups[2], P.kmask, ctx->d_status, ctx->d_npend, ctx->d_pending);
+  return launch_halo_knots(ctx, P);
+}
+
+int chomp_stage_k(chomp_ctx* ctx, const chomp_halo_par* mass_par, int mf_kind,
+                  const chomp_halo_par* profile, const chomp_hod_par* hod, unsigned tables) {
+  if (!ctx || !mass_par || !profile || !hod) return fail(ctx, CHOMP_ERR_ARG, "stage_k: bad args");
+  if (!ctx->have_epochs) return fail(ctx, CHOMP_ERR_STATE, "stage_k before epochs_set");
+  if (mf_kind != CHOMP_MF_ST && mf_kind != CHOMP_MF_TINKER)
+    return fail(ctx, CHOMP_ERR_ARG, "stage_k: unknown mass function kind");
+  HIPCHK(hipSetDevice(ctx->device));
+  int rc = upload(ctx, ctx->d_mass_par, mass_par, ctx->n_epoch * sizeof(chomp_halo_par), ctx->sh_mass);
+  if (rc) return rc;
+  HaloPlan P;
+  rc = halo_prepare(ctx, profile, hod, tables, &P);
+  if (rc) return rc;
+  rc = launch_nu_mass(ctx, mf_kind, &P);
+  if (rc) return rc;
+  ctx->have_mass = true;
+  return launch_halo_knots(ctx, P);
 }
 
 int chomp_set_transfer(chomp_ctx* ctx, int kind) {

@@ -1,12 +1,15 @@
 // chomp_halo_kernels.h -- Stage K, second half (gfx950): the halo-model knot tables.
 //
-//   k_halo_nodes    k-independent factors of the halo integrands on the Romberg node grid,
-//                   and n_bar (halo.py:674-700)
+//   k_nu_mass       the nu table of the mass function; its per-epoch tail builds the mass
+//                   function's splines and normalisations and (chomp_stage_k) the node tables
+//   k_halo_nodes    k-independent factors of the halo integrands on the Romberg node grid
+//                   (the same node tables, for a halo set-up on its own)
 //   k_halo_knots    the 50-knot integrals h_m, pp_mm, h_g, pp_gm, pp_gg from the node tables
-//                   (halo.py:904-1086; HaloExclusion: halo.py:1201-1233)
-//   k_halo_knots_deep  the knots whose Romberg runs beyond the node tables (direct evaluation)
-//   k_halo_finalize normalisations + not-a-knot splines over ln k (halo.py:916-918,
-//                   959-961, 983-986, 1026-1029, 1072-1075)
+//                   (halo.py:904-1086; HaloExclusion: halo.py:1201-1233), and n_bar
+//                   (halo.py:674-700)
+//   k_halo_knots_fast  the knots whose Romberg runs beyond the node tables; the block that
+//                   completes an epoch goes on with its normalisations and not-a-knot
+//                   splines over ln k (halo.py:916-918, 959-961, 983-986, 1026-1029, 1072-1075)
 #pragma once
 
 #include "chomp_mass_kernels.h"
@@ -19,6 +22,10 @@ namespace chomp {
 // `norm` and divides it out again; it cancels in the relative stopping test and is
 // omitted.
 // ---------------------------------------------------------------------------
+constexpr double kPendingLevel = -1.0;   // levels-table marker: needs the deep pass
+constexpr int kPendingHead = 4;          // ints in front of the items of the work list
+constexpr unsigned kMaskExclusion = 1u << 8;   // bit of the kernels' family mask: HaloExclusion
+
 struct HaloCtx {
   const Epoch* e;
   const SiCiTab* sici;
@@ -142,8 +149,9 @@ __device__ __forceinline__ double group_lower(const Epoch& E, int group) {
   return group == 0 ? log(E.nu_min) : (group == 1 ? E.ln_nu_lo_first : E.ln_nu_lo_second);
 }
 
-// Stage what every halo-integral block needs into LDS and derive the epoch's
-// halo/HOD constants there (all threads call; ends with a barrier).
+// Stage what every halo-integral block needs into LDS (all threads call; ends with a
+// barrier).  The epoch record already carries its halo / HOD constants: the node-table stage
+// of a halo set-up writes them (halo_nodes_block).
 struct HaloLds {
   double *nu_knots, *lnm_pp, *nu_pp, *rest;
   __device__ __forceinline__ void stage(const TabLayout& L, Epoch& E, SiCiTab& S,
@@ -162,63 +170,17 @@ struct HaloLds {
     copy_doubles(nu_knots, t + L.off_nu, NM);
     copy_doubles(lnm_pp, t + L.off_lnm_pp, 4 * (NM - 1));
     copy_doubles(nu_pp, t + L.off_nu_pp, 4 * (NM - 1));
-    __syncthreads();
-    if (threadIdx.x == 0) apply_halo_hod(E, profile[e], hod[e], nu_pp, t[L.off_ln_mass], NM);
+    (void)profile; (void)hod;
     __syncthreads();
   }
 };
 
-// ---------------------------------------------------------------------------
-// k_halo_nodes: grid (ceil(kNodeCount / 256) + 1, n_epoch, n_groups), block 256: one
-// node of the (epoch, group) table per thread; the extra x-block of z == 0 does the
-// epoch's n_bar integral (halo.py:674-700).
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_halo_nodes(
-    chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs,
-    const double* __restrict__ tab, const chomp_halo_par* __restrict__ profile,
-    const HodDev* __restrict__ hod, const SiCiTab* __restrict__ sici_g,
-    double* __restrict__ nodes, double* __restrict__ tab_out, int g0, int g1, int g2,
-    unsigned* __restrict__ status) {
-  extern __shared__ __align__(16) double sm[];
-  __shared__ Epoch E;
-  __shared__ SiCiTab S;
-  const int e = blockIdx.y;
-  const int group = blockIdx.z == 0 ? g0 : (blockIdx.z == 1 ? g1 : g2);
-  const bool nbar_block = blockIdx.x == gridDim.x - 1;
-  // a new build of the knot tables: forget what the previous one reported
-  if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0) atomicAnd(&status[e], ~kStHaloBits);
-  if (nbar_block && blockIdx.z != 0) return;
-  if (!nbar_block && (group < 0 || group > 2)) return;
-  HaloLds H;
-  H.stage(L, E, S, epochs, e, tab + (size_t)e * L.stride, profile, hod, sici_g, sm);
-  if (nbar_block) {
-    HaloCtx c{&E, &S, H.nu_knots, H.lnm_pp, L.NM, 0.0, false};
-    IntegrandNbar f{c};
-    const double v = romberg1<4>(f, E.ln_nu_lo_first, log(E.nu_max), cfg.global_precision,
-                                 cfg.halo_precision, cfg.divmax, H.rest);
-    if (threadIdx.x == 0) tab_out[(size_t)e * L.stride + L.off_misc] = v;
-    return;
-  }
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= kNodeCount) return;
-  const double a = group_lower(E, group), b = log(E.nu_max);
-  if (idx == 0) {
-    double* hdr = nodes + ((size_t)e * 3 + group) * kNodeStride + kNodeFields * kNodeCount;
-    hdr[0] = a;
-    hdr[1] = b;
-  }
-  double x;
-  if (idx < 2) {
-    x = idx == 0 ? a : b;
-  } else {
-    const int m = idx - 1;
-    const int lev = 32 - __builtin_clz((unsigned)m);      // floor(log2 m) + 1
-    const long j = m - (1 << (lev - 1));
-    const double h = (b - a) / (double)(1L << (lev - 1));
-    x = (a + 0.5 * h) + h * (double)j;
-  }
+// Fields of node x = ln nu of group `group` (see kNodeFields).
+__device__ __forceinline__ void halo_node_fields(const Epoch& E, const double* nu_knots,
+                                                 const double* lnm_pp, int NM, int group,
+                                                 double x, double (&f)[kNodeFields]) {
   const double nu = exp(x);
-  const double lnm = spline_eval(H.nu_knots, H.lnm_pp, L.NM, nu);
+  const double lnm = spline_eval(nu_knots, lnm_pp, NM, nu);
   const double mass = exp(lnm);
   double nf, bias = 0.0;
   mf_node(E, nu, x, group != 2, &nf, &bias);
@@ -244,14 +206,165 @@ __global__ __launch_bounds__(256) void k_halo_nodes(
       flag = n2 < 1.0 ? 1.0 : 0.0;
     }
   }
-  double* n = nodes + ((size_t)e * 3 + group) * kNodeStride + idx;
-  n[0 * kNodeCount] = wA;
-  n[1 * kNodeCount] = wB;
-  n[2 * kNodeCount] = ln_rv - ln_c;
-  n[3 * kNodeCount] = con;
-  n[4 * kNodeCount] = ln_cp;
-  n[5 * kNodeCount] = 1.0 / (ln_cp - con / cp);
-  n[6 * kNodeCount] = flag;
+  f[0] = wA; f[1] = wB; f[2] = ln_rv - ln_c; f[3] = con; f[4] = ln_cp;
+  f[5] = 1.0 / (ln_cp - con / cp); f[6] = flag;
+}
+
+// The integrand pair of a knot at one node, from the node's fields (out[0] = wA y,
+// out[1] = wB (flag ? y : y^2); group 2 uses only out[1]).
+__device__ __forceinline__ void node_pair(const SiCiTab& S, double ln_k, bool exclusion,
+                                          double wA, double wB, double ln_rs, double con,
+                                          double ln_cp, double inv_mass_k, double flag,
+                                          double (&out)[2]) {
+  double z;             // k r_s; k * 2 r_v = 2 c z
+  const double y = y_nfw_core(S, ln_k, ln_rs, con, ln_cp, inv_mass_k, &z);
+  out[0] = wA * y;
+  if (exclusion) out[0] *= exclusion_window(S, 2.0 * con * z);
+  out[1] = wB * (flag != 0.0 ? y : y * y);
+}
+
+// The node table of one (epoch, group) by a whole block: every node of the level-kNodeLevel
+// grid over [group_lower, ln nu_max], the limits behind it, and -- so that a knot's first
+// Romberg round fills a wavefront exactly (k_halo_knots) -- the integrand pair of every
+// knot at the upper end point, endp[2 ik + {0, 1}].  E: the complete epoch record (LDS).
+__device__ __forceinline__ void halo_nodes_block(const chomp_config& cfg, const TabLayout& L,
+                                                 const Epoch& E, const SiCiTab& S,
+                                                 const double* nu_knots, const double* lnm_pp,
+                                                 int group, bool exclusion,
+                                                 double* __restrict__ node,
+                                                 double* __restrict__ endp) {
+  const double a = group_lower(E, group), b = log(E.nu_max);
+  for (int idx = threadIdx.x; idx < kNodeCount; idx += blockDim.x) {
+    double x;
+    if (idx < 2) {
+      x = idx == 0 ? a : b;
+    } else {
+      const int m = idx - 1;
+      const int lev = 32 - __builtin_clz((unsigned)m);      // floor(log2 m) + 1
+      const long j = m - (1 << (lev - 1));
+      const double h = (b - a) / (double)(1L << (lev - 1));
+      x = (a + 0.5 * h) + h * (double)j;
+    }
+    double f[kNodeFields];
+    halo_node_fields(E, nu_knots, lnm_pp, L.NM, group, x, f);
+#pragma unroll
+    for (int q = 0; q < kNodeFields; ++q) node[q * kNodeCount + idx] = f[q];
+  }
+  if (threadIdx.x == 0) {
+    node[kNodeFields * kNodeCount] = a;
+    node[kNodeFields * kNodeCount + 1] = b;
+  }
+  double fb[kNodeFields];
+  halo_node_fields(E, nu_knots, lnm_pp, L.NM, group, b, fb);   // (every thread: no exchange)
+  for (int ik = threadIdx.x; ik < L.NK; ik += blockDim.x) {
+    const double ln_k = linspace_at(log(cfg.k_min), log(cfg.k_max), L.NK, ik);
+    double o[2];
+    node_pair(S, ln_k, exclusion, fb[0], fb[1], fb[2], fb[3], fb[4], fb[5], fb[6], o);
+    endp[2 * ik] = o[0];
+    endp[2 * ik + 1] = o[1];
+  }
+}
+
+// What a halo set-up does to the state of an epoch before its knots are integrated: the
+// halo / HOD constants into the record, the status bits of the previous build cleared, the
+// completion counter of its knots armed (1: the token k_halo_knots_fast takes).
+__device__ __forceinline__ void halo_epoch_begin(Epoch& E, const chomp_halo_par& hp,
+                                                 const HodDev& h, const double* nu_pp,
+                                                 double lnm0, int NM, unsigned* status_e,
+                                                 int* npend_e, int* pending, bool first_epoch) {
+  apply_halo_hod(E, hp, h, nu_pp, lnm0, NM);
+  atomicAnd(status_e, ~kStHaloBits);
+  *npend_e = 1;
+  // the work list of the knots: emptied once per set-up, before any knot is integrated
+  // (every block of the previous set-up's k_halo_knots_fast has finished by now)
+  if (first_epoch) { pending[0] = 0; pending[1] = 0; pending[2] = 0; }
+}
+
+// ---------------------------------------------------------------------------
+// k_halo_nodes: grid (n_epoch, n_groups), block 256: chomp_halo_setup on its own (after a
+// chomp_mass_setup; the fused chomp_stage_k does the same in the tail of k_nu_mass).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_halo_nodes(
+    chomp_config cfg, TabLayout L, Epoch* __restrict__ epochs, const double* __restrict__ tab,
+    const chomp_halo_par* __restrict__ profile, const HodDev* __restrict__ hod,
+    const SiCiTab* __restrict__ sici_g, double* __restrict__ nodes, double* __restrict__ endp,
+    int g0, int g1, int g2, unsigned mask, unsigned* __restrict__ status,
+    int* __restrict__ npend, int* __restrict__ pending) {
+  extern __shared__ __align__(16) double sm[];
+  __shared__ Epoch E;
+  __shared__ SiCiTab S;
+  const int e = blockIdx.x;
+  const int group = blockIdx.y == 0 ? g0 : (blockIdx.y == 1 ? g1 : g2);
+  HaloLds H;
+  H.stage(L, E, S, epochs, e, tab + (size_t)e * L.stride, profile, hod, sici_g, sm);
+  if (threadIdx.x == 0) {
+    unsigned scratch_status = 0u;
+    int scratch_npend = 0;
+    // (every group's block derives the same constants; the first one publishes them)
+    halo_epoch_begin(E, profile[e], hod[e], H.nu_pp, tab[(size_t)e * L.stride + L.off_ln_mass],
+                     L.NM, blockIdx.y == 0 ? &status[e] : &scratch_status,
+                     blockIdx.y == 0 ? &npend[e] : &scratch_npend, pending,
+                     blockIdx.y == 0 && e == 0);
+  }
+  __syncthreads();
+  if (blockIdx.y == 0)
+    copy_doubles(reinterpret_cast<double*>(&epochs[e]), reinterpret_cast<const double*>(&E),
+                 kEpochDoubles);
+  if (group < 0 || group > 2) return;            // n_bar only: the record is all it needs
+  halo_nodes_block(cfg, L, E, S, H.nu_knots, H.lnm_pp, group, (mask & kMaskExclusion) != 0,
+                   nodes + ((size_t)e * 3 + group) * kNodeStride,
+                   endp + ((size_t)e * 3 + group) * 2 * L.NK);
+}
+
+// ---------------------------------------------------------------------------
+// k_mass_nodes: grid (n_epoch, max(n_groups, 1)), block 256.  Once the nu table of the
+// batch is complete (k_nu_table): the mass function's splines and normalisations
+// (mass_setup_block) and, with do_nodes (chomp_stage_k: the halo model follows in the same
+// call), the node table of group groups[blockIdx.y] straight from the splines still in LDS.
+// Every group's block of an epoch repeats the (cheap, latency-bound) mass function part; the
+// first one publishes it.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mass_nodes(
+    chomp_config cfg, TabLayout L, Epoch* __restrict__ epochs, const double* __restrict__ search,
+    double* __restrict__ tab, const chomp_halo_par* __restrict__ mass_par, int mf_kind,
+    const TinkerTab* __restrict__ tinker, const double* __restrict__ gl16, int do_nodes,
+    const chomp_halo_par* __restrict__ profile, const HodDev* __restrict__ hod,
+    const SiCiTab* __restrict__ sici_g, double* __restrict__ nodes, double* __restrict__ endp,
+    int g0, int g1, int g2, unsigned mask, unsigned* __restrict__ status,
+    int* __restrict__ npend, int* __restrict__ pending) {
+  extern __shared__ __align__(16) double sm[];
+  __shared__ Epoch E;
+  __shared__ SiCiTab S;
+  const int e = blockIdx.x;
+  const bool first = blockIdx.y == 0;
+  copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
+               kEpochDoubles);
+  if (do_nodes)
+    copy_doubles(reinterpret_cast<double*>(&S), reinterpret_cast<const double*>(sici_g),
+                 (int)(sizeof(SiCiTab) / sizeof(double)));
+  __syncthreads();
+  MassLds M;
+  M.carve(sm, L.NM);
+  const int n_search = (int)(search[(e * 2 + 0) * 2 + 1] + search[(e * 2 + 1) * 2 + 1]);
+  mass_setup_block(cfg, L, E, epochs, e, first, search[(e * 2 + 0) * 2], search[(e * 2 + 1) * 2],
+                   n_search, tab + (size_t)e * L.stride, mass_par[e], mf_kind, tinker, gl16, M);
+  if (!do_nodes) return;
+  if (threadIdx.x == 0) {
+    unsigned scratch_status = 0u;
+    int scratch_npend = 0;
+    halo_epoch_begin(E, profile[e], hod[e], M.c_nu, M.x_lnm[0], L.NM,
+                     first ? &status[e] : &scratch_status, first ? &npend[e] : &scratch_npend,
+                     pending, first && e == 0);
+  }
+  __syncthreads();
+  if (first)
+    copy_doubles(reinterpret_cast<double*>(&epochs[e]), reinterpret_cast<const double*>(&E),
+                 kEpochDoubles);
+  const int group = blockIdx.y == 0 ? g0 : (blockIdx.y == 1 ? g1 : g2);
+  if (group < 0 || group > 2) return;            // n_bar only: the record is all it needs
+  halo_nodes_block(cfg, L, E, S, M.y_nu, M.c_lnm, group, (mask & kMaskExclusion) != 0,
+                   nodes + ((size_t)e * 3 + group) * kNodeStride,
+                   endp + ((size_t)e * 3 + group) * 2 * L.NK);
 }
 
 // Halo.calculate_bias / calculate_m_eff / calculate_f_sat (halo.py:709-838): grid (3, n),
@@ -284,12 +397,8 @@ struct NodeIntegrand {
   bool exclusion;         // HaloExclusion (halo.py:1208-1233): window on the 2-halo term
   __device__ __forceinline__ void operator()(double, double (&out)[2], int lev, long j) const {
     const double* n = node + node_index(lev, j);
-    double z;             // k r_s; k * 2 r_v = 2 c z
-    const double y = y_nfw_core(*sici, ln_k, n[2 * kNodeCount], n[3 * kNodeCount],
-                                n[4 * kNodeCount], n[5 * kNodeCount], &z);
-    out[0] = n[0] * y;
-    if (exclusion) out[0] *= exclusion_window(*sici, 2.0 * n[3 * kNodeCount] * z);
-    out[1] = n[kNodeCount] * (n[6 * kNodeCount] != 0.0 ? y : y * y);
+    node_pair(*sici, ln_k, exclusion, n[0], n[kNodeCount], n[2 * kNodeCount], n[3 * kNodeCount],
+              n[4 * kNodeCount], n[5 * kNodeCount], n[6 * kNodeCount], out);
   }
 };
 
@@ -297,41 +406,66 @@ __device__ __forceinline__ int group_fa(int group) { return group == 0 ? F_HM : 
 __device__ __forceinline__ int group_fb(int group) {
   return group == 0 ? F_PPMM : (group == 1 ? F_PPGM : F_PPGG);
 }
-constexpr double kPendingLevel = -1.0;   // levels-table marker: needs the deep pass
-constexpr unsigned kMaskExclusion = 1u << 8;   // bit of the kernels' family mask: HaloExclusion
 
 // ---------------------------------------------------------------------------
-// k_halo_knots: grid (NK, n_epoch, n_groups), block 256 (4 wavefronts per integral
-// pair): knot ln k_i of group groups[blockIdx.z] (0: h_m + pp_mm, 1: h_g + pp_gm,
-// 2: pp_gg), Romberg levels <= kNodeLevel from the node table; integrals not
-// converged by then are marked for k_halo_knots_deep.  A block only stages the Si/Ci
-// tables: everything else it needs is in the (epoch, group) node table.
+// k_halo_knots: grid (ceil(NK / 4) [+ 1], n_epoch, n_groups), block 256 = four wavefronts,
+// each with one knot ln k_i of group groups[blockIdx.z] (0: h_m + pp_mm, 1: h_g + pp_gm,
+// 2: pp_gg): the pair's Romberg on the node table, levels <= kNodeLevel.  The first round
+// fills the wavefront exactly (romberg_wave6: lane p on node p of the level-6 grid, the
+// upper end point from the table halo_nodes_block left), so the four fifths of the knots
+// that scipy stops at level 6 or 7 cost one or two evaluations per lane.  Integrals not
+// converged at the depth of the node table are listed for k_halo_knots_fast (pending[];
+// npend[e] counts an epoch's listed knots on top of its token).  A block only stages the
+// Si/Ci tables: everything else it needs is in the (epoch, group) node table.
+// With want_nbar the extra x-block of z == 0 does the epoch's n_bar integral
+// (halo.py:674-700) beside the knots.
 // ---------------------------------------------------------------------------
-constexpr int kKnotNW = 2;
-__global__ __launch_bounds__(64 * kKnotNW) void k_halo_knots(
-    chomp_config cfg, TabLayout L, double* __restrict__ tab,
-    const SiCiTab* __restrict__ sici_g, const double* __restrict__ nodes, int g0, int g1,
-    int g2, unsigned mask, int* __restrict__ pending, unsigned* __restrict__ status) {
+__global__ __launch_bounds__(256) void k_halo_knots(
+    chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs, double* __restrict__ tab,
+    const chomp_halo_par* __restrict__ profile, const HodDev* __restrict__ hod,
+    const SiCiTab* __restrict__ sici_g, const double* __restrict__ nodes,
+    const double* __restrict__ endp, int g0, int g1, int g2, unsigned mask, int want_nbar,
+    int* __restrict__ pending, int* __restrict__ npend, unsigned* __restrict__ status) {
+  extern __shared__ __align__(16) double sm[];
   __shared__ SiCiTab S;
-  __shared__ double red[kKnotScratch];
+  __shared__ Epoch E;              // (the n_bar block only)
   const int NK = L.NK;
-  const int ik = blockIdx.x, e = blockIdx.y;
+  const int e = blockIdx.y;
+  const int kb = (NK + 3) / 4;     // knot blocks
+  if ((int)blockIdx.x >= kb) {     // ---- n_bar
+    if (!want_nbar || blockIdx.z != 0) return;
+    HaloLds H;
+    H.stage(L, E, S, epochs, e, tab + (size_t)e * L.stride, profile, hod, sici_g, sm);
+    HaloCtx c{&E, &S, H.nu_knots, H.lnm_pp, L.NM, 0.0, false};
+    IntegrandNbar f{c};
+    const double v = romberg1<4>(f, E.ln_nu_lo_first, log(E.nu_max), cfg.global_precision,
+                                 cfg.halo_precision, cfg.divmax, H.rest);
+    if (threadIdx.x == 0) tab[(size_t)e * L.stride + L.off_misc] = v;
+    return;
+  }
   const int group = blockIdx.z == 0 ? g0 : (blockIdx.z == 1 ? g1 : g2);
   if (group < 0 || group > 2) return;
   copy_doubles(reinterpret_cast<double*>(&S), reinterpret_cast<const double*>(sici_g),
                (int)(sizeof(SiCiTab) / sizeof(double)));
+  __syncthreads();
+  const int ik = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+  if (ik >= NK) return;            // (no barrier below: the wavefronts are independent)
   const double* node = nodes + ((size_t)e * 3 + group) * kNodeStride;
   const double a = node[kNodeFields * kNodeCount], b = node[kNodeFields * kNodeCount + 1];
-  __syncthreads();
+  const double* ep = endp + ((size_t)e * 3 + group) * 2 * NK + 2 * ik;
+  const double fb[2] = {ep[0], ep[1]};
   double* t = tab + (size_t)e * L.stride;
   const double ln_k = linspace_at(log(cfg.k_min), log(cfg.k_max), NK, ik);   // halo.py:52-54
   NodeIntegrand f{&S, node, ln_k, (mask & kMaskExclusion) != 0};
   const int dmax = cfg.divmax < kNodeLevel ? cfg.divmax : kNodeLevel;
-  const RombergOut<2> r = romberg_group<kKnotNW, 2>(f, a, b, cfg.global_precision,
-                                                    cfg.halo_precision, dmax, red);
-  if (threadIdx.x == 0) {
+  RombergOut<2> r;
+  if (dmax >= 6)
+    r = romberg_wave6<2>(f, a, b, fb, cfg.global_precision, cfg.halo_precision, dmax);
+  else
+    r = romberg_group<1, 2>(f, a, b, cfg.global_precision, cfg.halo_precision, dmax, nullptr);
+  if ((threadIdx.x & 63) == 0) {
     double* lev = t + L.off_levels;
-    const int fa = group_fa(group), fb = group_fb(group);
+    const int fa = group_fa(group), fb_ = group_fb(group);
     const bool more = cfg.divmax > kNodeLevel;
     if (group != 2 && (mask & (1u << fa))) {
       t[L.off_knot[fa] + ik] = r.value[0];
@@ -339,20 +473,80 @@ __global__ __launch_bounds__(64 * kKnotNW) void k_halo_knots(
     }
     bool any = false;
     if (group != 2 && (mask & (1u << fa))) any = any || (!r.converged[0] && more);
-    if (mask & (1u << fb)) {
-      t[L.off_knot[fb] + ik] = r.value[1];
-      lev[fb * NK + ik] = (!r.converged[1] && more) ? kPendingLevel : (double)r.level[1];
+    if (mask & (1u << fb_)) {
+      t[L.off_knot[fb_] + ik] = r.value[1];
+      lev[fb_ * NK + ik] = (!r.converged[1] && more) ? kPendingLevel : (double)r.level[1];
       any = any || (!r.converged[1] && more);
     }
     // divmax within the node tables: scipy returns the last row with an AccuracyWarning
     if (!more) {
       unsigned st = 0u;
       if (group != 2 && (mask & (1u << fa)) && !r.converged[0]) st |= kStHaloDivmax0 << fa;
-      if ((mask & (1u << fb)) && !r.converged[1]) st |= kStHaloDivmax0 << fb;
+      if ((mask & (1u << fb_)) && !r.converged[1]) st |= kStHaloDivmax0 << fb_;
       if (st) atomicOr(&status[e], st);
     }
-    // work list of k_halo_knots_deep: [0] items, [1] next item to hand out, [2...] items
-    if (any) pending[2 + atomicAdd(&pending[0], 1)] = (int)((blockIdx.z * gridDim.y + e) * NK + ik);
+    // work list of k_halo_knots_fast: [0] items, [1] next item to hand out, [2] epochs
+    // finalised, [kPendingHead...] items
+    if (any) {
+      atomicAdd(&npend[e], 1);
+      pending[kPendingHead + atomicAdd(&pending[0], 1)] = (int)((blockIdx.z * gridDim.y + e) * NK + ik);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// halo_finalize_block: the end of an epoch's halo set-up by a whole block of 256 threads,
+// once all its knots are final: normalise the families of fam_mask, build their not-a-knot
+// splines over ln k (the builds run in lockstep, one wavefront each, parallel cyclic
+// reduction), the Stage-E record, n_bar into the epoch record.  sm: 51 NK doubles.
+// ---------------------------------------------------------------------------
+__host__ __device__ inline int finalize_lds_doubles(int NK) { return 42 * NK; }
+__device__ __forceinline__ void halo_finalize_block(const chomp_config& cfg, const TabLayout& L,
+                                                    Epoch* __restrict__ epochs,
+                                                    double* __restrict__ tab, int e,
+                                                    unsigned fam_mask,
+                                                    unsigned* __restrict__ status, double* sm) {
+  const int NK = L.NK;
+  double* xk = sm;                      // [NK]
+  double* yk = xk + NK;                 // [5][NK]
+  double* work = yk + 5 * NK;           // [4][9 NK]
+  double* t = tab + (size_t)e * L.stride;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const double nbr = t[L.off_misc];                    // n_bar / rho_bar
+  const double rho_bar = epochs[e].rho_bar;
+  for (int i = threadIdx.x; i < NK; i += blockDim.x)
+    xk[i] = linspace_at(log(cfg.k_min), log(cfg.k_max), NK, i);
+  if (threadIdx.x == 0) {
+    // Stage-E record: amplitude of Delta^2 and "same cosmology as the previous epoch"
+    const Epoch& E = epochs[e];
+    t[L.off_misc + 1] = E.amp * E.sigma_norm * E.sigma_norm;
+    t[L.off_misc + 2] = (e > 0 && same_cosmology(E, epochs[e - 1])) ? 1.0 : 0.0;
+    epochs[e].n_bar_over_rho_bar = nbr;                // halo.py:692-700
+    epochs[e].n_bar = nbr * rho_bar;
+  }
+  for (int round = 0; round < 2; ++round) {
+    const int f = wave + 4 * round;
+    const bool active = f < 5 && ((fam_mask >> f) & 1u);
+    if (active) {
+      const double n_bar = nbr * rho_bar;
+      double scale = 1.0;
+      if (f == F_PPMM) scale = 1.0 / rho_bar;                       // halo.py:983
+      else if (f == F_HG) scale = 1.0 / nbr;                        // :959
+      else if (f == F_PPGM) scale = 1.0 / n_bar;                    // :1072
+      else if (f == F_PPGG) scale = rho_bar / (n_bar * n_bar);      // :1026
+      bool bad = false;
+      for (int i = lane; i < NK; i += 64) {
+        const double v = t[L.off_knot[f] + i] * scale;
+        yk[f * NK + i] = v;
+        t[L.off_knot[f] + i] = v;
+        bad = bad || !(fabs(v) <= 1.79769313486231570815e308);   // NaN or infinity
+      }
+      if (__any(bad) && lane == 0) atomicOr(&status[e], kStNonfinite);
+    }
+    __syncthreads();
+    const int fs = f < 5 ? f : 0;
+    spline_build_pcr(xk, yk + fs * NK, NK, t + L.off_kpp[fs], work + wave * 9 * NK, lane, 64,
+                     active);
   }
 }
 
@@ -547,12 +741,18 @@ __device__ __forceinline__ double deep_coarse_x(double a, double b, int q) {
 template <int LC>
 inline size_t deep_fast_lds(int NM) {
   constexpr int NC = 1 << LC;
-  return (size_t)(NM + 8 * (NM - 1) + kKnotScratch + 2 * (NC + 1) + kDeepWStride) * sizeof(double) +
-         (size_t)((NC + 1 + 15) & ~15);
+  const size_t deep = (size_t)(NM + 8 * (NM - 1) + kKnotScratch + 2 * (NC + 1) + kDeepWStride) *
+                          sizeof(double) + (size_t)((NC + 1 + 15) & ~15);
+  return deep;                     // (> finalize_lds_doubles(NK) for any NK <= 512 at LC >= 11)
 }
 
-// grid any (blocks draw knots from the list k_halo_knots left; an empty list costs one load
-// per block), block 256.  deepw: deep_weights_host(LC, divmax).  force_literal: evaluate
+// grid >= n_epoch (blocks draw knots from the list k_halo_knots left), block 256.  An epoch's
+// set-up ends with halo_finalize_block once all its knots are final: npend[e] counts its
+// listed knots plus one token, which block e takes first -- an epoch with nothing listed
+// (every P_mm epoch at the default precision) is finalised right there, otherwise by the
+// block that completes its last knot.  (The list is cleared by the next set-up's node-table
+// stage, halo_epoch_begin: blocks of this launch may still be polling its head.)
+// deepw: deep_weights_host(LC, divmax).  force_literal: evaluate
 // every node (chomp_set_tuning CHOMP_TUNE_DEEP_LITERAL: the checker).  stats (optional):
 // [0] knots done by the fast path, [1] by the literal one; why literal: [2] too many break
 // points, [3] too many node-by-node intervals, [4] self-check; [5] largest self-check
@@ -562,34 +762,51 @@ __global__ __launch_bounds__(256) void k_halo_knots_fast(
     chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs, double* __restrict__ tab,
     const chomp_halo_par* __restrict__ profile, const HodDev* __restrict__ hod,
     const SiCiTab* __restrict__ sici_g, int g0, int g1, int g2, unsigned mask, int n_epoch,
-    int* __restrict__ pending, unsigned* __restrict__ status, const double* __restrict__ deepw,
+    int* __restrict__ pending, int* __restrict__ npend, Epoch* __restrict__ epochs_rw,
+    unsigned fam_mask, unsigned* __restrict__ status, const double* __restrict__ deepw,
     int force_literal, int* __restrict__ stats) {
   constexpr int NC = 1 << LC;
   extern __shared__ __align__(16) double sm[];
   __shared__ Epoch E;
   __shared__ SiCiTab S;
-  __shared__ int item_sh, n_rough_sh, n_fine_sh, n_seg_sh;
+  __shared__ int item_sh, n_rough_sh, n_fine_sh, n_seg_sh, last_sh;
   __shared__ int rough_sh[kDeepMaxRough], fine_sh[kDeepMaxFine];
   __shared__ int seg_lo[kDeepMaxRough + 1], seg_hi[kDeepMaxRough + 1];
   const int NK = L.NK;
-  const int count = pending[0];
-  if (count == 0) return;          // nothing listed: no traffic on the queue head
   const int tid = threadIdx.x;
+  const int count = pending[0];
+  // One more arrival at epoch e (its token, or one of its listed knots done): whoever brings
+  // the count to zero finalises the epoch; the last of ALL arrivals clears the list.
+  auto arrive = [&](int e) {
+    __syncthreads();               // (the block's results are written)
+    if (tid == 0) {
+      __threadfence();             // ... and visible before the count moves
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      last_sh = atomicSub(&npend[e], 1) == 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (last_sh) {                 // block-uniform
+      __threadfence();
+      halo_finalize_block(cfg, L, epochs_rw, tab, e, fam_mask, status, sm);
+    }
+  };
+  if ((int)blockIdx.x < n_epoch) arrive((int)blockIdx.x);
+  if (count == 0) return;          // nothing listed: no traffic on the queue head
   for (;;) {
     __syncthreads();               // (previous item done with E, S, sm)
     if (tid == 0) item_sh = atomicAdd(&pending[1], 1);
     __syncthreads();
     if (item_sh >= count) return;  // block-uniform
-    const int item = pending[2 + item_sh];
+    const int item = pending[kPendingHead + item_sh];
     const int ik = item % NK, e = (item / NK) % n_epoch, zg = item / (NK * n_epoch);
     const int group = zg == 0 ? g0 : (zg == 1 ? g1 : g2);
-    if (group < 0 || group > 2) continue;
+    if (group < 0 || group > 2) { arrive(e); continue; }   // (never listed; keep the count right)
     double* t = tab + (size_t)e * L.stride;
     double* levs = t + L.off_levels;
     const int fa = group_fa(group), fb = group_fb(group);
     const bool pa = group != 2 && (mask & (1u << fa)) && levs[fa * NK + ik] == kPendingLevel;
     const bool pb = (mask & (1u << fb)) && levs[fb * NK + ik] == kPendingLevel;
-    if (!pa && !pb) continue;
+    if (!pa && !pb) { arrive(e); continue; }
     HaloLds H;
     H.stage(L, E, S, epochs, e, t, profile, hod, sici_g, sm);
     double* red = H.rest;
@@ -797,66 +1014,8 @@ __global__ __launch_bounds__(256) void k_halo_knots_fast(
       if (st) atomicOr(&status[e], st);
       if (stats) atomicAdd(&stats[literal ? 1 : 0], 1);
     }
+    arrive(e);
   }   // next item
-}
-
-// ---------------------------------------------------------------------------
-// k_halo_finalize: grid n_epoch, block 384 (6 wavefronts).  Wavefront f < 5
-// normalises family f and builds its not-a-knot spline over ln k (the five builds
-// run in lockstep, parallel cyclic reduction); lane 0 of wavefront 5 writes the
-// epoch's halo/HOD constants and n_bar back.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(384) void k_halo_finalize(
-    chomp_config cfg, TabLayout L, Epoch* __restrict__ epochs, double* __restrict__ tab,
-    const chomp_halo_par* __restrict__ profile, const HodDev* __restrict__ hod,
-    unsigned fam_mask, int* __restrict__ pending, unsigned* __restrict__ status) {
-  extern __shared__ __align__(16) double sm[];
-  const int NK = L.NK;
-  if (blockIdx.x == 0 && threadIdx.x == 0) { pending[0] = 0; pending[1] = 0; }
-  double* xk = sm;                      // [NK]
-  double* yk = xk + NK;                 // [5][NK]
-  double* work = yk + 5 * NK;           // [5][9 NK]
-  const int e = blockIdx.x;
-  double* t = tab + (size_t)e * L.stride;
-  const int f = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const double nbr = t[L.off_misc];                    // n_bar / rho_bar
-  const double rho_bar = epochs[e].rho_bar;            // unchanged by the write-back below
-  for (int i = threadIdx.x; i < NK; i += blockDim.x)
-    xk[i] = linspace_at(log(cfg.k_min), log(cfg.k_max), NK, i);
-  const bool active = f < 5 && ((fam_mask >> f) & 1u);
-  if (active) {
-    const double n_bar = nbr * rho_bar;
-    double scale = 1.0;
-    if (f == F_PPMM) scale = 1.0 / rho_bar;                       // halo.py:983
-    else if (f == F_HG) scale = 1.0 / nbr;                        // :959
-    else if (f == F_PPGM) scale = 1.0 / n_bar;                    // :1072
-    else if (f == F_PPGG) scale = rho_bar / (n_bar * n_bar);      // :1026
-    bool bad = false;
-    for (int i = lane; i < NK; i += 64) {
-      const double v = t[L.off_knot[f] + i] * scale;
-      yk[f * NK + i] = v;
-      t[L.off_knot[f] + i] = v;
-      bad = bad || !(fabs(v) <= 1.79769313486231570815e308);   // NaN or infinity
-    }
-    if (__any(bad) && lane == 0) atomicOr(&status[e], kStNonfinite);
-  }
-  if (f == 5 && lane == 1) {
-    // Stage-E record: amplitude of Delta^2 and "same cosmology as the previous epoch"
-    const Epoch& E = epochs[e];
-    t[L.off_misc + 1] = E.amp * E.sigma_norm * E.sigma_norm;
-    t[L.off_misc + 2] = (e > 0 && same_cosmology(E, epochs[e - 1])) ? 1.0 : 0.0;
-  }
-  if (f == 5 && lane == 0) {
-    Epoch E = epochs[e];
-    apply_halo_hod(E, profile[e], hod[e], t + L.off_nu_pp, t[L.off_ln_mass], L.NM);
-    E.n_bar_over_rho_bar = nbr;                        // halo.py:692-700
-    E.n_bar = nbr * E.rho_bar;
-    epochs[e] = E;
-  }
-  __syncthreads();
-  const int fs = f < 5 ? f : 0;
-  spline_build_pcr(xk, yk + fs * NK, NK, t + L.off_kpp[fs], work + fs * 9 * NK, lane, 64,
-                   active);
 }
 
 }  // namespace chomp

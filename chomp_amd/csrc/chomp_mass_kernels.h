@@ -5,11 +5,13 @@
 //                   sigma(R) node table, the sigma_8 integral (cosmology.py:118-119), the
 //                   coarse ln S(R) table that aims the mass-limit search, and the
 //                   closed-form part of every epoch record (cosmology.py:39-119)
-//   k_epoch_init    comoving distance + the mass-limit search of
+//   k_epoch_probe   comoving distance + the mass-limit search of
 //                   MassFunction._set_mass_limits (mass_function.py:160-203)
-//   k_nu_table      MassFunction._initialize_splines nu_m loop (mass_function.py:205-210)
-//   k_mass_setup    splines, m_star, f/bias normalisation (mass_function.py:212-241,
-//                   Tinker 532-564)
+//   k_nu_mass       MassFunction._initialize_splines nu_m loop (mass_function.py:205-210);
+//                   the last block of an epoch to finish goes on with the splines, m_star and
+//                   the f / bias normalisations (mass_function.py:212-241, Tinker 532-564)
+//                   and, when the halo model follows in the same call (chomp_stage_k), with
+//                   the node tables of the halo integrals (chomp_halo_kernels.h)
 //
 // Also here: the layout of the per-epoch table block (TabLayout) and of the node tables,
 // shared by the other kernel headers.
@@ -148,7 +150,21 @@ constexpr int kSigmaOffPart = kSigmaOffLnS + kSGrid;
 // doubles per cosmology: k[], d2[], I8 = int dlnk d2 W(8k)^2 (sigma_8 normalisation; the slot
 // after it is the arrival counter of the node blocks), ln S[], and the node blocks'
 // per-level partial sums of the sigma_8 integrand
-constexpr int kSigmaStride = kSigmaOffPart + kSigmaNodeBlocks * (kSigmaLevel + 1);
+constexpr int kSigmaOffG = kSigmaOffPart + kSigmaNodeBlocks * (kSigmaLevel + 1);
+// Outside that range of R sigma_r's limits follow R (cosmology.py:611-632) and no node table
+// can be shared; the R-independent factor of the integrand is then INTERPOLATED instead of
+// recomputed (exp, log, three divisions per node): (k/H0)^(3+n) T(k)^2 / k^6 and k itself on
+// a uniform grid of kGTabN intervals in ln k over [ln(k_min / 100), ln(100 k_max)] -- the
+// widest range sigma_r ever integrates over -- with kGTabPad extra points at either end for
+// the 6-point Lagrange stencil.  At 8192 intervals (d ln k = 2.5e-3) the interpolation error
+// is ~1e-13 relative; only the no-wiggle transfer function is smooth enough for this (the
+// BAO instances keep the direct evaluation).
+constexpr int kGTabN = 8192;
+constexpr int kGTabPad = 3;
+constexpr int kGTabCount = kGTabN + 1 + 2 * kGTabPad;
+constexpr int kGTabBlocks = (kGTabCount + 255) / 256;
+// doubles per cosmology: ..., then g / k^6 [kGTabCount] and k [kGTabCount]
+constexpr int kSigmaStride = kSigmaOffG + 2 * kGTabCount;
 
 // Everything here depends on the cosmology only, not on z, so it is built once per
 // distinct cosmology of the batch ("slot"; the z-axis of a (k, z) grid is one slot).
@@ -190,6 +206,7 @@ __global__ __launch_bounds__(256) void k_sigma_nodes(chomp_config cfg,
     return;
   }
   const int slot = blockIdx.y, e = first[slot];
+  const int nb = kSigmaNodeBlocks;                // node-table blocks
   if (threadIdx.x == 0) {
     const chomp_cosmo c = cosmo[e];
     E.om0 = c.omega_m0; E.ob0 = c.omega_b0; E.ol0 = c.omega_l0; E.or0 = c.omega_r0;
@@ -199,7 +216,18 @@ __global__ __launch_bounds__(256) void k_sigma_nodes(chomp_config cfg,
   }
   __syncthreads();
   double* n = snodes + (size_t)slot * kSigmaStride;
-  const int nb = (int)gridDim.x - kSGrid;         // node-table blocks
+  if ((int)blockIdx.x >= nb + kSGrid) {           // ---- interpolation table of the direct path
+    const int i = ((int)blockIdx.x - nb - kSGrid) * 256 + (int)threadIdx.x;
+    if (i >= kGTabCount) return;
+    const double xlo = log(cfg.k_min / 100.0), xhi = log(cfg.k_max * 100.0);
+    const double x = xlo + (xhi - xlo) * ((double)(i - kGTabPad) / (double)kGTabN);
+    const double k = exp(x);
+    const double T = transfer_t<BAO>(E, k);
+    const double k3 = k * k * k;
+    n[kSigmaOffG + i] = exp((3.0 + E.ns) * (x - E.ln_H0)) * T * T / (k3 * k3);
+    n[kSigmaOffG + kGTabCount + i] = k;
+    return;
+  }
   if ((int)blockIdx.x >= nb) {
     const int i = (int)blockIdx.x - nb;           // ln S point
     const double R = exp(make_sgrid(cfg.k_min, cfg.k_max).ln_r(i));
@@ -351,6 +379,44 @@ struct SigmaTabIntegrand {
   }
 };
 
+// The same integrand where sigma_r's limits follow R: Delta^2 W^2 with the R-independent
+// factor and k interpolated from the cosmology's uniform ln k table (kGTab*; 6-point
+// Lagrange, k through a short series of exp over the fraction of a step).
+struct SigmaInterpIntegrand {
+  const double* g;         // g / k^6 on the grid (index 0 = first pad point)
+  double xlo, dx, inv_dx;
+  double scale, amp2_nine_over_r6, amp2;
+  // k R < 1 over the whole range (wave-uniform): the window in the reference's own form
+  // 3 (sin x / x^3 - cos x / x^2), whose rounding error at x << 1 is what ends a saturated
+  // mass-limit walk (search_status); s - x c is exactly 0 there and would never end it
+  bool tiny_r;
+  __device__ __forceinline__ double operator()(double ln_k) const {
+    const double u = (ln_k - xlo) * inv_dx;
+    int i = (int)u;
+    i = i < 0 ? 0 : (i > kGTabN - 1 ? kGTabN - 1 : i);
+    const double t = u - (double)i;
+    const double* q = g + i + kGTabPad - 2;            // stencil nodes -2 .. 3 around interval i
+    const double a = t + 2.0, b = t + 1.0, d = t - 1.0, e = t - 2.0, f = t - 3.0;
+    const double ab = a * b, ef = e * f, cd = t * d;
+    const double gv = q[0] * (b * cd * ef) * (-1.0 / 120.0) + q[1] * (a * cd * ef) * (1.0 / 24.0) +
+                      q[2] * (ab * d * ef) * (-1.0 / 12.0) + q[3] * (ab * t * ef) * (1.0 / 12.0) +
+                      q[4] * (ab * cd * f) * (-1.0 / 24.0) + q[5] * (ab * cd * e) * (1.0 / 120.0);
+    const double y = t * dx;                           // <= 2.6e-3: four terms reach 1e-16
+    const double ey = fma(y, fma(y, fma(y, fma(y, 1.0 / 24.0, 1.0 / 6.0), 0.5), 1.0), 1.0);
+    const double k = q[2 + kGTabCount] * ey;
+    const double kR = scale * k;
+    double s, c;
+    fast_sincos(kR, &s, &c);
+    if (tiny_r) {
+      const double kR2 = kR * kR, k3 = k * k * k;
+      const double W = 3.0 * (s / (kR2 * kR) - c / kR2);
+      return amp2 * (gv * (k3 * k3)) * (W * W);
+    }
+    const double w = s - kR * c;
+    return amp2_nine_over_r6 * gv * (w * w);
+  }
+};
+
 // sigma^2(R) = int dlnk Delta^2 W^2 (cosmology.py:602-642) with the whole group on
 // one Romberg integral; `rtol` is cosmo_precision for reference-exact values.
 // UNROLL > 1 overlaps the table loads of several nodes (worth it where few blocks share a
@@ -371,11 +437,23 @@ __device__ __forceinline__ double sigma2_block(const Epoch& E, const double* sno
     if (converged) *converged = r.converged[0];
     return amp2 * r.value[0];
   }
-  SigmaIntegrandT<BAO> f{&E, R};
-  Scalar1<SigmaIntegrandT<BAO>> w{f};
-  const RombergOut<1> r = romberg_group<NW, 1>(w, lo, hi, cfg.global_precision, rtol, cfg.divmax, red);
-  if (converged) *converged = r.converged[0];
-  return r.value[0];
+  if constexpr (!BAO) {
+    const double xlo = log(E.k_min / 100.0), xhi = log(E.k_max * 100.0);
+    const double dx = (xhi - xlo) / (double)kGTabN;
+    const double r3 = R * R * R;
+    SigmaInterpIntegrand f{snode + kSigmaOffG, xlo, dx, 1.0 / dx, R, amp2 * 9.0 / (r3 * r3), amp2,
+                           100.0 * E.k_max * R < 1.0};
+    Scalar1<SigmaInterpIntegrand> w{f};
+    const RombergOut<1> r = romberg_group<NW, 1>(w, lo, hi, cfg.global_precision, rtol, cfg.divmax, red);
+    if (converged) *converged = r.converged[0];
+    return r.value[0];
+  } else {
+    SigmaIntegrandT<BAO> f{&E, R};
+    Scalar1<SigmaIntegrandT<BAO>> w{f};
+    const RombergOut<1> r = romberg_group<NW, 1>(w, lo, hi, cfg.global_precision, rtol, cfg.divmax, red);
+    if (converged) *converged = r.converged[0];
+    return r.value[0];
+  }
 }
 
 // Not-a-knot spline build by parallel cyclic reduction.  Every thread of the block
@@ -456,6 +534,7 @@ __device__ __forceinline__ SideThresholds side_thresholds(int side, const double
 // nu(M) at a probe: a looser Romberg tolerance first; a probe that lands within
 // kAmbiguous (in ln nu) of a band edge is redone at the reference's tolerance, so every
 // comparison that decides the stopping step is either clear of the edge or exact.
+// (One Romberg call site inside a loop: a second inlined copy costs registers.)
 template <int NW, bool BAO>
 __device__ __forceinline__ double nu_probe(const Epoch& E, const double* snode, double m,
                                            const chomp_config& cfg, double thr_lo,
@@ -463,11 +542,14 @@ __device__ __forceinline__ double nu_probe(const Epoch& E, const double* snode, 
   // (a cosmo_precision looser than the probe tolerance is used as it is: the reference's
   // decision rests on exactly that integral)
   const double kAmbiguous = 2e-5;
-  const double rtol_probe = cfg.cosmo_precision > 1e-6 ? cfg.cosmo_precision : 1e-6;
-  double nu = nu_of_mass_block<NW, 4, BAO>(E, snode, m, cfg, rtol_probe, red);
-  const double edge = fmin(fabs(log(nu / thr_lo)), fabs(log(nu / thr_hi)));
-  if (edge < kAmbiguous && cfg.cosmo_precision < rtol_probe)
-    nu = nu_of_mass_block<NW, 4, BAO>(E, snode, m, cfg, cfg.cosmo_precision, red);
+  double rtol = cfg.cosmo_precision > 1e-6 ? cfg.cosmo_precision : 1e-6;
+  double nu = 0.0;
+  for (int pass = 0; pass < 2; ++pass) {
+    nu = nu_of_mass_block<NW, 1, BAO>(E, snode, m, cfg, rtol, red);
+    const double edge = fmin(fabs(log(nu / thr_lo)), fabs(log(nu / thr_hi)));
+    if (!(edge < kAmbiguous) || !(cfg.cosmo_precision < rtol)) break;
+    rtol = cfg.cosmo_precision;
+  }
   return nu;
 }
 
@@ -535,6 +617,25 @@ __device__ double search_side_exact(const Epoch& E, const double* snode, int sid
     mass = tab[jh];
   }
   return mass;
+}
+
+// Status bits of a finished walk (chomp_get_status).  mass_min: once k R < 0.2 over sigma_r's
+// whole k range (clamped at 100 k_max, cosmology.py:627-632) the top-hat window is 1 to
+// 4e-3, nu(M) has converged to a constant -- above the band, or the walk would have ended
+// earlier -- and only the rounding error of 3 (sin x / x^3 - cos x / x^2) at small x, whose
+// variance biases sigma^2 upwards like eps^2 / x^4, ends the reference's walk: the step it
+// stops at is a property of the libm in use (DESIGN.md "Known limit of parity").  At
+// k R = 0.2 a 5 % step still moves nu by 3e-5 against a rounding error of 1e-7; a factor two
+// below that the two are equal.  mass_max: the walk ended with sigma_r's range clamped at
+// k_min / 100 (cosmology.py:617-622).
+__device__ __forceinline__ unsigned search_status(const Epoch& E, int side, double mass,
+                                                  bool exhausted) {
+  const double R = scale_of_mass(E, mass);
+  unsigned st = 0u;
+  if (side == 0 && 100.0 * E.k_max * R < 0.2) st |= kStMassMinSaturated;
+  if (side == 1 && 0.1 / R <= E.k_min / 100.0) st |= kStMassMaxSaturated;
+  if (exhausted) st |= kStSearchExhausted;
+  return st;
 }
 
 // ln S at ln R = x from the coarse table (6-point Lagrange inside one segment); NaN
@@ -622,12 +723,16 @@ __device__ __forceinline__ SidePlan plan_side(const Epoch& E, const double* lns,
 // grid (n_epoch, 2 * kProbes), block 64 * kInitNW.  blockIdx.y = kProbes * side + p
 // certifies candidate j - 2 + p of side 0 (mass_min) / 1 (mass_max); role kProbes also
 // does the comoving distance (or only that, with fixed mass limits).  The last block of
-// an epoch to finish combines the results (count[e], reset by it).  epochs[e] holds the closed-form part of
-// the record (k_sigma_nodes) on entry and the complete record on exit.
+// an epoch to finish combines the results (count[e], reset by it): a side whose probes
+// show "fails at c - 1, passes at c" is settled; any other (the estimate off by more than
+// the probes cover, a walk that leaves the ln S table: rare) falls back to the bracketing
+// secant search on exact integrals, seeded with what the probes established.
+// epochs[e] holds the closed-form part of the record (k_sigma_nodes) on entry and the
+// complete record on exit.
 constexpr int kProbes = 4;
 constexpr int kProbeStride = 24;   // doubles per epoch: nu[2][kProbes], chi, pad[3], plan[2][4]
 template <bool BAO>
-__global__ __launch_bounds__(64 * kInitNW) void k_epoch_init(
+__global__ __launch_bounds__(64 * kInitNW) void k_epoch_probe(
     chomp_config cfg, Epoch* __restrict__ epochs, double* __restrict__ search,
     const double* __restrict__ cand, const double* __restrict__ snodes,
     double* __restrict__ probe, int* __restrict__ count, unsigned* __restrict__ status) {
@@ -635,6 +740,8 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_init(
   __shared__ double red[romberg_scratch<kInitNW, 1>()];
   __shared__ double lns[kSGrid];   // the cosmology's coarse ln S(R) table
   __shared__ int last, sh_j;
+  __shared__ double seeds[2][6];   // per side: dir, jl, nu_l, jh, nu_h, n_eval (uncertified)
+  __shared__ int open_side[2];
   const int e = blockIdx.x, role = blockIdx.y;
   const bool chi_role = role == kProbes;
   const int side = role / kProbes, p = role % kProbes;
@@ -700,103 +807,106 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_init(
   }
   __syncthreads();
   if (!last) return;
-  // ---- last block of the epoch: certify both sides, exact search where that fails
+  // ---- last block of the epoch: certify both sides (thread 0: scalar logic on 8 numbers)
   __threadfence();
-  auto peek = [](const double* q) {
-    return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
-  for (int sd = 0; sd < 2; ++sd) {
-    __syncthreads();
-    const double* pl = pr + 2 * kProbes + 4 + 4 * sd;
-    const double mode = peek(pl);
-    const bool ok = mode != 0.0, at_edge = mode == 2.0;
-    int dir = (int)peek(pl + 1);
-    const int j = (int)peek(pl + 2);
-    double nu_start = peek(pl + 3);
-    const SideThresholds S = side_thresholds(sd, cand);
-    double mass = S.down[0];
-    int n_eval = 0;
-    bool certified = ok;
-    int seed_dir = 0, seed_jl = 0, seed_jh = -1;
-    double nu_l = 0.0, nu_h = 0.0;
-    bool walk = ok && dir != 0;
-    if (at_edge) {                 // the exact nu of the starting mass decides the direction
-      nu_start = peek(pr + kProbes * sd);
-      const int dir_exact = S.thr_hi < nu_start ? -1 : (S.thr_lo > nu_start ? +1 : 0);
-      n_eval = 1;
-      if (!(nu_start == nu_start)) { certified = false; walk = false; n_eval = 0; }
-      else if (dir_exact == 0) walk = false;                     // stays at the start: done
-      else if (dir_exact != dir) {                               // guessed the other way
-        certified = false; walk = false;
-        seed_dir = dir_exact; seed_jl = 0; nu_l = nu_start;
-      }
-    }
-    if (walk) {
-      const double* tab = dir < 0 ? S.down : S.up;
-      const double thr = dir < 0 ? S.thr_hi : S.thr_lo;
-      // status of candidates j - 2 .. j + 1: 0 fails, 1 passes, -1 unknown
-      int st[kProbes];
-      double nu[kProbes];
-#pragma unroll
-      for (int q = 0; q < kProbes; ++q) {
-        const int c = j - 2 + q;
-        nu[q] = peek(pr + kProbes * sd + q);
-        if (c <= 0) st[q] = 0;     // (at an edge: candidate 0 fails exactly, see above)
-        else if (!(nu[q] == nu[q])) st[q] = -1;
-        else { st[q] = (dir < 0 ? !(thr < nu[q]) : !(thr > nu[q])) ? 1 : 0; ++n_eval; }
-      }
-      certified = false;
-      int first_pass = -1, before = -1;          // status of the candidate before it
-      double nu_first = 0.0;
-#pragma unroll
-      for (int q = kProbes - 1; q >= 0; --q)
-        if (st[q] == 1) { first_pass = q; nu_first = nu[q]; before = q > 0 ? st[q - 1] : -1; }
-      if (first_pass > 0 && before == 0) {                       // fails at c - 1, passes at c
-        certified = true;
-        mass = tab[j - 2 + first_pass];
-      } else if (first_pass == 0 && j - 2 == 1) {                // passes at 1, 0 fails
-        certified = true;
-        mass = tab[1];
-      }
-      if (!certified) {            // the estimate was off by more than the probes cover:
-        seed_dir = dir;            // the exact search starts from what they established
-        seed_jl = 0; nu_l = nu_start;
-#pragma unroll
-        for (int q = 0; q < kProbes; ++q)
-          if (st[q] == 0 && j - 2 + q > 0) { seed_jl = j - 2 + q; nu_l = nu[q]; }
-        if (first_pass >= 0 && j - 2 + first_pass > seed_jl) {
-          seed_jh = j - 2 + first_pass; nu_h = nu_first;
+  if (threadIdx.x == 0) {
+    auto peek = [](const double* q) {
+      return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    for (int sd = 0; sd < 2; ++sd) {
+      const double* pl = pr + 2 * kProbes + 4 + 4 * sd;
+      const double mode = peek(pl);
+      const bool ok = mode != 0.0, at_edge = mode == 2.0;
+      const int dir = (int)peek(pl + 1);
+      const int j = (int)peek(pl + 2);
+      double nu_start = peek(pl + 3);
+      const SideThresholds S = side_thresholds(sd, cand);
+      double mass = S.down[0];
+      int n_eval = 0;
+      bool certified = ok;
+      int seed_dir = 0, seed_jl = 0, seed_jh = -1;
+      double nu_l = 0.0, nu_h = 0.0;
+      bool walk = ok && dir != 0;
+      if (at_edge) {               // the exact nu of the starting mass decides the direction
+        nu_start = peek(pr + kProbes * sd);
+        const int dir_exact = S.thr_hi < nu_start ? -1 : (S.thr_lo > nu_start ? +1 : 0);
+        n_eval = 1;
+        if (!(nu_start == nu_start)) { certified = false; walk = false; n_eval = 0; }
+        else if (dir_exact == 0) walk = false;                   // stays at the start: done
+        else if (dir_exact != dir) {                             // guessed the other way
+          certified = false; walk = false;
+          seed_dir = dir_exact; seed_jl = 0; nu_l = nu_start;
         }
       }
+      if (walk) {
+        const double* tab = dir < 0 ? S.down : S.up;
+        const double thr = dir < 0 ? S.thr_hi : S.thr_lo;
+        // status of candidates j - 2 .. j + 1: 0 fails, 1 passes, -1 unknown
+        // (scalars, not arrays: dynamic indexing would put them in scratch)
+        int st0, st1, st2, st3;
+        double nu0, nu1, nu2, nu3;
+        auto classify = [&](int q, int* st, double* nu) {
+          const int c = j - 2 + q;
+          *nu = peek(pr + kProbes * sd + q);
+          if (c <= 0) *st = 0;     // (at an edge: candidate 0 fails exactly, see above)
+          else if (!(*nu == *nu)) *st = -1;
+          else { *st = (dir < 0 ? !(thr < *nu) : !(thr > *nu)) ? 1 : 0; ++n_eval; }
+        };
+        classify(0, &st0, &nu0); classify(1, &st1, &nu1);
+        classify(2, &st2, &nu2); classify(3, &st3, &nu3);
+        certified = false;
+        int first_pass = -1, before = -1;        // status of the candidate before it
+        double nu_first = 0.0;
+        if (st3 == 1) { first_pass = 3; nu_first = nu3; before = st2; }
+        if (st2 == 1) { first_pass = 2; nu_first = nu2; before = st1; }
+        if (st1 == 1) { first_pass = 1; nu_first = nu1; before = st0; }
+        if (st0 == 1) { first_pass = 0; nu_first = nu0; before = -1; }
+        if (first_pass > 0 && before == 0) {                     // fails at c - 1, passes at c
+          certified = true;
+          mass = tab[j - 2 + first_pass];
+        } else if (first_pass == 0 && j - 2 == 1) {              // passes at 1, 0 fails
+          certified = true;
+          mass = tab[1];
+        }
+        if (!certified) {          // the estimate was off by more than the probes cover:
+          seed_dir = dir;          // the exact search starts from what they established
+          seed_jl = 0; nu_l = nu_start;
+          if (st0 == 0 && j - 2 > 0) { seed_jl = j - 2; nu_l = nu0; }
+          if (st1 == 0 && j - 1 > 0) { seed_jl = j - 1; nu_l = nu1; }
+          if (st2 == 0 && j > 0) { seed_jl = j; nu_l = nu2; }
+          if (st3 == 0 && j + 1 > 0) { seed_jl = j + 1; nu_l = nu3; }
+          if (first_pass >= 0 && j - 2 + first_pass > seed_jl) {
+            seed_jh = j - 2 + first_pass; nu_h = nu_first;
+          }
+        }
+      }
+      seeds[sd][0] = (double)seed_dir; seeds[sd][1] = (double)seed_jl; seeds[sd][2] = nu_l;
+      seeds[sd][3] = (double)seed_jh; seeds[sd][4] = nu_h; seeds[sd][5] = (double)n_eval;
+      open_side[sd] = certified ? 0 : 1;
+      if (certified) {
+        search[(e * 2 + sd) * 2 + 0] = log(mass);
+        search[(e * 2 + sd) * 2 + 1] = (double)n_eval;
+        const unsigned st = search_status(E, sd, mass, false);
+        if (st) atomicOr(&status[e], st);
+      }
     }
+    E.chi = peek(pr + 2 * kProbes);
+    count[e] = 0;
+  }
+  __syncthreads();
+  for (int sd = 0; sd < 2; ++sd) {
+    if (!open_side[sd]) continue;                // block-uniform
+    int n_eval = (int)seeds[sd][5];
     bool exhausted = false;
-    if (!certified)                // block-uniform: every thread read the same values
-      mass = search_side_exact<kInitNW, BAO>(E, snode, sd, cfg, cand, red, &n_eval, &exhausted,
-                                             seed_dir, seed_jl, nu_l, seed_jh, nu_h);
+    const double mass = search_side_exact<kInitNW, BAO>(
+        E, snode, sd, cfg, cand, red, &n_eval, &exhausted, (int)seeds[sd][0], (int)seeds[sd][1],
+        seeds[sd][2], (int)seeds[sd][3], seeds[sd][4]);
     if (threadIdx.x == 0) {
       search[(e * 2 + sd) * 2 + 0] = log(mass);
       search[(e * 2 + sd) * 2 + 1] = (double)n_eval;
-      // Where the walk ended.  mass_min: once k R < 0.2 over sigma_r's whole k range (clamped
-      // at 100 k_max, cosmology.py:627-632) the top-hat window is 1 to 4e-3, nu(M) has
-      // converged to a constant -- above the band, or the walk would have ended earlier --
-      // and only the rounding error of 3 (sin x / x^3 - cos x / x^2) at small x, whose
-      // variance biases sigma^2 upwards like eps^2 / x^4, ends the reference's walk: the step
-      // it stops at is a property of the libm in use (DESIGN.md "Known limit of parity").
-      // At k R = 0.2 a 5 % step still moves nu by 3e-5 against a rounding error of 1e-7; a
-      // factor two below that the two are equal.  The caller is told.  mass_max: the walk
-      // ended with sigma_r's range clamped at k_min / 100 (cosmology.py:617-622).
-      const double R = scale_of_mass(E, mass);
-      unsigned st = 0u;
-      if (sd == 0 && 100.0 * E.k_max * R < 0.2) st |= kStMassMinSaturated;
-      if (sd == 1 && 0.1 / R <= E.k_min / 100.0) st |= kStMassMaxSaturated;
-      if (exhausted) st |= kStSearchExhausted;
+      const unsigned st = search_status(E, sd, mass, exhausted);
       if (st) atomicOr(&status[e], st);
     }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    E.chi = peek(pr + 2 * kProbes);
-    count[e] = 0;
   }
   __syncthreads();
   copy_doubles(reinterpret_cast<double*>(&epochs[e]), reinterpret_cast<const double*>(&E),
@@ -804,27 +914,27 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_init(
 }
 
 // ---------------------------------------------------------------------------
-// k_nu_table: grid (NM, n_epoch), block 64 * kNuNW: nu_i = nu_m(exp(ln_mass_i)).
+// k_nu_table: grid (NM, n_epoch), block 64: one wavefront per sigma(R) Romberg of the nu
+// table, nu_i = nu_m(exp(ln_mass_i)) (mass_function.py:205-210).
 // ---------------------------------------------------------------------------
-constexpr int kNuNW = 1;         // wavefronts per sigma(R) integral of k_nu_table
 template <bool BAO>
-__global__ __launch_bounds__(64 * kNuNW) void k_nu_table(chomp_config cfg, TabLayout L,
-                                                  const Epoch* __restrict__ epochs,
-                                                  const double* __restrict__ search,
-                                                  const double* __restrict__ snodes,
-                                                  double* __restrict__ tab,
-                                                  unsigned* __restrict__ status) {
+__global__ __launch_bounds__(64) void k_nu_table(chomp_config cfg, TabLayout L,
+                                                 const Epoch* __restrict__ epochs,
+                                                 const double* __restrict__ search,
+                                                 const double* __restrict__ snodes,
+                                                 double* __restrict__ tab,
+                                                 unsigned* __restrict__ status) {
   __shared__ Epoch E;
-  __shared__ double red[romberg_scratch<4, 2>()];
   const int i = blockIdx.x, e = blockIdx.y;
   copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
                kEpochDoubles);
   __syncthreads();
+  const double* snode = snodes + (size_t)E.cosmo_slot * kSigmaStride;
   const double ln_lo = search[(e * 2 + 0) * 2], ln_hi = search[(e * 2 + 1) * 2];
   const double lnm = linspace_at(ln_lo, ln_hi, L.NM, i);
   bool conv = true;
-  const double nu = nu_of_mass_block<kNuNW, 1, BAO>(E, snodes + (size_t)E.cosmo_slot * kSigmaStride, exp(lnm), cfg,
-                                            cfg.cosmo_precision, red, &conv);
+  const double nu = nu_of_mass_block<1, 1, BAO>(E, snode, exp(lnm), cfg, cfg.cosmo_precision,
+                                                nullptr, &conv);
   if (threadIdx.x == 0) {
     double* t = tab + (size_t)e * L.stride;
     t[L.off_ln_mass + i] = lnm;
@@ -868,44 +978,50 @@ struct FnuBiasLn {
 };
 
 // ---------------------------------------------------------------------------
-// k_mass_setup: grid n_epoch, block 256.  Dynamic LDS: see carve-up below.
+// mass_setup_block: MassFunction._initialize_splines / _normalize for one epoch
+// (mass_function.py:212-241, Tinker 532-564) by a whole block of 256 threads, once the
+// epoch's nu table is complete.  E: the epoch record in LDS (completed here; written back
+// with the spline coefficients if `publish`); M: the LDS carve-up below, which afterwards holds the ln M grid, the nu knots and
+// the pp coefficients of nu(ln M) and ln M(nu) for whoever goes on in the same block.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_mass_setup(
-    chomp_config cfg, TabLayout L, Epoch* __restrict__ epochs,
-    const double* __restrict__ search, double* __restrict__ tab,
-    const chomp_halo_par* __restrict__ par, int mf_kind,
-    const TinkerTab* __restrict__ tinker, const double* __restrict__ gl16) {
-  extern __shared__ __align__(16) double sm[];
-  __shared__ Epoch E;
+struct MassLds {
+  double *x_lnm, *y_nu, *c_nu, *c_lnm, *work, *gl, *red;
+  __device__ __forceinline__ void carve(double* sm, int NM) {
+    x_lnm = sm;                      // [NM]
+    y_nu = x_lnm + NM;               // [NM]
+    c_nu = y_nu + NM;                // [4(NM-1)]
+    c_lnm = c_nu + 4 * (NM - 1);     // [4(NM-1)]
+    work = c_lnm + 4 * (NM - 1);     // [18 NM]
+    gl = work + 18 * NM;             // [32]
+    red = gl + 32;                   // [romberg_scratch<4, 2>()]
+  }
+};
+__host__ __device__ inline int mass_lds_doubles(int NM) {
+  return 2 * NM + 8 * (NM - 1) + 18 * NM + 32 + romberg_scratch<4, 2>();
+}
+
+__device__ __forceinline__ void mass_setup_block(
+    const chomp_config& cfg, const TabLayout& L, Epoch& E, Epoch* __restrict__ epochs, int e,
+    bool publish, double ln_mass_min, double ln_mass_max, int n_search, double* __restrict__ t,
+    const chomp_halo_par& hp, int mf_kind, const TinkerTab* __restrict__ tinker,
+    const double* __restrict__ gl16, const MassLds& M) {
   const int NM = L.NM;
-  double* x_lnm = sm;                    // [NM]
-  double* y_nu = x_lnm + NM;             // [NM]
-  double* c_nu = y_nu + NM;              // [4(NM-1)]
-  double* c_lnm = c_nu + 4 * (NM - 1);   // [4(NM-1)]
-  double* work = c_lnm + 4 * (NM - 1);   // [18 NM]
-  double* gl = work + 18 * NM;           // [32]
-  double* red = gl + 32;                 // [romberg_scratch<4, 1>()]
-  const int e = blockIdx.x;
-  double* t = tab + (size_t)e * L.stride;
-  copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
-               kEpochDoubles);
-  copy_doubles(x_lnm, t + L.off_ln_mass, NM);
-  copy_doubles(y_nu, t + L.off_nu, NM);
-  copy_doubles(gl, gl16, 32);
+  copy_doubles(M.x_lnm, t + L.off_ln_mass, NM);
+  copy_doubles(M.y_nu, t + L.off_nu, NM);
+  copy_doubles(M.gl, gl16, 32);
   __syncthreads();
   {   // nu(ln M) on threads 0..127, ln M(nu) on threads 128..255, in lockstep
     const int sys = threadIdx.x >> 7, tid = threadIdx.x & 127;
-    spline_build_pcr(sys == 0 ? x_lnm : y_nu, sys == 0 ? y_nu : x_lnm, NM,
-                     sys == 0 ? c_nu : c_lnm, work + sys * 9 * NM, tid, 128, true);
+    spline_build_pcr(sys == 0 ? M.x_lnm : M.y_nu, sys == 0 ? M.y_nu : M.x_lnm, NM,
+                     sys == 0 ? M.c_nu : M.c_lnm, M.work + sys * 9 * NM, tid, 128, true);
   }
   if (threadIdx.x == 0) {
-    const chomp_halo_par hp = par[e];
-    E.ln_mass_min = search[(e * 2 + 0) * 2];
-    E.ln_mass_max = search[(e * 2 + 1) * 2];
-    E.n_search = (int)(search[(e * 2 + 0) * 2 + 1] + search[(e * 2 + 1) * 2 + 1]);
-    E.nu_min = 1.001 * y_nu[0];                       // mass_function.py:212-213
-    E.nu_max = 0.999 * y_nu[NM - 1];
-    E.m_star = exp(spline_eval(y_nu, c_lnm, NM, 1.0));   // :223
+    E.ln_mass_min = ln_mass_min;
+    E.ln_mass_max = ln_mass_max;
+    E.n_search = n_search;
+    E.nu_min = 1.001 * M.y_nu[0];                       // mass_function.py:212-213
+    E.nu_max = 0.999 * M.y_nu[NM - 1];
+    E.m_star = exp(spline_eval(M.y_nu, M.c_lnm, NM, 1.0));   // :223
     E.stq = hp.stq;
     E.st_a = hp.st_little_a;
     E.mf_delta_v = (hp.delta_v == -1.0) ? E.delta_v : hp.delta_v;
@@ -942,10 +1058,10 @@ __global__ __launch_bounds__(256) void k_mass_setup(
     if (literal) {
       FnuLin f{&E};
       norm = romberg1<4>(f, E.nu_min, E.nu_max, cfg.global_precision, cfg.mass_precision,
-                         cfg.divmax, red);
+                         cfg.divmax, M.red);
     } else {
       FnuLn f{&E};
-      norm = gauss_panels<4>(f, a, b, 8, gl, red, flip);
+      norm = gauss_panels<4>(f, a, b, 8, M.gl, M.red, flip);
     }
     __syncthreads();
     if (threadIdx.x == 0) E.f_norm = 1.0 / norm;
@@ -956,19 +1072,20 @@ __global__ __launch_bounds__(256) void k_mass_setup(
     if (literal) {
       FnuBiasLin f{&E};
       norm = romberg1<4>(f, E.nu_min, E.nu_max, cfg.global_precision, cfg.mass_precision,
-                         cfg.divmax, red);
+                         cfg.divmax, M.red);
     } else {
       FnuBiasLn f{&E};
-      norm = gauss_panels<4>(f, a, b, 8, gl, red, flip);
+      norm = gauss_panels<4>(f, a, b, 8, M.gl, M.red, flip);
     }
     __syncthreads();
     if (threadIdx.x == 0) E.bias_norm = 1.0 / norm;
     __syncthreads();
   }
+  if (!publish) return;
   copy_doubles(reinterpret_cast<double*>(&epochs[e]), reinterpret_cast<const double*>(&E),
                kEpochDoubles);
-  copy_doubles(t + L.off_nu_pp, c_nu, 4 * (NM - 1));
-  copy_doubles(t + L.off_lnm_pp, c_lnm, 4 * (NM - 1));
+  copy_doubles(t + L.off_nu_pp, M.c_nu, 4 * (NM - 1));
+  copy_doubles(t + L.off_lnm_pp, M.c_lnm, 4 * (NM - 1));
 }
 
 }  // namespace chomp

@@ -72,8 +72,10 @@ CHOMP_HD void fast_sincos(double x, double* sp, double* cp) {
 struct SiCiTab {
   double si_ser[CHOMP_SICI_NSER];
   double ci_ser[CHOMP_SICI_NSER];
-  double f[CHOMP_FG_NINT][CHOMP_FG_NCOEF];
-  double g[CHOMP_FG_NINT][CHOMP_FG_NCOEF];
+  // (rows padded by one double: lanes in different rows then hit different LDS banks --
+  //  16-double rows put rows of equal parity on the same banks, a 4-way conflict)
+  double f[CHOMP_FG_NINT][CHOMP_FG_NCOEF + 1];
+  double g[CHOMP_FG_NINT][CHOMP_FG_NCOEF + 1];
 };
 struct BesselTab {
   double cheb[8][CHOMP_J0_NCOEF];   // J0 and J2 have the same table shape
@@ -88,11 +90,14 @@ inline void fill_tables(SiCiTab* s, BesselTab* j0, BesselTab* j2) {
     s->si_ser[i] = CHOMP_SI_SER[i];
     s->ci_ser[i] = CHOMP_CI_SER[i];
   }
-  for (int j = 0; j < CHOMP_FG_NINT; ++j)
+  for (int j = 0; j < CHOMP_FG_NINT; ++j) {
     for (int i = 0; i < CHOMP_FG_NCOEF; ++i) {
       s->f[j][i] = CHOMP_AUX_F[j][i];
       s->g[j][i] = CHOMP_AUX_G[j][i];
     }
+    s->f[j][CHOMP_FG_NCOEF] = 0.0;
+    s->g[j][CHOMP_FG_NCOEF] = 0.0;
+  }
   for (int j = 0; j < 8; ++j)
     for (int i = 0; i < CHOMP_J0_NCOEF; ++i) {
       j0->cheb[j][i] = CHOMP_J0_CHEB[j][i];

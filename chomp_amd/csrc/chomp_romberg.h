@@ -50,6 +50,10 @@ __device__ __forceinline__ double wave_sum(double v) {
   return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
 }
 
+__device__ __forceinline__ double dpp_or_shfl_xor(double v, int offset) {
+  return __shfl_xor(v, offset, 64);
+}
+
 // Sum over the group.  NW == 1: the group is one wavefront (any number of groups
 // per block, no barrier).  NW > 1: the group is the whole block (blockDim.x ==
 // 64*NW); `red` points to 2*NW doubles of LDS, `flip` alternates the two halves so
@@ -317,6 +321,125 @@ __device__ __forceinline__ RombergOut<NF> romberg_group(const F& f, double a, do
       }
     }
   }
+  return out;
+}
+
+// One wavefront per integral (or NF integrals sharing their nodes) with a first round that
+// fills it exactly: lane p evaluates node p of the level-6 grid (p = 0: the lower end point;
+// 64 intervals, 65 points) and the values at the UPPER end point are handed in (fb: the
+// caller has them from a table, e.g. one end-point evaluation per knot done elsewhere).
+// Rows 0..6 and their stopping tests are replayed from the per-level sums exactly as in
+// romberg_group's multi-wavefront first round; deeper levels walk on as romberg_group<1>.
+// A knot that scipy stops at level 6 costs one evaluation per lane, at level 7 two.
+// Needs divmax >= 6.
+template <int NF, class F>
+__device__ __forceinline__ RombergOut<NF> romberg_wave6(const F& f, double a, double b,
+                                                        const double (&fb)[NF], double tol,
+                                                        double rtol, int divmax) {
+  constexpr int L0max = 6;
+  const int lane = threadIdx.x & 63;
+  const int cl = lane & 31;
+  const double intrange = b - a;
+  double ordsum[NF], Tl[NF], prev[NF];
+  bool done[NF];
+  RombergOut<NF> out;
+  bool all_done = false;
+  auto advance = [&](int q, int i, double S, double n, double c_il) {
+    ordsum[q] += S;
+    const double Ti = intrange * ordsum[q] / n;          // R[i][0]
+    if (lane == i) Tl[q] = Ti;
+    const double cur = wave_sum(lane < 32 ? c_il * Tl[q] : 0.0);
+    const double err = fabs(cur - prev[q]);
+    prev[q] = cur;
+    out.value[q] = cur;
+    out.level[q] = i;
+    if (err < tol || err < rtol * fabs(cur)) done[q] = true;
+  };
+  constexpr int L0 = L0max, N0 = 1 << L0max;             // (the caller guarantees divmax >= 6)
+  double crow[L0max + 1];
+#pragma unroll
+  for (int i = 1; i <= L0max; ++i) crow[i] = CHOMP_ROMBERG_C[i][cl];
+  double v[NF];
+#pragma unroll
+  for (int q = 0; q < NF; ++q) v[q] = 0.0;
+  if (lane < N0) {
+    int lev = 0;
+    long j = 0;
+    double x = a;
+    if (lane > 0) {
+      const int tz = __builtin_ctz((unsigned)lane);
+      lev = L0 - tz;
+      j = (long)(((lane >> tz) - 1) >> 1);
+      const double h = intrange / (double)(1L << (lev - 1));
+      x = (a + 0.5 * h) + h * (double)j;
+    }
+    detail::call_f<F, NF>(f, x, v, lev, j, 0);
+  }
+  // C_s = sum of the interior nodes at multiples of s; level l (stride s = N0 >> l) sums to
+  // C_s - C_2s.  One xor butterfly leaves C_32 .. C_1 in lane 0 on the way.
+  double n = 1.0;
+#pragma unroll
+  for (int q = 0; q < NF; ++q) {
+    double C[7];                                         // C[st] = C_(32 >> st); C[6]: dummy
+    double x = (lane > 0 && lane < N0) ? v[q] : 0.0;
+#pragma unroll
+    for (int st = 0; st < 6; ++st) {
+      x += dpp_or_shfl_xor(x, 32 >> st);
+      C[st] = readlane_d(x, 0);
+    }
+    C[6] = 0.0;
+    ordsum[q] = 0.5 * (readlane_d(v[q], 0) + fb[q]);
+    out.value[q] = intrange * ordsum[q];
+    out.level[q] = 0;
+    prev[q] = out.value[q];
+    Tl[q] = (lane == 0) ? out.value[q] : 0.0;
+    done[q] = false;
+    // rows 1..L0 of this integrand (the integrands are independent: replaying one after the
+    // other visits the same rows as interleaving them)
+    double nq = 1.0;
+#pragma unroll
+    for (int i = 1; i <= L0max; ++i) {
+      if (!done[q]) {
+        nq *= 2.0;
+        // level i: stride 64 >> i = 32 >> (i - 1), i.e. C[i - 1] - C[i - 2] (C_64 = 0)
+        const double Cs = C[i - 1];
+        const double C2s = i >= 2 ? C[i - 2] : 0.0;
+        advance(q, i, Cs - C2s, nq, crow[i]);
+      }
+    }
+    n = nq > n ? nq : n;
+  }
+  all_done = true;
+#pragma unroll
+  for (int q = 0; q < NF; ++q) all_done = all_done && done[q];
+  // (an integrand that stopped early keeps its own n; the walk below continues from L0 for
+  //  the others, whose n is 2^L0)
+  n = (double)(1L << L0);
+  for (int i = L0 + 1; i <= divmax && !all_done; ++i) {
+    const double c_il = CHOMP_ROMBERG_C[i][cl];
+    n *= 2.0;
+    const long numtosum = 1L << (i - 1);
+    const double h = intrange / (double)numtosum;
+    const double lox = a + 0.5 * h;
+    double part[NF];
+#pragma unroll
+    for (int q = 0; q < NF; ++q) part[q] = 0.0;
+    for (long j = lane; j < numtosum; j += 64) {
+      double w[NF];
+      detail::call_f<F, NF>(f, lox + h * (double)j, w, i, j, 0);
+#pragma unroll
+      for (int q = 0; q < NF; ++q) part[q] += w[q];
+    }
+    all_done = true;
+#pragma unroll
+    for (int q = 0; q < NF; ++q) {
+      const double S = wave_sum(part[q]);
+      if (!done[q]) advance(q, i, S, n, c_il);
+      all_done = all_done && done[q];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NF; ++q) out.converged[q] = done[q];
   return out;
 }
 

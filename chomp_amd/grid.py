@@ -79,8 +79,7 @@ class HaloGrid(object):
         if len(self.idx) == 0:
             return
         self.ctx.epochs_set(self._c_cosmo, self._z)
-        self.ctx.mass_setup(self._c_halo, self.kind)
-        self.ctx.halo_setup(self._c_halo, self._c_hod, need)
+        self.ctx.stage_k(self._c_halo, self.kind, self._c_halo, self._c_hod, need)
         self._tables = need
 
     def status(self, warn=False):

@@ -140,6 +140,13 @@ int chomp_mass_setup(chomp_ctx* ctx, const chomp_halo_par* par, int mf_kind);
 int chomp_halo_setup(chomp_ctx* ctx, const chomp_halo_par* profile,
                      const chomp_hod_par* hod, unsigned tables);
 
+/* chomp_mass_setup followed by chomp_halo_setup in fewer launches (the mass function's tail
+ * and the halo model's node tables share a kernel): what a batch that always builds both --
+ * the (k, z) grid, a SimulationDesign -- calls per set-up.  Same results, bit for bit. */
+int chomp_stage_k(chomp_ctx* ctx, const chomp_halo_par* mass_par, int mf_kind,
+                  const chomp_halo_par* profile, const chomp_hod_par* hod,
+                  unsigned tables);
+
 /* HaloFit._initialize_sigma_spline (halo.py:1268-1319) for epoch `src_epoch`,
  * stored as the HaloFit coefficient set of epoch `dst_epoch`; f_1..f_3, omega_l
  * and w are passed explicitly because the reference fixes them at construction
