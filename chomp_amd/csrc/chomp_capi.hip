@@ -598,7 +598,11 @@ static int launch_nu_mass(chomp_ctx* ctx, int mf_kind, const HaloPlan* plan) {
                        L, ctx->d_epochs, ctx->d_search, ctx->d_snodes, ctx->d_tab, ctx->d_status);
   const size_t sh = (size_t)mass_lds_doubles(L.NM) * sizeof(double);
   const int ng = plan && plan->ng > 0 ? plan->ng : 1;
-  hipLaunchKernelGGL(k_mass_nodes, dim3((unsigned)n, (unsigned)ng), dim3(256), sh, ctx->stream,
+  // (node-table chunks: as many blocks per (epoch, group) as keep the launch under ~2 blocks
+  //  per CU -- below that the chip is idle anyway and each block's node loop gets shorter)
+  unsigned chunks = plan ? (unsigned)(512 / (n * ng)) : 1u;
+  chunks = chunks < 1 ? 1 : (chunks > 5 ? 5 : chunks);
+  hipLaunchKernelGGL(k_mass_nodes, dim3((unsigned)n, (unsigned)ng, chunks), dim3(256), sh, ctx->stream,
                      ctx->cfg, L, ctx->d_epochs, ctx->d_search, ctx->d_tab, ctx->d_mass_par, mf_kind,
                      ctx->d_tinker, ctx->d_gl16, plan ? 1 : 0, ctx->d_profile, ctx->d_hod,
                      ctx->d_sici, ctx->d_nodes, ctx->d_endp, plan ? plan->groups[0] : -1,
@@ -799,31 +803,32 @@ int chomp_power_range(chomp_ctx* ctx, int which, size_t epoch0, size_t n, const 
       (reinterpret_cast<uintptr_t>(dk) % 16 == 0) && (reinterpret_cast<uintptr_t>(dout) % 16 == 0)) {
     const unsigned gx = (unsigned)((nk + 511) / 512);
     const size_t groups = (nk + 127) / 128;
-    const size_t had = ctx->cap_slow;
-    rc = ensure(ctx, &ctx->d_slow, &ctx->cap_slow, groups + 2);
-    if (rc) return rc;
-    if (ctx->cap_slow != had) {                    // fresh buffer: clear both counters
-      HIPCHK(hipMemsetAsync(ctx->d_slow, 0, 2 * sizeof(int), ctx->stream));
-    }
-    // The list counters ping-pong on a host-side parity bit (a launch appends through one and
-    // clears the other for the next call).  A call captured into a HIP graph would replay ONE
-    // parity for ever and run its counter past the list, so under capture the call clears both
-    // counters itself (a memset node) and keeps the bit still.
-    int parity = ctx->slow_parity;
-    if (capturing(ctx)) ctx->slow_by_memset = true;
-    if (ctx->slow_by_memset) {       // (sticky: a graph may be replayed between any two calls)
-      HIPCHK(hipMemsetAsync(ctx->d_slow, 0, 2 * sizeof(int), ctx->stream));
-      parity = 0;
-    } else {
-      ctx->slow_parity ^= 1;
-    }
-    bool one_cosmology = true;
+    bool one_cosmology = true, streaming = true;
     for (size_t i = 1; i < n; ++i) one_cosmology &= ctx->slot[epoch0 + i] == ctx->slot[epoch0];
     const int w = which & 15;
     size_t stream_min = (size_t)1 << 22;           // samples; below this the launches dominate
     // (chomp_set_tuning: the tests force either launch shape on small grids)
     if (ctx->tune[CHOMP_TUNE_E_STREAM_MIN] >= 0) stream_min = (size_t)ctx->tune[CHOMP_TUNE_E_STREAM_MIN];
+    int parity = 0;
     if (one_cosmology && w != CHOMP_P_LIN && nk % 2 == 0 && nk * n >= stream_min) {
+      // k groups that cannot take the streaming kernel go on a compact list for the per-lane
+      // pass.  Its counters ping-pong on a host-side parity bit (a launch appends through one
+      // and clears the other for the next streaming call).  A call captured into a HIP graph
+      // would replay ONE parity for ever and run its counter past the list, so under capture
+      // the call clears both counters itself (a memset node) and keeps the bit still.
+      const size_t had = ctx->cap_slow;
+      rc = ensure(ctx, &ctx->d_slow, &ctx->cap_slow, groups + 2);
+      if (rc) return rc;
+      if (ctx->cap_slow != had)                      // fresh buffer: clear both counters
+        HIPCHK(hipMemsetAsync(ctx->d_slow, 0, 2 * sizeof(int), ctx->stream));
+      parity = ctx->slow_parity;
+      if (capturing(ctx)) ctx->slow_by_memset = true;
+      if (ctx->slow_by_memset) {     // (sticky: a graph may be replayed between any two calls)
+        HIPCHK(hipMemsetAsync(ctx->d_slow, 0, 2 * sizeof(int), ctx->stream));
+        parity = 0;
+      } else {
+        ctx->slow_parity ^= 1;
+      }
       const unsigned gx8 = (gx + 7) / 8 * 8;
       rc = ensure(ctx, &ctx->d_winfo, &ctx->cap_winfo, (size_t)gx8 * 4);
       if (rc) return rc;
@@ -870,21 +875,24 @@ int chomp_power_range(chomp_ctx* ctx, int which, size_t epoch0, size_t n, const 
       if (ctx->with_bao)
         hipLaunchKernelGGL(k_power_grid<true>, dim3(gx, gy), dim3(256), 0, ctx->stream, ctx->cfg, L,
                            ctx->d_epochs, ctx->d_tab, w, (int)epoch0, (int)n, epy, 1, dk, nk,
-                           dout, ctx->d_slow, parity);
+                           dout, ctx->d_slow, parity, 1, extrap);
       else
         hipLaunchKernelGGL(k_power_grid<false>, dim3(gx, gy), dim3(256), 0, ctx->stream, ctx->cfg, L,
                            ctx->d_epochs, ctx->d_tab, w, (int)epoch0, (int)n, epy, 1, dk, nk,
-                           dout, ctx->d_slow, parity);
+                           dout, ctx->d_slow, parity, 1, extrap);
+      streaming = false;
     }
-    // per-lane pass over the listed k groups
-    if (ctx->with_bao)
-      hipLaunchKernelGGL(k_power_grid_lanes<true>, dim3(1024), dim3(256), 0, ctx->stream, ctx->cfg,
-                         L, ctx->d_epochs, ctx->d_tab, w, extrap, (int)epoch0, (int)n, dk, nk, dout,
-                         ctx->d_slow, parity);
-    else
-      hipLaunchKernelGGL(k_power_grid_lanes<false>, dim3(1024), dim3(256), 0, ctx->stream, ctx->cfg,
-                         L, ctx->d_epochs, ctx->d_tab, w, extrap, (int)epoch0, (int)n, dk, nk, dout,
-                         ctx->d_slow, parity);
+    // per-lane pass over the listed k groups (streaming shape only)
+    if (streaming) {
+      if (ctx->with_bao)
+        hipLaunchKernelGGL(k_power_grid_lanes<true>, dim3(1024), dim3(256), 0, ctx->stream, ctx->cfg,
+                           L, ctx->d_epochs, ctx->d_tab, w, extrap, (int)epoch0, (int)n, dk, nk, dout,
+                           ctx->d_slow, parity);
+      else
+        hipLaunchKernelGGL(k_power_grid_lanes<false>, dim3(1024), dim3(256), 0, ctx->stream, ctx->cfg,
+                           L, ctx->d_epochs, ctx->d_tab, w, extrap, (int)epoch0, (int)n, dk, nk, dout,
+                           ctx->d_slow, parity);
+    }
     if (ctx->timing_valid) HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
   } else {
     unsigned gx = (unsigned)((nk + 255) / 256);

@@ -143,6 +143,52 @@ __device__ __forceinline__ void apply_halo_hod(Epoch& E, const chomp_halo_par& h
   E.ln_nu_lo_second = log(nu2);
 }
 
+// The same by one wavefront (all 64 lanes call; lane 0 writes E, which lives in LDS): the
+// logarithms, powers and spline look-ups that apply_halo_hod does one after the other are
+// independent of each other in three stages, so each stage is ONE call with a different
+// argument per lane -- the serial version is ~1500 dependent instructions on the critical
+// path of every halo set-up.  Same operations on the same arguments: identical numbers.
+__device__ __forceinline__ void apply_halo_hod_wave(Epoch& E, const chomp_halo_par& hp,
+                                                    const HodDev& h, const double* nu_pp,
+                                                    double lnm0, int NM) {
+  const int lane = threadIdx.x & 63;
+  const double c0 = hp.c0 / (1.0 + E.z);
+  const double dv = (hp.delta_v == -1.0) ? E.delta_v : hp.delta_v;
+  // stage A: five logarithms, two powers of ten, one exponential
+  const double la = lane == 0 ? 3.0 / (4.0 * kPi * dv * E.rho_bar)
+                  : lane == 1 ? c0 : lane == 2 ? E.m_star
+                  : lane == 3 ? h.first_zero : h.second_zero;
+  const double lg = log(lane < 5 ? la : 1.0);
+  const double pw = pow(10.0, lane == 0 ? h.log_M_0 : h.log_M_1p);
+  const double mass_min = exp(E.ln_mass_min);
+  const double ln_a0 = readlane_d(lg, 0), ln_c0 = readlane_d(lg, 1), ln_mstar = readlane_d(lg, 2);
+  // stage B: nu at the two zeros of the HOD moments (lanes 0, 1)
+  const double dlnm = (E.ln_mass_max - E.ln_mass_min) / (double)(NM - 1);
+  const double zero = lane == 0 ? h.first_zero : h.second_zero;
+  const double ln_zero = lane == 0 ? readlane_d(lg, 3) : readlane_d(lg, 4);
+  double nu = E.nu_min;
+  if (zero > -1.0 && zero > mass_min) nu = spline_eval_uniform(lnm0, dlnm, nu_pp, NM, ln_zero);
+  // stage C: their logarithms
+  const double ln_nu = log(nu);
+  const double ln_nu1 = readlane_d(ln_nu, 0), ln_nu2 = readlane_d(ln_nu, 1);
+  const double M0 = readlane_d(pw, 0), M1p = readlane_d(pw, 1);
+  if (lane == 0) {
+    E.c0 = c0;
+    E.beta = hp.beta;
+    E.prof_delta_v = dv;
+    E.ln_rv_const = ln_a0;
+    E.ln_c_const = ln_c0 - E.beta * ln_mstar;
+    E.hod_log_M_min = h.log_M_min; E.hod_sigma = h.sigma; E.hod_log_M_0 = h.log_M_0;
+    E.hod_log_M_1p = h.log_M_1p; E.hod_alpha = h.alpha;
+    E.hod_first_zero = h.first_zero; E.hod_second_zero = h.second_zero;
+    E.hod_safe_norm = h.safe_norm;
+    E.hod_M0 = M0;
+    E.hod_M1p = M1p;
+    E.ln_nu_lo_first = ln_nu1;
+    E.ln_nu_lo_second = ln_nu2;
+  }
+}
+
 // Lower limit of group g's integrals: 0: nu_min; 1: nu(first_moment_zero); 2:
 // nu(second_moment_zero) (halo.py:909-911, 935-939, 1002-1006).
 __device__ __forceinline__ double group_lower(const Epoch& E, int group) {
@@ -232,9 +278,12 @@ __device__ __forceinline__ void halo_nodes_block(const chomp_config& cfg, const 
                                                  const double* nu_knots, const double* lnm_pp,
                                                  int group, bool exclusion,
                                                  double* __restrict__ node,
-                                                 double* __restrict__ endp) {
+                                                 double* __restrict__ endp, int chunk = 0,
+                                                 int n_chunks = 1) {
   const double a = group_lower(E, group), b = log(E.nu_max);
-  for (int idx = threadIdx.x; idx < kNodeCount; idx += blockDim.x) {
+  // (chunk c of n: nodes c, c + n, c + 2 n, ... dealt to the threads; knots likewise)
+  for (int idx = chunk + n_chunks * (int)threadIdx.x; idx < kNodeCount;
+       idx += n_chunks * (int)blockDim.x) {
     double x;
     if (idx < 2) {
       x = idx == 0 ? a : b;
@@ -250,13 +299,14 @@ __device__ __forceinline__ void halo_nodes_block(const chomp_config& cfg, const 
 #pragma unroll
     for (int q = 0; q < kNodeFields; ++q) node[q * kNodeCount + idx] = f[q];
   }
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && chunk == 0) {
     node[kNodeFields * kNodeCount] = a;
     node[kNodeFields * kNodeCount + 1] = b;
   }
+  if (chunk + n_chunks * (int)threadIdx.x >= L.NK) return;
   double fb[kNodeFields];
   halo_node_fields(E, nu_knots, lnm_pp, L.NM, group, b, fb);   // (every thread: no exchange)
-  for (int ik = threadIdx.x; ik < L.NK; ik += blockDim.x) {
+  for (int ik = chunk + n_chunks * (int)threadIdx.x; ik < L.NK; ik += n_chunks * (int)blockDim.x) {
     const double ln_k = linspace_at(log(cfg.k_min), log(cfg.k_max), L.NK, ik);
     double o[2];
     node_pair(S, ln_k, exclusion, fb[0], fb[1], fb[2], fb[3], fb[4], fb[5], fb[6], o);
@@ -272,7 +322,9 @@ __device__ __forceinline__ void halo_epoch_begin(Epoch& E, const chomp_halo_par&
                                                  const HodDev& h, const double* nu_pp,
                                                  double lnm0, int NM, unsigned* status_e,
                                                  int* npend_e, int* pending, bool first_epoch) {
-  apply_halo_hod(E, hp, h, nu_pp, lnm0, NM);
+  // (called by the 64 lanes of one wavefront)
+  apply_halo_hod_wave(E, hp, h, nu_pp, lnm0, NM);
+  if ((threadIdx.x & 63) != 0) return;
   atomicAnd(status_e, ~kStHaloBits);
   *npend_e = 1;
   // the work list of the knots: emptied once per set-up, before any knot is integrated
@@ -297,9 +349,9 @@ __global__ __launch_bounds__(256) void k_halo_nodes(
   const int group = blockIdx.y == 0 ? g0 : (blockIdx.y == 1 ? g1 : g2);
   HaloLds H;
   H.stage(L, E, S, epochs, e, tab + (size_t)e * L.stride, profile, hod, sici_g, sm);
-  if (threadIdx.x == 0) {
-    unsigned scratch_status = 0u;
-    int scratch_npend = 0;
+  __shared__ unsigned scratch_status;
+  __shared__ int scratch_npend;
+  if (threadIdx.x < 64) {
     // (every group's block derives the same constants; the first one publishes them)
     halo_epoch_begin(E, profile[e], hod[e], H.nu_pp, tab[(size_t)e * L.stride + L.off_ln_mass],
                      L.NM, blockIdx.y == 0 ? &status[e] : &scratch_status,
@@ -317,12 +369,12 @@ __global__ __launch_bounds__(256) void k_halo_nodes(
 }
 
 // ---------------------------------------------------------------------------
-// k_mass_nodes: grid (n_epoch, max(n_groups, 1)), block 256.  Once the nu table of the
-// batch is complete (k_nu_table): the mass function's splines and normalisations
+// k_mass_nodes: grid (n_epoch, max(n_groups, 1), n_chunks), block 256.  Once the nu table of
+// the batch is complete (k_nu_table): the mass function's splines and normalisations
 // (mass_setup_block) and, with do_nodes (chomp_stage_k: the halo model follows in the same
-// call), the node table of group groups[blockIdx.y] straight from the splines still in LDS.
-// Every group's block of an epoch repeats the (cheap, latency-bound) mass function part; the
-// first one publishes it.
+// call), chunk blockIdx.z of the node table of group groups[blockIdx.y] straight from the
+// splines still in LDS.  Every block of an epoch repeats the mass function part (cheap, a
+// latency chain, and the chip is otherwise idle here); the first one publishes it.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_mass_nodes(
     chomp_config cfg, TabLayout L, Epoch* __restrict__ epochs, const double* __restrict__ search,
@@ -336,7 +388,9 @@ __global__ __launch_bounds__(256) void k_mass_nodes(
   __shared__ Epoch E;
   __shared__ SiCiTab S;
   const int e = blockIdx.x;
-  const bool first = blockIdx.y == 0;
+  const bool first = blockIdx.y == 0 && blockIdx.z == 0;
+  __shared__ unsigned scratch_status;
+  __shared__ int scratch_npend;
   copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
                kEpochDoubles);
   if (do_nodes)
@@ -349,13 +403,10 @@ __global__ __launch_bounds__(256) void k_mass_nodes(
   mass_setup_block(cfg, L, E, epochs, e, first, search[(e * 2 + 0) * 2], search[(e * 2 + 1) * 2],
                    n_search, tab + (size_t)e * L.stride, mass_par[e], mf_kind, tinker, gl16, M);
   if (!do_nodes) return;
-  if (threadIdx.x == 0) {
-    unsigned scratch_status = 0u;
-    int scratch_npend = 0;
+  if (threadIdx.x < 64)
     halo_epoch_begin(E, profile[e], hod[e], M.c_nu, M.x_lnm[0], L.NM,
                      first ? &status[e] : &scratch_status, first ? &npend[e] : &scratch_npend,
                      pending, first && e == 0);
-  }
   __syncthreads();
   if (first)
     copy_doubles(reinterpret_cast<double*>(&epochs[e]), reinterpret_cast<const double*>(&E),
@@ -364,7 +415,7 @@ __global__ __launch_bounds__(256) void k_mass_nodes(
   if (group < 0 || group > 2) return;            // n_bar only: the record is all it needs
   halo_nodes_block(cfg, L, E, S, M.y_nu, M.c_lnm, group, (mask & kMaskExclusion) != 0,
                    nodes + ((size_t)e * 3 + group) * kNodeStride,
-                   endp + ((size_t)e * 3 + group) * 2 * L.NK);
+                   endp + ((size_t)e * 3 + group) * 2 * L.NK, (int)blockIdx.z, (int)gridDim.z);
 }
 
 // Halo.calculate_bias / calculate_m_eff / calculate_f_sat (halo.py:709-838): grid (3, n),
@@ -524,7 +575,8 @@ __device__ __forceinline__ void halo_finalize_block(const chomp_config& cfg, con
     epochs[e].n_bar_over_rho_bar = nbr;                // halo.py:692-700
     epochs[e].n_bar = nbr * rho_bar;
   }
-  for (int round = 0; round < 2; ++round) {
+  const int rounds = (fam_mask >> 4) ? 2 : 1;          // (family 4 = pp_gg is the only one of round 1)
+  for (int round = 0; round < rounds; ++round) {
     const int f = wave + 4 * round;
     const bool active = f < 5 && ((fam_mask >> f) & 1u);
     if (active) {
@@ -777,20 +829,26 @@ __global__ __launch_bounds__(256) void k_halo_knots_fast(
   const int count = pending[0];
   // One more arrival at epoch e (its token, or one of its listed knots done): whoever brings
   // the count to zero finalises the epoch; the last of ALL arrivals clears the list.
-  auto arrive = [&](int e) {
+  // (with an empty list no block of this launch writes a knot: every value the finalisation
+  //  reads comes from the previous launch, and no fence is needed)
+  const bool fences = count != 0;
+  auto arrive = [&](int e, bool token) {
+    (void)token;
     __syncthreads();               // (the block's results are written)
     if (tid == 0) {
-      __threadfence();             // ... and visible before the count moves
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (fences) {
+        __threadfence();           // ... and visible before the count moves
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       last_sh = atomicSub(&npend[e], 1) == 1 ? 1 : 0;
     }
     __syncthreads();
     if (last_sh) {                 // block-uniform
-      __threadfence();
+      if (fences) __threadfence();
       halo_finalize_block(cfg, L, epochs_rw, tab, e, fam_mask, status, sm);
     }
   };
-  if ((int)blockIdx.x < n_epoch) arrive((int)blockIdx.x);
+  if ((int)blockIdx.x < n_epoch) arrive((int)blockIdx.x, true);
   if (count == 0) return;          // nothing listed: no traffic on the queue head
   for (;;) {
     __syncthreads();               // (previous item done with E, S, sm)
@@ -800,13 +858,13 @@ __global__ __launch_bounds__(256) void k_halo_knots_fast(
     const int item = pending[kPendingHead + item_sh];
     const int ik = item % NK, e = (item / NK) % n_epoch, zg = item / (NK * n_epoch);
     const int group = zg == 0 ? g0 : (zg == 1 ? g1 : g2);
-    if (group < 0 || group > 2) { arrive(e); continue; }   // (never listed; keep the count right)
+    if (group < 0 || group > 2) { arrive(e, false); continue; }   // (never listed; keep the count right)
     double* t = tab + (size_t)e * L.stride;
     double* levs = t + L.off_levels;
     const int fa = group_fa(group), fb = group_fb(group);
     const bool pa = group != 2 && (mask & (1u << fa)) && levs[fa * NK + ik] == kPendingLevel;
     const bool pb = (mask & (1u << fb)) && levs[fb * NK + ik] == kPendingLevel;
-    if (!pa && !pb) { arrive(e); continue; }
+    if (!pa && !pb) { arrive(e, false); continue; }
     HaloLds H;
     H.stage(L, E, S, epochs, e, t, profile, hod, sici_g, sm);
     double* red = H.rest;
@@ -1014,7 +1072,7 @@ __global__ __launch_bounds__(256) void k_halo_knots_fast(
       if (st) atomicOr(&status[e], st);
       if (stats) atomicAdd(&stats[literal ? 1 : 0], 1);
     }
-    arrive(e);
+    arrive(e, false);
   }   // next item
 }
 

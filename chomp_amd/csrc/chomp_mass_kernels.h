@@ -424,7 +424,8 @@ struct SigmaInterpIntegrand {
 template <int NW, int UNROLL = 1, bool BAO = false>
 __device__ __forceinline__ double sigma2_block(const Epoch& E, const double* snode, double R,
                                                const chomp_config& cfg, double rtol,
-                                               double* red, bool* converged = nullptr) {
+                                               double* red, bool* converged = nullptr,
+                                               const RombergLoose* loose = nullptr) {
   double lo, hi;
   sigma_limits(E, R, &lo, &hi);
   const double need_min = 1.0 / R / 10.0, need_max = 1.0 / R * 14.0662;
@@ -432,8 +433,11 @@ __device__ __forceinline__ double sigma2_block(const Epoch& E, const double* sno
   if (need_min > E.k_min && need_max < E.k_max) {          // fixed range: table path
     const double r3 = R * R * R;
     SigmaTabIntegrand<BAO> f{&E, snode, R, 1.0 / amp2, 9.0 / (r3 * r3)};
+    RombergLoose ls{0.0, 0.0, 0.0, 0.0, 0.0};          // (the integral is sigma^2 / amp2 here)
+    if (loose) ls = RombergLoose{loose->rtol, loose->lo1 / amp2, loose->hi1 / amp2,
+                                 loose->lo2 / amp2, loose->hi2 / amp2};
     const RombergOut<1> r = romberg_group<NW, 1, SigmaTabIntegrand<BAO>, UNROLL>(
-        f, lo, hi, cfg.global_precision, rtol, cfg.divmax, red);
+        f, lo, hi, cfg.global_precision, rtol, cfg.divmax, red, nullptr, loose ? &ls : nullptr);
     if (converged) *converged = r.converged[0];
     return amp2 * r.value[0];
   }
@@ -444,13 +448,15 @@ __device__ __forceinline__ double sigma2_block(const Epoch& E, const double* sno
     SigmaInterpIntegrand f{snode + kSigmaOffG, xlo, dx, 1.0 / dx, R, amp2 * 9.0 / (r3 * r3), amp2,
                            100.0 * E.k_max * R < 1.0};
     Scalar1<SigmaInterpIntegrand> w{f};
-    const RombergOut<1> r = romberg_group<NW, 1>(w, lo, hi, cfg.global_precision, rtol, cfg.divmax, red);
+    const RombergOut<1> r = romberg_group<NW, 1>(w, lo, hi, cfg.global_precision, rtol, cfg.divmax, red,
+                                                 nullptr, loose);
     if (converged) *converged = r.converged[0];
     return r.value[0];
   } else {
     SigmaIntegrandT<BAO> f{&E, R};
     Scalar1<SigmaIntegrandT<BAO>> w{f};
-    const RombergOut<1> r = romberg_group<NW, 1>(w, lo, hi, cfg.global_precision, rtol, cfg.divmax, red);
+    const RombergOut<1> r = romberg_group<NW, 1>(w, lo, hi, cfg.global_precision, rtol, cfg.divmax, red,
+                                                 nullptr, loose);
     if (converged) *converged = r.converged[0];
     return r.value[0];
   }
@@ -492,9 +498,10 @@ template <int NW, int UNROLL = 1, bool BAO = false>
 __device__ __forceinline__ double nu_of_mass_block(const Epoch& E, const double* snode,
                                                    double mass, const chomp_config& cfg,
                                                    double rtol, double* red,
-                                                   bool* converged = nullptr) {
+                                                   bool* converged = nullptr,
+                                                   const RombergLoose* loose = nullptr) {
   const double s2 = sigma2_block<NW, UNROLL, BAO>(E, snode, scale_of_mass(E, mass), cfg, rtol, red,
-                                                  converged);
+                                                  converged, loose);
   const double sq = E.delta_c / sqrt(s2);
   return sq * sq;
 }
@@ -531,26 +538,27 @@ __device__ __forceinline__ SideThresholds side_thresholds(int side, const double
   return t;
 }
 
-// nu(M) at a probe: a looser Romberg tolerance first; a probe that lands within
-// kAmbiguous (in ln nu) of a band edge is redone at the reference's tolerance, so every
-// comparison that decides the stopping step is either clear of the edge or exact.
-// (One Romberg call site inside a loop: a second inlined copy costs registers.)
+// nu(M) at a probe.  The probe only has to decide on which side of the band edges nu lies,
+// so the Romberg may stop at a looser tolerance as soon as its result is clear of both edges
+// by kAmbiguous (in ln nu); a result within that of an edge walks on to the reference's
+// tolerance (RombergLoose: the same rows, no second integral), so every comparison that
+// decides the stopping step is either clear of the edge or exact.
 template <int NW, bool BAO>
-__device__ __forceinline__ double nu_probe(const Epoch& E, const double* snode, double m,
+__device__ __noinline__ double nu_probe(const Epoch& E, const double* snode, double m,
                                            const chomp_config& cfg, double thr_lo,
                                            double thr_hi, double* red) {
   // (a cosmo_precision looser than the probe tolerance is used as it is: the reference's
   // decision rests on exactly that integral)
   const double kAmbiguous = 2e-5;
-  double rtol = cfg.cosmo_precision > 1e-6 ? cfg.cosmo_precision : 1e-6;
-  double nu = 0.0;
-  for (int pass = 0; pass < 2; ++pass) {
-    nu = nu_of_mass_block<NW, 1, BAO>(E, snode, m, cfg, rtol, red);
-    const double edge = fmin(fabs(log(nu / thr_lo)), fabs(log(nu / thr_hi)));
-    if (!(edge < kAmbiguous) || !(cfg.cosmo_precision < rtol)) break;
-    rtol = cfg.cosmo_precision;
-  }
-  return nu;
+  const double rtol_probe = 1e-6;
+  if (!(cfg.cosmo_precision < rtol_probe))
+    return nu_of_mass_block<NW, 1, BAO>(E, snode, m, cfg, cfg.cosmo_precision, red);
+  // nu = delta_c^2 / sigma^2: the windows in sigma^2
+  const double d2 = E.delta_c * E.delta_c;
+  const double up = 1.0 + kAmbiguous, dn = 1.0 - kAmbiguous;
+  const RombergLoose loose{rtol_probe, d2 / thr_hi * dn, d2 / thr_hi * up, d2 / thr_lo * dn,
+                           d2 / thr_lo * up};
+  return nu_of_mass_block<NW, 1, BAO>(E, snode, m, cfg, cfg.cosmo_precision, red, nullptr, &loose);
 }
 
 // The bracketing secant search on exact integrals (whole block).  Returns the mass the
@@ -675,41 +683,59 @@ __device__ __forceinline__ SidePlan plan_side(const Epoch& E, const double* lns,
   const SideThresholds T = side_thresholds(side, cand);
   const SGrid G = make_sgrid(E.k_min, E.k_max);
   const double margin = 1e-2;             // estimate error ~1e-4; candidates are >= 0.4 % apart
+  const double ln_margin = 0.00995033085; // ln(1 + margin)
   SidePlan P{false, 0, 0, 0.0, false};
   // ln nu = ln_nu_c - ln S(ln R); the candidates are M_0 * 1.05^(-+j), so ln R moves by
-  // ln(1.05) / 3 per step (to the estimate's accuracy)
-  const double ln_nu_c = log(E.delta_c * E.delta_c / (E.amp * E.sigma_norm * E.sigma_norm));
-  const double x0 = log(scale_of_mass(E, T.down[0]));
+  // ln(1.05) / 3 per step (to the estimate's accuracy).  The four logarithms this needs are
+  // one call with a different argument in each of four lanes.
+  const int lane = threadIdx.x & 63;
+  const double arg = lane == 0 ? E.delta_c * E.delta_c / (E.amp * E.sigma_norm * E.sigma_norm)
+                   : lane == 1 ? 3.0 * T.down[0] / (4.0 * kPi * E.rho_bar)
+                   : lane == 2 ? T.thr_hi : T.thr_lo;
+  const double lg = log(arg);
+  const double ln_nu_c = readlane_d(lg, 0), x0 = readlane_d(lg, 1) * (1.0 / 3.0);
+  const double ln_hi = readlane_d(lg, 2), ln_lo = readlane_d(lg, 3);
   const double step = 0.016263388 /* ln(1.05) / 3 */;
-  const double nu0 = exp(ln_nu_c - ln_s_estimate(G, lns, x0));
-  P.nu_start = nu0;
-  if (!(nu0 == nu0)) return P;
-  if (nu0 > T.thr_hi * (1.0 + margin)) P.dir = -1;
-  else if (nu0 < T.thr_lo * (1.0 - margin)) P.dir = +1;
-  else if (nu0 >= T.thr_lo * (1.0 + margin) && nu0 <= T.thr_hi * (1.0 - margin)) {
+  const double ln_nu0 = ln_nu_c - ln_s_estimate(G, lns, x0);
+  P.nu_start = exp(ln_nu0);
+  if (!(ln_nu0 == ln_nu0)) return P;
+  if (ln_nu0 > ln_hi + ln_margin) P.dir = -1;
+  else if (ln_nu0 < ln_lo - ln_margin) P.dir = +1;
+  else if (ln_nu0 >= ln_lo + ln_margin && ln_nu0 <= ln_hi - ln_margin) {
     P.ok = true;                          // inside the band with room to spare
     return P;
   } else {                                // on an edge: probe the start and its neighbours
     P.ok = true;
     P.at_edge = true;
-    P.dir = nu0 > 0.5 * (T.thr_lo + T.thr_hi) ? -1 : +1;
+    P.dir = P.nu_start > 0.5 * (T.thr_lo + T.thr_hi) ? -1 : +1;
     P.j = 2;
     return P;
   }
-  const double ln_thr = log(P.dir < 0 ? T.thr_hi : T.thr_lo);
+  (void)margin;
+  const double ln_thr = P.dir < 0 ? ln_hi : ln_lo;
+  // nu is monotone along the table, so the first passing index is the minimum over the
+  // passing ones; a candidate outside the ln S table counts as passing, and is rejected
+  // below if it turns out to be the first.  Two rounds: every (kSearchJ / 256)-th candidate,
+  // then the candidates between the last failing and the first passing one of those.
+  auto passes = [&](int j) {
+    const double ln_nu = ln_nu_c - ln_s_estimate(G, lns, x0 + (double)(P.dir * j) * step);
+    return !(ln_nu == ln_nu) || (P.dir < 0 ? !(ln_thr < ln_nu) : !(ln_thr > ln_nu));
+  };
+  constexpr int kStride = kSearchJ / 256;
   __syncthreads();
   if (threadIdx.x == 0) *sh = kSearchJ;
   __syncthreads();
-  // nu is monotone along the table, so the first passing index is the minimum over the
-  // passing ones; a candidate outside the ln S table counts as passing, and is rejected
-  // below if it turns out to be the first.
-  int mine = kSearchJ;
-  for (int j = 1 + (int)threadIdx.x; j < kSearchJ; j += blockDim.x) {
-    const double ln_nu = ln_nu_c - ln_s_estimate(G, lns, x0 + (double)(P.dir * j) * step);
-    const bool pass = !(ln_nu == ln_nu) || (P.dir < 0 ? !(ln_thr < ln_nu) : !(ln_thr > ln_nu));
-    if (pass) { mine = j; break; }               // (ascending j: the first is the smallest)
+  {
+    const int j = kStride * (1 + (int)threadIdx.x) - 1;        // 7, 15, ..., 2047
+    if (j < kSearchJ && passes(j)) atomicMin(sh, j);
   }
-  if (mine < kSearchJ) atomicMin(sh, mine);
+  __syncthreads();
+  const int jc = *sh;                     // first passing coarse candidate (or kSearchJ)
+  __syncthreads();
+  if (jc < kSearchJ && (int)threadIdx.x < kStride - 1) {
+    const int j = jc - (kStride - 1) + (int)threadIdx.x;       // jc - 7 .. jc - 1
+    if (j >= 1 && passes(j)) atomicMin(sh, j);
+  }
   __syncthreads();
   const int j = *sh;
   if (j >= kSearchJ) return P;                   // nothing passes: exact search
@@ -1053,32 +1079,44 @@ __device__ __forceinline__ void mass_setup_block(
   int flip = 0;
   const bool literal = cfg.divmax < kNormLiteralDivmax;
   const double a = log(E.nu_min), b = log(E.nu_max);
-  if (mf_kind == CHOMP_MF_ST) {
-    double norm;
-    if (literal) {
+  if (literal) {
+    if (mf_kind == CHOMP_MF_ST) {
       FnuLin f{&E};
-      norm = romberg1<4>(f, E.nu_min, E.nu_max, cfg.global_precision, cfg.mass_precision,
-                         cfg.divmax, M.red);
-    } else {
-      FnuLn f{&E};
-      norm = gauss_panels<4>(f, a, b, 8, M.gl, M.red, flip);
+      const double norm = romberg1<4>(f, E.nu_min, E.nu_max, cfg.global_precision,
+                                      cfg.mass_precision, cfg.divmax, M.red);
+      __syncthreads();
+      if (threadIdx.x == 0) E.f_norm = 1.0 / norm;
+      __syncthreads();
     }
-    __syncthreads();
-    if (threadIdx.x == 0) E.f_norm = 1.0 / norm;
-    __syncthreads();
-  }
-  {
-    double norm;
-    if (literal) {
-      FnuBiasLin f{&E};
-      norm = romberg1<4>(f, E.nu_min, E.nu_max, cfg.global_precision, cfg.mass_precision,
-                         cfg.divmax, M.red);
-    } else {
-      FnuBiasLn f{&E};
-      norm = gauss_panels<4>(f, a, b, 8, M.gl, M.red, flip);
-    }
+    FnuBiasLin f{&E};
+    const double norm = romberg1<4>(f, E.nu_min, E.nu_max, cfg.global_precision,
+                                    cfg.mass_precision, cfg.divmax, M.red);
     __syncthreads();
     if (threadIdx.x == 0) E.bias_norm = 1.0 / norm;
+    __syncthreads();
+  } else {
+    // both integrals in one pass over the 128 nodes (f_norm = bias_norm = 1 in E meanwhile):
+    // int f and int f b; the bias integrand of the reference carries the NORMALISED f, i.e.
+    // f_norm times the raw integral
+    constexpr int NT = 256;
+    const double wd = (b - a) / 8.0;
+    double p1 = 0.0, p2 = 0.0;
+    for (int idx = threadIdx.x; idx < 16 * 8; idx += NT) {
+      const int pn = idx >> 4, q = idx & 15;
+      const double mid = a + wd * ((double)pn + 0.5);
+      const double nu = exp(mid + 0.5 * wd * M.gl[q]);
+      const double fn = f_nu(E, nu) * nu;
+      p1 += M.gl[16 + q] * fn;
+      p2 += M.gl[16 + q] * (fn * bias_nu(E, nu));
+    }
+    const double i1 = 0.5 * wd * group_sum<4>(p1, M.red, flip);
+    const double i2 = 0.5 * wd * group_sum<4>(p2, M.red, flip);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double fnorm = mf_kind == CHOMP_MF_ST ? 1.0 / i1 : 1.0;   // Tinker: f is normalised
+      E.f_norm = fnorm;
+      E.bias_norm = 1.0 / (fnorm * i2);
+    }
     __syncthreads();
   }
   if (!publish) return;

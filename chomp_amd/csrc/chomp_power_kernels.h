@@ -344,6 +344,60 @@ __device__ __forceinline__ void slow_list_append(int* slow, int parity, int k_gr
   slow[2 + at] = k_group;
 }
 
+// One wavefront's 128 k (two per lane) for the epochs [q_lo, q_hi) on the per-lane path: any
+// k, any knot interval, any order.  In-range k still re-use the Eisenstein-Hu shape across
+// epochs of one cosmology; k outside [k_min, k_max] take the full formula (halo.py:314-320).
+template <bool BAO>
+__device__ __forceinline__ void power_lanes_range(const chomp_config& cfg, const TabLayout& L,
+                                                  const Epoch* __restrict__ epochs,
+                                                  const double* __restrict__ tab, int w,
+                                                  bool extrap, int epoch0, int q_lo, int q_hi,
+                                                  const KLanes& s, size_t nk,
+                                                  double* __restrict__ out) {
+  const PowerFam F = power_families(w);
+  const int NK = L.NK;
+  const double x0 = log(cfg.k_min);
+  const double dx = (log(cfg.k_max) - x0) / (double)(NK - 1);
+  const double e0 = s.lk0 - (x0 + dx * (double)s.idx0), e1 = s.lk1 - (x0 + dx * (double)s.idx1);
+  double sh0 = 0.0, sh1 = 0.0;
+  for (int q = q_lo; q < q_hi; ++q) {
+    const int e = epoch0 + q;
+    const Epoch& E = epochs[e];
+    const double* t = tab + (size_t)e * L.stride;
+    double* o = out + (size_t)q * nk + s.i0;
+    const bool same = q > q_lo && t[L.off_misc + 2] != 0.0;
+    const double A = t[L.off_misc + 1];
+    if (!same && w != CHOMP_P_LIN) {
+      sh0 = power_shape_t<BAO>(E, s.lk0, s.k0);
+      sh1 = power_shape_t<BAO>(E, s.lk1, s.k1);
+    }
+    if (s.have0) {
+      double r;
+      if (s.in0 && w != CHOMP_P_LIN) {
+        const double ha = pp_poly(t + L.off_kpp[F.fa], s.idx0, e0);
+        const double hb = pp_poly(t + L.off_kpp[F.fb], s.idx0, e0);
+        const double pp = pp_poly(t + L.off_kpp[F.fp], s.idx0, e0);
+        r = fma(A * sh0, ha * hb, pp);
+      } else {
+        r = power_lane<BAO>(cfg, L, E, t, F.fa, F.fb, F.fp, w, extrap, s.k0);
+      }
+      o[0] = r;
+    }
+    if (s.have1) {
+      double r;
+      if (s.in1 && w != CHOMP_P_LIN) {
+        const double ha = pp_poly(t + L.off_kpp[F.fa], s.idx1, e1);
+        const double hb = pp_poly(t + L.off_kpp[F.fb], s.idx1, e1);
+        const double pp = pp_poly(t + L.off_kpp[F.fp], s.idx1, e1);
+        r = fma(A * sh1, ha * hb, pp);
+      } else {
+        r = power_lane<BAO>(cfg, L, E, t, F.fa, F.fb, F.fp, w, extrap, s.k1);
+      }
+      o[1] = r;
+    }
+  }
+}
+
 // The row-walking streaming pass (epochs of different cosmologies, or small grids).
 // grid (ceil(nk / 512), ceil(n_epoch / epochs_per_y)), block 256.  A wavefront whose k
 // do not qualify for the fast path only enters itself in the slow list.
@@ -355,8 +409,9 @@ __global__ __launch_bounds__(256) void k_power_grid(chomp_config cfg, TabLayout 
                                                     int rot,
                                                     const double* __restrict__ k, size_t nk,
                                                     double* __restrict__ out,
-                                                    int* __restrict__ slow, int parity) {
-  slow_list_begin(slow, parity);
+                                                    int* __restrict__ slow, int parity,
+                                                    int inline_lanes, bool extrap) {
+  if (!inline_lanes) slow_list_begin(slow, parity);
   const int k_group = (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
   const PowerFam F = power_families(w);
   const bool same_ab = F.fa == F.fb;
@@ -370,14 +425,18 @@ __global__ __launch_bounds__(256) void k_power_grid(chomp_config cfg, TabLayout 
                           (s.idx0 == idxu || s.idx0 == idxu + 1) &&
                           (s.idx1 == idxu || s.idx1 == idxu + 1)) &&
                     w != CHOMP_P_LIN;
-  if (!fast) {
-    if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && (size_t)k_group * 128 < nk)
-      slow_list_append(slow, parity, k_group);
-    return;
-  }
   const int q_lo = blockIdx.y * epochs_per_y;
   int q_hi = q_lo + epochs_per_y;
   if (q_hi > n_epoch) q_hi = n_epoch;
+  if (!fast) {
+    if (inline_lanes) {            // small grids: this block's epochs on the per-lane path, here
+      if ((size_t)k_group * 128 < nk)
+        power_lanes_range<BAO>(cfg, L, epochs, tab, w, extrap, epoch0, q_lo, q_hi, s, nk, out);
+    } else if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && (size_t)k_group * 128 < nk) {
+      slow_list_append(slow, parity, k_group);
+    }
+    return;
+  }
   const double x0 = log(cfg.k_min);
   const double dx = (log(cfg.k_max) - x0) / (double)(NK - 1);
   const bool two = !__all(s.idx0 == idxu && s.idx1 == idxu);  // wave-uniform
@@ -584,6 +643,10 @@ __global__ __launch_bounds__(256) void k_power_stream(TabLayout L, const double*
 // per-epoch coefficient loads of this path are a dependent chain), a fully listed grid
 // -> one item per group.  In-range k still re-use the Eisenstein-Hu shape across epochs
 // of one cosmology; k outside [k_min, k_max] take the full formula (halo.py:314-320).
+// The per-lane pass of the streaming shape: 1-D grid; every wavefront walks work items
+// (listed k group, chunk of epochs).  The chunk length adapts to the length of the list: few
+// listed groups -> short chunks over many wavefronts (the per-epoch coefficient loads of this
+// path are a dependent chain), a fully listed grid -> one item per group.
 template <bool BAO>
 __global__ __launch_bounds__(256) void k_power_grid_lanes(
     chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs,
@@ -592,10 +655,7 @@ __global__ __launch_bounds__(256) void k_power_grid_lanes(
     const int* __restrict__ slow, int parity) {
   const int count = slow[parity];
   if (count == 0) return;
-  const PowerFam F = power_families(w);
   const int NK = L.NK;
-  const double x0 = log(cfg.k_min);
-  const double dx = (log(cfg.k_max) - x0) / (double)(NK - 1);
   const long n_waves = (long)gridDim.x * 4;
   int chunks = (int)(n_waves / count);
   chunks = chunks < 1 ? 1 : (chunks > n_epoch ? n_epoch : chunks);
@@ -609,44 +669,7 @@ __global__ __launch_bounds__(256) void k_power_grid_lanes(
     int q_hi = q_lo + epochs_per_item;
     if (q_hi > n_epoch) q_hi = n_epoch;
     const KLanes s = load_k_lanes(cfg, NK, k, nk, (size_t)k_group * 64 + lane);
-    const double e0 = s.lk0 - (x0 + dx * (double)s.idx0), e1 = s.lk1 - (x0 + dx * (double)s.idx1);
-    double sh0 = 0.0, sh1 = 0.0;
-    for (int q = q_lo; q < q_hi; ++q) {
-      const int e = epoch0 + q;
-      const Epoch& E = epochs[e];
-      const double* t = tab + (size_t)e * L.stride;
-      double* o = out + (size_t)q * nk + s.i0;
-      const bool same = q > q_lo && t[L.off_misc + 2] != 0.0;
-      const double A = t[L.off_misc + 1];
-      if (!same && w != CHOMP_P_LIN) {
-        sh0 = power_shape_t<BAO>(E, s.lk0, s.k0);
-        sh1 = power_shape_t<BAO>(E, s.lk1, s.k1);
-      }
-      if (s.have0) {
-        double r;
-        if (s.in0 && w != CHOMP_P_LIN) {
-          const double ha = pp_poly(t + L.off_kpp[F.fa], s.idx0, e0);
-          const double hb = pp_poly(t + L.off_kpp[F.fb], s.idx0, e0);
-          const double pp = pp_poly(t + L.off_kpp[F.fp], s.idx0, e0);
-          r = fma(A * sh0, ha * hb, pp);
-        } else {
-          r = power_lane<BAO>(cfg, L, E, t, F.fa, F.fb, F.fp, w, extrap, s.k0);
-        }
-        o[0] = r;
-      }
-      if (s.have1) {
-        double r;
-        if (s.in1 && w != CHOMP_P_LIN) {
-          const double ha = pp_poly(t + L.off_kpp[F.fa], s.idx1, e1);
-          const double hb = pp_poly(t + L.off_kpp[F.fb], s.idx1, e1);
-          const double pp = pp_poly(t + L.off_kpp[F.fp], s.idx1, e1);
-          r = fma(A * sh1, ha * hb, pp);
-        } else {
-          r = power_lane<BAO>(cfg, L, E, t, F.fa, F.fb, F.fp, w, extrap, s.k1);
-        }
-        o[1] = r;
-      }
-    }
+    power_lanes_range<BAO>(cfg, L, epochs, tab, w, extrap, epoch0, q_lo, q_hi, s, nk, out);
   }
 }
 

@@ -120,11 +120,23 @@ __device__ __forceinline__ void call_f(const F& f, double x, double (&o)[NF], in
 // node sum and the last row's value -- so that another kernel can carry it on to deeper
 // levels (k_halo_deep_level / k_halo_deep_advance).
 constexpr int kRombergDump = 34;
+// Optional second, looser stopping rule for an integral whose value only has to DECIDE a
+// comparison: a row also ends the integral when err < rtol |result| with this (looser) rtol
+// and the result lies outside both windows (lo1, hi1), (lo2, hi2) around the values it is
+// compared with.  A result inside a window walks on to the regular tolerance: the same rows,
+// so the value is then exactly what the regular rule alone would have returned.
+struct RombergLoose {
+  double rtol, lo1, hi1, lo2, hi2;
+  __device__ __forceinline__ bool decides(double err, double cur) const {
+    return err < rtol * fabs(cur) && !(cur > lo1 && cur < hi1) && !(cur > lo2 && cur < hi2);
+  }
+};
 template <int NW, int NF, class F, int UNROLL = 1>
 __device__ __forceinline__ RombergOut<NF> romberg_group(const F& f, double a, double b,
                                                         double tol, double rtol,
                                                         int divmax, double* red,
-                                                        double* dump = nullptr) {
+                                                        double* dump = nullptr,
+                                                        const RombergLoose* loose = nullptr) {
   constexpr int NT = 64 * NW;
   const int lane = threadIdx.x & 63;
   const int gt = (NW == 1) ? lane : (int)threadIdx.x;
@@ -151,6 +163,7 @@ __device__ __forceinline__ RombergOut<NF> romberg_group(const F& f, double a, do
     out.value[q] = cur;
     out.level[q] = i;
     if (err < tol || err < rtol * fabs(cur)) done[q] = true;
+    if (loose != nullptr && loose->decides(err, cur)) done[q] = true;
   };
 
   int i0;   // first level handled by the generic loop
