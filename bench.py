@@ -3,19 +3,28 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Default workload (the headline): a "step" is one full pass of the hot path over
-BASELINE.json's configs[1]:
+Headline (BASELINE.json configs[1]): a "step" is one full pass of the hot path --
 Stage K (every table of the 64 redshifts: sigma_8 normalisation, mass-limit search,
 nu table, splines, normalisations, n_bar, the 50-knot 2-halo / 1-halo integrals)
 followed by Stage E (P_mm on the 4096 x 64 (k, z) grid), with k resident in HBM
 and, for N > 1, the all-gather that re-assembles the grid on every rank.  Rank 0
-prints ONE JSON line (contract in the task description) carrying `roofline`
-(Stage-E kernel, HIP events on the kernel's own stream) and `cpu_baseline` (the
-NumPy oracle = a port of the reference's algorithm, timed on this box's host
-cores on a bounded sample of the same workload).
+prints ONE JSON line (contract in the task description) carrying
 
---workload c3 is configs[2] (same grid, Tinker10 + Zheng07 P_gm); c4 / c5 are the
-projection configs (w(theta) at 1024 theta + C_l at 2048 l, see projection_bench).
+  roofline          the streaming Stage-E kernel on the enlarged grid of SURVEY 8(d)
+                    (HIP events on the kernel's own stream), the whole call beside it,
+                    and the kernel the timed C2 step actually runs
+  roofline_stage_k  Stage K of the timed step against the vector-fp64 peak (FLOP per
+                    step from the committed SQ counters of the same kernels)
+  cpu_baseline      the NumPy oracle = a port of the reference's algorithm, timed on
+                    this box's host cores on a bounded sample of the same workload
+  other_configs     configs[2..4] (c3, c4, c5) timed in the same process, GPU side
+
+N > 1 (torch.distributed.run, one rank per GPU, RCCL): the headline is WEAK scaling
+(every GPU carries configs[1]'s 64 redshift rows; at N = 1 exactly configs[1]); the
+same run then times the STRONG split of SURVEY 8(e) (the 64 rows dealt over the ranks)
+and reports it under `strong_scaling`.
+
+--workload c3 | c4 | c5 runs one of the other configs as the headline instead.
 """
 import argparse
 import json
@@ -31,8 +40,13 @@ if ROOT not in sys.path:
 
 NK, NZ, Z_MAX = 4096, 64, 1.5
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 measured copy)
+FP64_VALU_PEAK_TFLOPS = 78.6   # vector fp64: half the 157.3 TFLOP/s fp32 vector peak
+N_THETA, N_ELL = 1024, 2048
 
 
+# ---------------------------------------------------------------------------
+# CPU baselines (the oracle: tests' checker, here only timed)
+# ---------------------------------------------------------------------------
 def _oracle_row(args):
     """One redshift row through the oracle (module-level: used by the process pool)."""
     which, mass_function, z = args
@@ -72,9 +86,6 @@ def cpu_baseline(which, mass_function, sample_z, pool_z):
             "host_cores_available": os.cpu_count()}
 
 
-N_THETA, N_ELL = 1024, 2048
-
-
 def projection_baseline(ggl):
     """The oracle on a bounded sample of the projection workload (one thread): the set-up
     (MultiEpoch, windows, 50-knot kernel, halo tables at z_bar) and a few theta / l."""
@@ -110,32 +121,79 @@ def projection_baseline(ggl):
             "host_cores_available": os.cpu_count()}
 
 
-def projection_bench(args, world, rank, local):
+# ---------------------------------------------------------------------------
+# GPU legs
+# ---------------------------------------------------------------------------
+class Dist(object):
+    """What a leg needs to know about the job: ranks, fences, the max over ranks."""
+
+    def __init__(self, args, world, rank, local, dev):
+        self.args, self.world, self.rank, self.local, self.dev = args, world, rank, local, dev
+
+    def fence(self):
+        import torch
+        import torch.distributed as dist
+        torch.cuda.synchronize(self.dev)
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(self.dev)
+
+    def max_over_ranks(self, seconds):
+        import torch
+        import torch.distributed as dist
+        if self.world == 1:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64,
+                         device="cpu" if self.args.rehearse else self.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+def grid_leg(D, which, mf, nz, steps, warmup, stream):
+    """`steps` timed steps of the (k, z) grid workload with nz redshift rows in all, dealt
+    over the ranks (interleaved).  Steps are software-pipelined for N > 1: the all-gather of
+    step i (RCCL's own stream) overlaps Stage K of step i + 1; every step's gather has
+    completed and been re-ordered inside the timed region.  Returns (seconds, hg, k, out)."""
+    import torch
+    from chomp_amd import grid
+    z = numpy.linspace(0.0, Z_MAX, nz)
+    hg = grid.HaloGrid(z, mass_function=mf, device=D.local, stream=stream.cuda_stream,
+                       rank=D.rank, world=D.world)
+    k = torch.logspace(-3, 2, NK, dtype=torch.float64, device=D.dev)
+
+    def run(n_steps):
+        out, pending = None, None
+        for _ in range(n_steps):
+            hg.setup(which)                             # Stage K, this rank's redshifts
+            nxt = hg.power_all_async(which, k)          # Stage E + all-gather launch
+            if pending is not None:
+                out = pending.wait()
+            pending = nxt
+        if pending is not None:
+            out = pending.wait()
+        return out
+
+    out = run(warmup)
+    D.fence()
+    t0 = time.perf_counter()
+    out = run(steps)
+    D.fence()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0)
+    assert out.shape == (nz, NK) and bool(torch.isfinite(out).all())
+    return elapsed, hg, k, out
+
+
+def projection_leg(D, ggl, steps, warmup):
     """configs[3] (c4: gal-gal clustering, J0, P_gg) and configs[4] (c5: galaxy-galaxy
     lensing, J2, HaloFit P_gm): a step = the whole projection path -- MultiEpoch chi(z),
     both windows, the 50-knot Bessel kernel and z_bar, the halo tables at z_bar, then
     w(theta) at 1024 theta and C_l at 2048 l -- with theta / l sharded over the ranks
     (set-up replicated, as SURVEY 8(e) prescribes) and one all-gather each."""
-    ggl = args.workload == "c5"
-    baseline = None
-    if world == 1 and not args.no_cpu_baseline:
-        baseline = projection_baseline(ggl)
+    import contextlib
     import torch
-    import torch.distributed as dist
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
-    if args.rehearse:
-        local = 0
-        os.environ["CHOMP_DEVICE"] = "0"      # the mirror classes pick their device from here
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo" if args.rehearse else "nccl",
-                                **({} if args.rehearse else {"device_id": dev}))
-    from chomp_amd import cosmology, correlation, halo, kernel
+    from chomp_amd import cosmology, correlation, halo, kernel, grid
     d2r = numpy.pi / 180.0
     cm = cosmology.MultiEpoch(0.0, 5.0)
-    import contextlib
     with contextlib.redirect_stdout(sys.stderr):     # (the reference's z_max warning)
         lens_a = kernel.dNdzMagLim(0.0, 2.0, 2.0, 0.3, 2.0)
         lens_b = kernel.dNdzMagLim(0.0, 2.0, 2.0, 0.3, 2.0)
@@ -150,12 +208,14 @@ def projection_bench(args, world, rank, local):
         kern = kernel.Kernel(1e-6 * d2r, 100.0 * d2r, wa, wb, cm)
         h = halo.Halo(0.0)
         spec = "power_gg"
-    corr = correlation.Correlation(0.001, 1.0, kern, input_halo=h, power_spec=spec)
-    theta = torch.logspace(-3, 0, N_THETA, dtype=torch.float64, device=dev) * d2r
-    ell = torch.logspace(1, 4, N_ELL, dtype=torch.float64, device=dev)
-    from chomp_amd import grid
-    my_theta = grid.shard_samples(theta, rank, world)
-    my_ell = grid.shard_samples(ell, rank, world)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")               # (divmax warnings of the HOD integrands)
+        corr = correlation.Correlation(0.001, 1.0, kern, input_halo=h, power_spec=spec)
+    theta = torch.logspace(-3, 0, N_THETA, dtype=torch.float64, device=D.dev) * d2r
+    ell = torch.logspace(1, 4, N_ELL, dtype=torch.float64, device=D.dev)
+    my_theta = grid.shard_samples(theta, D.rank, D.world)
+    my_ell = grid.shard_samples(ell, D.rank, D.world)
 
     def step():
         # forget every table: the step rebuilds the projection and the halo model
@@ -168,32 +228,120 @@ def projection_bench(args, world, rank, local):
         ctx, code = corr._prepare()
         w = ctx.wtheta(code, 0, corr._k_lim[0], corr._k_lim[1], corr.D_z, my_theta)
         c = ctx.cell(code, 0, corr.D_z, my_ell)
-        if world > 1:                      # one all-gather per output array
-            w = grid.gather_samples(w, N_THETA, world, via_host=args.rehearse)
-            c = grid.gather_samples(c, N_ELL, world, via_host=args.rehearse)
+        if D.world > 1:                      # one all-gather per output array
+            w = grid.gather_samples(w, N_THETA, D.world, via_host=D.args.rehearse)
+            c = grid.gather_samples(c, N_ELL, D.world, via_host=D.args.rehearse)
         return w, c
 
-    def fence():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    for _ in range(args.warmup):
-        w, c = step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        w, c = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse else dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    import warnings as _w
+    with _w.catch_warnings():
+        _w.simplefilter("ignore")
+        for _ in range(warmup):
+            w, c = step()
+        D.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            w, c = step()
+        D.fence()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0)
     assert w.numel() == N_THETA and c.numel() == N_ELL
     assert bool(torch.isfinite(w).all()) and bool((c > 0).all())
-    if rank == 0:
+    return elapsed
+
+
+def stage_k_roofline(stage_k_seconds, workload):
+    """Stage K against the vector-fp64 peak: FLOP per step from the SQ counters committed
+    under profiles/ (rocprofv3 --pmc SQ_INSTS_VALU_*_F64 of the same kernels on the same
+    workload; 64 lanes x (2 FMA + ADD + MUL + TRANS) per wavefront instruction)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "round2_stage_k_counters.json")) as fh:
+            cnt = json.load(fh)[workload]
+    except (OSError, ValueError, KeyError):
+        return None
+    flop = float(cnt["fp64_flop_per_step"])
+    return {"bound": "fp64_valu", "achieved": flop / stage_k_seconds / 1e12,
+            "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": flop / stage_k_seconds / 1e12 / FP64_VALU_PEAK_TFLOPS,
+            "flop_per_step": flop, "stage_k_ms": stage_k_seconds * 1e3,
+            "valu_insts_per_step": cnt.get("valu_insts_per_step"),
+            "kernels": cnt.get("kernels"),
+            "note": "latency chain of %d dependent launches on 64 epochs; counters: "
+                    "profiles/round2_stage_k_counters.json" % len(cnt.get("kernels", []))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1, c2 / c3: which split is the headline (the other one is timed "
+                         "too and reported beside it)")
+    ap.add_argument("--roofline-nk", type=int, default=1 << 20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true",
+                    help="development runs: the timed steps only (no stage split, roofline, "
+                         "other configs)")
+    ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="test-only: run the N > 1 path on ONE GPU (every rank on device 0, "
+                         "gloo all-gather through host memory); the numbers mean nothing")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node N"
+    proj = args.workload in ("c4", "c5")
+    which = "power_mm" if args.workload == "c2" else "power_gm"
+    mf = "st" if args.workload == "c2" else "tinker"
+    baseline = None
+    if world == 1 and not args.no_cpu_baseline:
+        # before the GPU is initialised: the pool forks
+        if proj:
+            baseline = projection_baseline(args.workload == "c5")
+        else:
+            z1 = numpy.linspace(0.0, Z_MAX, NZ)
+            if args.workload == "c2":
+                baseline = cpu_baseline(which, mf, z1, numpy.concatenate([z1, z1]))
+            else:
+                baseline = cpu_baseline(which, mf, z1[[0, 21, 42, 63]], z1[::4])
+
+    import torch
+    import torch.distributed as dist
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    if args.rehearse:
+        local = 0
+        os.environ["CHOMP_DEVICE"] = "0"      # the mirror classes pick their device from here
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    backend = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+        backend = dist.get_backend()
+    D = Dist(args, world, rank, local, dev)
+    # A stream of our own: on the legacy NULL stream every torch fill / memset on this
+    # image serialises against the whole device (+0.1 ms per step, measured).
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+    job = {"rccl_world_size": dist.get_world_size() if world > 1 else 1, "backend": backend or "none"}
+
+    def finish(res):
+        if rank == 0:
+            print(json.dumps(res))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+
+    # ---- projection workloads as the headline
+    if proj:
+        ggl = args.workload == "c5"
+        elapsed = projection_leg(D, ggl, args.steps, args.warmup)
         res = {"metric": "Limber w(theta) + C_l samples/sec (projection and halo set-up included)",
                "value": (N_THETA + N_ELL) * args.steps / elapsed, "unit": "samples/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -210,121 +358,43 @@ def projection_bench(args, world, rank, local):
                           "n_theta": N_THETA, "n_ell": N_ELL,
                           "sharding": "theta and l interleaved over %d rank(s), set-up "
                                       "replicated, one all-gather each" % world},
-               "roofline": None}
+               "job": job, "roofline": None}
         if baseline is not None:
             res["cpu_baseline"] = baseline
-        print(json.dumps(res))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        return finish(res)
 
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
-    ap.add_argument("--roofline-nk", type=int, default=1 << 20)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true",
-                    help="development runs: the timed steps only (no stage split, roofline)")
-    ap.add_argument("--rehearse", action="store_true",
-                    help="test-only: run the N > 1 path on ONE GPU (every rank on device 0, "
-                         "gloo all-gather through host memory); the numbers mean nothing")
-    args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node N"
-    if args.workload in ("c4", "c5"):
-        return projection_bench(args, world, rank, local)
-    which = "power_mm" if args.workload == "c2" else "power_gm"
-    mf = "st" if args.workload == "c2" else "tinker"
-    baseline = None
-    if world == 1 and not args.no_cpu_baseline:
-        # before the GPU is initialised: the pool forks
-        z1 = numpy.linspace(0.0, Z_MAX, NZ)
-        if args.workload == "c2":
-            baseline = cpu_baseline(which, mf, z1, numpy.concatenate([z1, z1]))
-        else:
-            baseline = cpu_baseline(which, mf, z1[[0, 21, 42, 63]], z1[::4])
-
-    import torch
-    import torch.distributed as dist
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
-    if args.rehearse:
-        local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.rehearse:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
-
-    from chomp_amd import grid
-    # weak scaling: every GPU carries configs[1]'s 64 redshift rows, so the global
-    # grid is 4096 k x (64 N) z; at N = 1 this is exactly configs[1].
-    nz = NZ * world
-    z = numpy.linspace(0.0, Z_MAX, nz)
-    # A stream of our own: on the legacy NULL stream every torch fill / memset on this
-    # image serialises against the whole device (+0.1 ms per step, measured).
-    stream = torch.cuda.Stream(dev)
-    torch.cuda.set_stream(stream)
-    hg = grid.HaloGrid(z, mass_function=mf, device=local, stream=stream.cuda_stream,
-                       rank=rank, world=world)
-    k = torch.logspace(-3, 2, NK, dtype=torch.float64, device=dev)
-
-    def run(n_steps):
-        """n_steps steps, software-pipelined for N > 1: the all-gather of step i (RCCL's
-        own stream) overlaps Stage K of step i + 1; every step's gather has completed and
-        been re-ordered before this returns."""
-        out, pending = None, None
-        for _ in range(n_steps):
-            hg.setup(which)                             # Stage K, this rank's redshifts
-            nxt = hg.power_all_async(which, k)          # Stage E + all-gather launch
-            if pending is not None:
-                out = pending.wait()
-            pending = nxt
-        if pending is not None:
-            out = pending.wait()
-        return out
-
-    def fence():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    out = run(args.warmup)
-    fence()
-    t0 = time.perf_counter()
-    out = run(args.steps)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64,
-                         device="cpu" if args.rehearse else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert out.shape == (nz, NK) and bool(torch.isfinite(out).all())
+    # ---- the (k, z) grid workloads
+    # weak: every GPU carries configs[1]'s 64 redshift rows (global grid 4096 k x 64 N z; at
+    # N = 1 exactly configs[1]); strong: configs[1]'s 64 rows dealt over the ranks.
+    nz_of = {"weak": NZ * world, "strong": NZ}
+    head = args.scaling
+    elapsed, hg, k, out = grid_leg(D, which, mf, nz_of[head], args.steps, args.warmup, stream)
+    nz = nz_of[head]
     ms_per_step = 1e3 * elapsed / args.steps
     value = nz * NK * args.steps / elapsed
+    n_local = len(hg.idx)
+    rows = None
+    if world > 1:
+        t = torch.zeros(world, dtype=torch.int64, device="cpu" if args.rehearse else dev)
+        t[rank] = n_local
+        dist.all_reduce(t)
+        rows = [int(x) for x in t.tolist()]
+    job["rows_per_rank"] = rows if rows is not None else [n_local]
+    other_split = None
+    if world > 1 and not args.no_roofline:
+        alt = "strong" if head == "weak" else "weak"
+        e2, _, _, _ = grid_leg(D, which, mf, nz_of[alt], args.steps, args.warmup, stream)
+        other_split = {"scaling": alt, "nz": nz_of[alt], "ms_per_step": 1e3 * e2 / args.steps,
+                       "value": nz_of[alt] * NK * args.steps / e2, "unit": "samples/s",
+                       "rows_per_rank": [len(range(r, nz_of[alt], world)) for r in range(world)]}
 
     if args.no_roofline:
-        if rank == 0:
-            print(json.dumps({"metric": "halo-model P(k,z) samples/sec (development run)",
-                              "value": value, "unit": "samples/s", "n_gpus": world,
-                              "steps": args.steps, "warmup": args.warmup,
-                              "ms_per_step": ms_per_step}))
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
-    # ---- stage split and roofline (rank 0's shard; HIP events on the kernel stream)
+        return finish({"metric": "halo-model P(k,z) samples/sec (development run)",
+                       "value": value, "unit": "samples/s", "n_gpus": world,
+                       "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+                       "scaling": head, "job": job})
+
+    # ---- stage split and rooflines (rank 0's shard; HIP events on the kernel stream)
     def timed(fn, reps):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         fn()
@@ -336,7 +406,6 @@ def main():
         torch.cuda.synchronize(dev)
         return ev0.elapsed_time(ev1) / reps * 1e-3
 
-    n_local = len(hg.idx)
     t_setup = timed(lambda: hg.setup(which), max(3, args.steps // 2))
     buf = torch.empty((n_local, NK), dtype=torch.float64, device=dev)
     t_e_c2 = timed(lambda: hg.power(which, k, out=buf), 50)
@@ -350,15 +419,28 @@ def main():
         hg.power(which, k_big, out=buf_big)
     t_e_big = timed(lambda: hg.power(which, k_big, out=buf_big), 100)
     # per-kernel durations of the same call (HIP events recorded by the library around its
-    # three launches, on the stream they run on): the last call of 5 back-to-back trains
+    # launches, on the stream they run on): the last call of 5 back-to-back trains
     hg.ctx.set_timing(True)
     per_kernel = []
     for _ in range(5):
         for _ in range(40):
             hg.power(which, k_big, out=buf_big)
         per_kernel.append(hg.ctx.get_timing())
-    hg.ctx.set_timing(False)
     t_prep, t_stream, t_lanes = (float(x) * 1e-6 for x in numpy.mean(per_kernel, axis=0))
+    # the same grid registered once (chomp_power_plan: the k-only table is kept, a grid
+    # without k groups for the per-lane pass skips that launch): what a caller who evaluates
+    # many (cosmology-preserving) set-ups on one k grid sees per call
+    hg.ctx.power_plan(k_big)
+    for _ in range(50):
+        hg.power(which, k_big, out=buf_big)
+    per_kernel = []
+    for _ in range(5):
+        for _ in range(40):
+            hg.power(which, k_big, out=buf_big)
+        per_kernel.append(hg.ctx.get_timing())
+    hg.ctx.set_timing(False)
+    tp_prep, tp_stream, tp_lanes = (float(x) * 1e-6 for x in numpy.mean(per_kernel, axis=0))
+    t_e_planned = timed(lambda: hg.power(which, k_big, out=buf_big), 100)
     # Algorithmic bytes of one Stage-E launch: k is read once (8 B per k) and one
     # P value is written per (k, z) sample (8 B).  SURVEY 8(d) prices the per-z
     # explicit-k call at 16 B/sample (k re-read for every z); the grid launch shares
@@ -377,52 +459,99 @@ def main():
                                 pmc["WRITE_SIZE_KiB_raw_by_kernel"][name])
     except (OSError, ValueError, KeyError, IndexError):
         pass
-    roof = {"bound": "hbm", "kernel": "k_power_stream (the dominant kernel of a Stage E call: it writes "
-                      "every output sample; HIP events around its launch on the context's stream)",
+    roof = {"bound": "hbm", "kernel": "k_power_stream (the dominant kernel of a Stage E call on a "
+                      "large grid: it writes every output sample; HIP events around its launch on "
+                      "the context's stream)",
             "workload": "%d k x %d z (enlarged grid, SURVEY 8(d))" % (nk_big, n_local),
             "achieved": bytes_big / t_stream / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": bytes_big / t_stream / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_source": "profiles/stage_e_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                              "passes of this command, FETCH doubled per MI355X_MICROARCH.md); "
+                              "not re-measured by this run",
             "bytes_per_launch": bytes_big, "avg_launch_us": t_stream * 1e6,
-            # the whole chomp_power call = k_power_prep + k_power_stream + k_power_grid_lanes
-            # (HIP events around 100 back-to-back calls): what a caller of Stage E sees
+            # the whole chomp_power call as a caller sees it (HIP events around 100 calls)
             "whole_call": {"kernels_us": {"k_power_prep": t_prep * 1e6,
                                           "k_power_stream": t_stream * 1e6,
                                           "k_power_grid_lanes": t_lanes * 1e6},
                            "avg_call_us": t_e_big * 1e6, "traffic": traffic_call,
                            "achieved": bytes_big / t_e_big / 1e9,
                            "frac": bytes_big / t_e_big / 1e9 / HBM_PEAK_GBS},
+            "whole_call_registered_grid": {
+                "kernels_us": {"k_power_prep": tp_prep * 1e6, "k_power_stream": tp_stream * 1e6,
+                               "k_power_grid_lanes": tp_lanes * 1e6},
+                "avg_call_us": t_e_planned * 1e6,
+                "achieved": bytes_big / t_e_planned / 1e9,
+                "frac": bytes_big / t_e_planned / 1e9 / HBM_PEAK_GBS,
+                "note": "chomp_power_plan: the k-only table of a registered k grid is kept "
+                        "across calls"},
             "achieved_at_16B_per_sample": 16.0 * n_local * nk_big / t_e_big / 1e9,
-            "c2_grid": {"achieved": bytes_c2 / t_e_c2 / 1e9, "avg_launch_us": t_e_c2 * 1e6,
-                        "bytes_per_launch": bytes_c2},
+            # what the TIMED step runs: a 4096 x 64 grid is 2 MB -- one small launch of the
+            # row-walking kernel, bound by its launch, not by HBM
+            "timed_step_kernel": {"kernel": "k_power_grid", "achieved": bytes_c2 / t_e_c2 / 1e9,
+                                  "frac": bytes_c2 / t_e_c2 / 1e9 / HBM_PEAK_GBS,
+                                  "avg_launch_us": t_e_c2 * 1e6, "bytes_per_launch": bytes_c2},
             "samples_per_s_stage_e_only": n_local * nk_big / t_e_big}
     del buf_big, k_big
 
-    if rank == 0:
-        res = {
-            "metric": "halo-model P(k,z) samples/sec (Stage K set-up + Stage E grid)",
-            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic" + (" (REHEARSAL on one GPU: not a measurement)"
-                                                   if args.rehearse else ""),
-            "config": {"workload": "configs[%d]: %s, WMAP7, %s mass function, %d k "
-                                   "(logspace -3..2) x %d z (linspace 0..%.1f)"
-                                   % (1 if args.workload == "c2" else 2, which,
-                                      "Sheth-Tormen" if mf == "st" else "Tinker10 + Zheng HOD",
-                                      NK, nz, Z_MAX),
-                       "nk": NK, "nz": nz, "sharding": "z interleaved over %d rank(s), one all-gather per step"
-                                   "%s" % (world, ", overlapped with the next step's Stage K"
-                                           if world > 1 else "")},
-            "stage_split_rank0": {"stage_k_ms": t_setup * 1e3, "stage_e_ms": t_e_c2 * 1e3,
-                                  "n_local_z": n_local},
-            "roofline": roof,
-        }
-        if baseline is not None:
-            res["cpu_baseline"] = baseline
-        print(json.dumps(res))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    res = {
+        "metric": "halo-model P(k,z) samples/sec (Stage K set-up + Stage E grid)",
+        "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": head, "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic" + (" (REHEARSAL on one GPU: not a measurement)"
+                                               if args.rehearse else ""),
+        "config": {"workload": "configs[%d]: %s, WMAP7, %s mass function, %d k "
+                               "(logspace -3..2) x %d z (linspace 0..%.1f)"
+                               % (1 if args.workload == "c2" else 2, which,
+                                  "Sheth-Tormen" if mf == "st" else "Tinker10 + Zheng HOD",
+                                  NK, nz, Z_MAX),
+                   "nk": NK, "nz": nz, "sharding": "z interleaved over %d rank(s), one all-gather per step"
+                               "%s" % (world, ", overlapped with the next step's Stage K"
+                                       if world > 1 else "")},
+        "job": job,
+        "stage_split_rank0": {"stage_k_ms": t_setup * 1e3, "stage_e_ms": t_e_c2 * 1e3,
+                              "n_local_z": n_local},
+        "roofline": roof,
+    }
+    if n_local == NZ:
+        rk = stage_k_roofline(t_setup, args.workload)
+        if rk is not None:
+            res["roofline_stage_k"] = rk
+    if other_split is not None:
+        res["strong_scaling" if other_split["scaling"] == "strong" else "weak_scaling"] = other_split
+    if baseline is not None:
+        res["cpu_baseline"] = baseline
+
+    # ---- the other configs, GPU side, same process (N = 1 only)
+    if world == 1 and not args.no_other_configs and args.workload == "c2":
+        other = {}
+        del hg
+        e3, hg3, k3, _ = grid_leg(D, "power_gm", "tinker", NZ, 10, 2, stream)
+        ts3 = timed(lambda: hg3.setup("power_gm"), 5)
+        f3 = stage_k_roofline(ts3, "c3")
+        other["c3"] = {"workload": "configs[2]: power_gm, Tinker10 + Zheng07, 4096 k x 64 z",
+                       "ms_per_step": 1e3 * e3 / 10, "value": NZ * NK * 10 / e3,
+                       "unit": "samples/s", "steps": 10,
+                       "dominant_kernel": "k_halo_knots_fast (knots beyond the node tables: "
+                                          "level sums from 2049 coarse samples)",
+                       "stage_k_ms": ts3 * 1e3,
+                       "frac": f3["frac"] if f3 else None,
+                       "frac_of": "vector-fp64 peak, Stage K (profiles/round2_stage_k_counters.json)",
+                       "deep_knots_fast_literal": list(hg3.ctx.deep_stats())}
+        del hg3
+        for name, ggl in (("c4", False), ("c5", True)):
+            ep = projection_leg(D, ggl, 10, 2)
+            other[name] = {"workload": "configs[%d]: %s, 1024 theta + 2048 l" % (
+                               4 if ggl else 3, "GGL J2 kernel + HaloFit power_gm" if ggl
+                               else "clustering J0 kernel + power_gg"),
+                           "ms_per_step": 1e3 * ep / 10, "value": (N_THETA + N_ELL) * 10 / ep,
+                           "unit": "samples/s", "steps": 10,
+                           "dominant_kernel": "k_wtheta (one theta per 1024-thread block, "
+                                              "Romberg on the tabulated k-only factor)",
+                           "frac": None,
+                           "profile": "profiles/round2_kernel_stats_%s.csv" % name}
+        res["other_configs"] = other
+    finish(res)
 
 
 if __name__ == "__main__":

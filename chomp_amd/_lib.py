@@ -103,7 +103,7 @@ EXPORTS = [
     "chomp_set_transfer", "chomp_kernel_raw",
     "chomp_covariance_table", "chomp_covariance_gaussian",
     "chomp_set_timing", "chomp_get_timing", "chomp_get_status", "chomp_set_tuning",
-    "chomp_get_deep_stats", "chomp_stage_k",
+    "chomp_get_deep_stats", "chomp_stage_k", "chomp_power_plan", "chomp_get_stream",
 ]
 
 # chomp_get_status bits (include/chomp_mi355x.h)
@@ -253,6 +253,7 @@ def lib():
         L.chomp_last_error.argtypes = [vp]
         L.chomp_last_error.restype = ctypes.c_char_p
         L.chomp_sync.argtypes = [vp]
+        L.chomp_get_stream.argtypes = [vp, ctypes.POINTER(vp)]
         L.chomp_epochs_set.argtypes = [vp, sz, ctypes.POINTER(Cosmo), c_double_p]
         L.chomp_mass_setup.argtypes = [vp, ctypes.POINTER(HaloPar), i]
         L.chomp_halo_setup.argtypes = [vp, ctypes.POINTER(HaloPar),
@@ -262,6 +263,7 @@ def lib():
         L.chomp_halofit_setup.argtypes = [vp, sz, sz, d, d, d, d, d]
         L.chomp_power.argtypes = [vp, i, vp, sz, vp, i]
         L.chomp_power_range.argtypes = [vp, i, sz, sz, vp, sz, vp, i]
+        L.chomp_power_plan.argtypes = [vp, sz, vp, sz]
         L.chomp_sigma_r.argtypes = [vp, sz, c_double_p, sz, c_double_p]
         L.chomp_y_nfw.argtypes = [vp, sz, c_double_p, c_double_p, sz, c_double_p]
         L.chomp_get_scalars.argtypes = [vp, sz, c_double_p]
@@ -356,21 +358,63 @@ def _is_torch(x):
     return type(x).__module__.split(".")[0] == "torch"
 
 
+def _torch_current_stream(device):
+    """torch's current HIP stream on `device`, if torch is in use in this process (never
+    imports torch or initialises the GPU through it by itself)."""
+    import sys
+    torch = sys.modules.get("torch")
+    if torch is None or not hasattr(torch, "cuda") or not torch.cuda.is_initialized():
+        return None
+    return torch.cuda.current_stream(device)
+
+
 class Context(object):
-    """Owns one chomp_ctx.  device: HIP ordinal; stream: raw hipStream_t or None."""
+    """Owns one chomp_ctx.  device: HIP ordinal; stream: raw hipStream_t or None.
+
+    stream=None: torch's current stream of the device when torch is already driving the GPU
+    in this process (so that tensors handed to power() / wtheta() / ... are produced and
+    consumed in stream order with the caller's other work), else a stream of the library's
+    own.  Calls that pass torch tensors from ANOTHER current stream are ordered against it
+    with events on both sides (_torch_enter / _torch_leave)."""
 
     def __init__(self, config, device=0, stream=None):
         self._L = lib()
         self._h = ctypes.c_void_p()
         self.config = config
         self.device = int(device)
+        if stream is None:
+            cur = _torch_current_stream(self.device)
+            if cur is not None:
+                stream = cur.cuda_stream
         rc = self._L.chomp_ctx_create(ctypes.byref(config), self.device,
                                       ctypes.c_void_p(stream or 0),
                                       ctypes.byref(self._h))
         if rc != OK:
             raise ChompError("chomp_ctx_create failed (%d): no usable MI355X / HIP "
                              "device; chomp_amd has no CPU fallback" % rc)
+        sp = ctypes.c_void_p()
+        self._L.chomp_get_stream(self._h, ctypes.byref(sp))
+        self.stream_ptr = sp.value or 0
         self.n_epoch = 0
+
+    # -- ordering against the caller's torch stream ------------------------------------
+    def _torch_enter(self):
+        """Before a call that reads torch tensors: the context's stream waits for what the
+        caller's current stream has queued.  Returns the pair of streams for _torch_leave
+        (None when both are the same stream: nothing to do)."""
+        import torch
+        cur = torch.cuda.current_stream(self.device)
+        if cur.cuda_stream == self.stream_ptr:
+            return None
+        mine = torch.cuda.ExternalStream(self.stream_ptr, device=self.device)
+        mine.wait_stream(cur)
+        return cur, mine
+
+    @staticmethod
+    def _torch_leave(pair):
+        """After it: the caller's stream waits for the context's (the outputs)."""
+        if pair is not None:
+            pair[0].wait_stream(pair[1])
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -461,9 +505,11 @@ class Context(object):
             assert k.is_cuda and k.dtype == torch.float64 and k.is_contiguous()
             if out is None:
                 out = torch.empty((n, k.numel()), dtype=torch.float64, device=k.device)
+            pair = self._torch_enter()
             self._check(self._L.chomp_power_range(
                 self._h, which, epoch0, n, ctypes.c_void_p(k.data_ptr()), k.numel(),
                 ctypes.c_void_p(out.data_ptr()), DEVICE))
+            self._torch_leave(pair)
             return out
         k = numpy.ascontiguousarray(k, dtype=numpy.float64).ravel()
         if out is None:
@@ -473,6 +519,13 @@ class Context(object):
                 self._h, which, epoch0, n, ctypes.c_void_p(k.ctypes.data), k.size,
                 ctypes.c_void_p(out.ctypes.data), HOST))
         return out
+
+    def power_plan(self, k, epoch0=0):
+        """Register a torch cuda k grid for repeated power() calls (chomp_power_plan): the
+        k-only work is done once; the caller keeps k unchanged meanwhile."""
+        assert _is_torch(k) and k.is_cuda and k.is_contiguous()
+        self._check(self._L.chomp_power_plan(self._h, epoch0, ctypes.c_void_p(k.data_ptr()),
+                                             k.numel()))
 
     def sigma_r(self, epoch, scale):
         s = numpy.ascontiguousarray(numpy.atleast_1d(scale), dtype=numpy.float64)
@@ -611,8 +664,10 @@ class Context(object):
             import torch
             assert x.is_cuda and x.dtype == torch.float64 and x.is_contiguous()
             out = torch.empty_like(x)
+            pair = self._torch_enter()
             self._check(fn(self._h, *pre, ctypes.c_void_p(x.data_ptr()), x.numel(),
                            ctypes.c_void_p(out.data_ptr()), DEVICE))
+            self._torch_leave(pair)
             return out
         x = numpy.ascontiguousarray(x, dtype=numpy.float64)
         out = numpy.empty_like(x)

@@ -103,9 +103,19 @@ struct chomp_ctx {
   int* d_winfo = nullptr;          // Stage E: per k group knot interval / flags (k_power_prep)
   double* d_ktab = nullptr;        // Stage E: per-k (offset, shape) table (k_power_prep)
   double* d_wnodes = nullptr;      // w(theta): theta-independent integrand factor on the Romberg nodes
+  double* d_cnodes = nullptr;      // C_l: chi-only factors on the Romberg nodes
+  size_t cap_cnodes = 0;
   double* d_deepw = nullptr;       // k_halo_knots_fast: level weights (deep_weights_host)
   int* d_deepstat = nullptr;       // k_halo_knots_fast: knots done by the fast / literal path
   size_t cap_slow = 0, cap_winfo = 0, cap_ktab = 0, cap_wnodes = 0;
+  // chomp_power_plan: the k-only table of a registered k grid, kept across chomp_power calls
+  struct PowerPlan {
+    bool valid = false;
+    const double* k = nullptr;
+    size_t nk = 0;
+    chomp_cosmo cosmo;             // the cosmology the shape column was computed for
+    int bao = 0, parity = 0, n_slow = -1;
+  } plan;
   int slow_parity = 0;
   bool slow_by_memset = false;     // set once a Stage E call has been captured into a HIP graph
   int precision = CHOMP_PREC_F64;  // chomp_set_precision
@@ -397,7 +407,7 @@ void chomp_ctx_destroy(chomp_ctx* ctx) {
   void* ptrs[] = {ctx->d_sici, ctx->d_j0, ctx->d_j2, ctx->d_tinker, ctx->d_gl16,
                   ctx->d_cand, ctx->d_cosmo, ctx->d_z, ctx->d_epochs, ctx->d_search, ctx->d_probe, ctx->d_count, ctx->d_pending,
                   ctx->d_tab, ctx->d_mass_par, ctx->d_profile, ctx->d_hod, ctx->d_nodes, ctx->d_snodes, ctx->d_slot, ctx->d_first, ctx->d_status, ctx->d_endp, ctx->d_npend,
-                  ctx->d_stage_in, ctx->d_stage_in2, ctx->d_stage_out, ctx->d_slow, ctx->d_wnodes, ctx->d_deepw, ctx->d_deepstat,
+                  ctx->d_stage_in, ctx->d_stage_in2, ctx->d_stage_out, ctx->d_slow, ctx->d_wnodes, ctx->d_cnodes, ctx->d_deepw, ctx->d_deepstat,
                   ctx->d_winfo, ctx->d_ktab};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -440,6 +450,12 @@ int chomp_get_timing(chomp_ctx* ctx, double* us, size_t n) {
     HIPCHK(hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));
     us[i] = 1e3 * (double)ms;
   }
+  return CHOMP_OK;
+}
+
+int chomp_get_stream(chomp_ctx* ctx, void** out) {
+  if (!ctx || !out) return CHOMP_ERR_ARG;
+  *out = reinterpret_cast<void*>(ctx->stream);
   return CHOMP_OK;
 }
 
@@ -770,6 +786,80 @@ static int prepare_extrapolation(chomp_ctx* ctx, int which, size_t epoch0, size_
   return CHOMP_OK;
 }
 
+// k_power_prep of the streaming shape: the k-only table (d_ktab, d_winfo) and the list of k
+// groups for the per-lane pass (d_slow, through counter *parity).
+static int stage_e_prep(chomp_ctx* ctx, size_t epoch0, int w, const double* dk, size_t nk,
+                        int* parity) {
+  const TabLayout& L = ctx->L;
+  const unsigned gx = (unsigned)((nk + 511) / 512);
+  const size_t groups = (nk + 127) / 128;
+  // k groups that cannot take the streaming kernel go on a compact list for the per-lane
+  // pass.  Its counters ping-pong on a host-side parity bit (a launch appends through one
+  // and clears the other for the next streaming call).  A call captured into a HIP graph
+  // would replay ONE parity for ever and run its counter past the list, so under capture
+  // the call clears both counters itself (a memset node) and keeps the bit still.
+  const size_t had = ctx->cap_slow;
+  int rc = ensure(ctx, &ctx->d_slow, &ctx->cap_slow, groups + 2);
+  if (rc) return rc;
+  if (ctx->cap_slow != had)                      // fresh buffer: clear both counters
+    HIPCHK(hipMemsetAsync(ctx->d_slow, 0, 2 * sizeof(int), ctx->stream));
+  *parity = ctx->slow_parity;
+  if (capturing(ctx)) ctx->slow_by_memset = true;
+  if (ctx->slow_by_memset) {     // (sticky: a graph may be replayed between any two calls)
+    HIPCHK(hipMemsetAsync(ctx->d_slow, 0, 2 * sizeof(int), ctx->stream));
+    *parity = 0;
+  } else {
+    ctx->slow_parity ^= 1;
+  }
+  const unsigned gx8 = (gx + 7) / 8 * 8;
+  rc = ensure(ctx, &ctx->d_winfo, &ctx->cap_winfo, (size_t)gx8 * 4);
+  if (rc) return rc;
+  rc = ensure(ctx, &ctx->d_ktab, &ctx->cap_ktab, (size_t)gx8 * 1024);
+  if (rc) return rc;
+  if (ctx->with_bao)
+    hipLaunchKernelGGL(k_power_prep<true>, dim3(gx8), dim3(256), 0, ctx->stream, ctx->cfg, L,
+                       ctx->d_epochs, (int)epoch0, w, dk, nk, ctx->d_ktab, ctx->d_winfo,
+                       ctx->d_slow, *parity);
+  else
+    hipLaunchKernelGGL(k_power_prep<false>, dim3(gx8), dim3(256), 0, ctx->stream, ctx->cfg, L,
+                       ctx->d_epochs, (int)epoch0, w, dk, nk, ctx->d_ktab, ctx->d_winfo,
+                       ctx->d_slow, *parity);
+  HIPCHK(hipGetLastError());
+  return CHOMP_OK;
+}
+
+static bool plan_matches(chomp_ctx* ctx, size_t epoch0, const double* dk, size_t nk) {
+  const chomp_ctx::PowerPlan& P = ctx->plan;
+  if (!P.valid || P.k != dk || P.nk != nk || P.bao != ctx->with_bao) return false;
+  if (ctx->sh_cosmo.shadow.size() < (epoch0 + 1) * sizeof(chomp_cosmo)) return false;
+  return std::memcmp(&P.cosmo, ctx->sh_cosmo.shadow.data() + epoch0 * sizeof(chomp_cosmo),
+                     sizeof(chomp_cosmo)) == 0;
+}
+
+int chomp_power_plan(chomp_ctx* ctx, size_t epoch0, const double* k, size_t nk) {
+  if (!ctx || !k || nk == 0) return fail(ctx, CHOMP_ERR_ARG, "power_plan: bad args");
+  if (!ctx->have_epochs || epoch0 >= ctx->n_epoch) return fail(ctx, CHOMP_ERR_STATE, "power_plan: epoch");
+  if (nk % 2 != 0 || reinterpret_cast<uintptr_t>(k) % 16 != 0)
+    return fail(ctx, CHOMP_ERR_ARG, "power_plan: k must be 16-byte aligned with an even length");
+  HIPCHK(hipSetDevice(ctx->device));
+  ctx->plan.valid = false;
+  int parity = 0;
+  int rc = stage_e_prep(ctx, epoch0, CHOMP_P_MM, k, nk, &parity);
+  if (rc) return rc;
+  int n_slow = 0;
+  HIPCHK(hipMemcpyAsync(&n_slow, ctx->d_slow + parity, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->plan.k = k;
+  ctx->plan.nk = nk;
+  std::memcpy(&ctx->plan.cosmo, ctx->sh_cosmo.shadow.data() + epoch0 * sizeof(chomp_cosmo),
+              sizeof(chomp_cosmo));
+  ctx->plan.bao = ctx->with_bao;
+  ctx->plan.parity = parity;
+  ctx->plan.n_slow = n_slow;
+  ctx->plan.valid = true;
+  return CHOMP_OK;
+}
+
 int chomp_power_range(chomp_ctx* ctx, int which, size_t epoch0, size_t n, const double* k,
                       size_t nk, double* out, int mem) {
   int rc = check_power(ctx, which, epoch0, n);
@@ -802,8 +892,7 @@ int chomp_power_range(chomp_ctx* ctx, int which, size_t epoch0, size_t n, const 
   if ((which & CHOMP_P_HALOFIT) == 0 &&
       (reinterpret_cast<uintptr_t>(dk) % 16 == 0) && (reinterpret_cast<uintptr_t>(dout) % 16 == 0)) {
     const unsigned gx = (unsigned)((nk + 511) / 512);
-    const size_t groups = (nk + 127) / 128;
-    bool one_cosmology = true, streaming = true;
+    bool one_cosmology = true, streaming = true, lanes_needed = true;
     for (size_t i = 1; i < n; ++i) one_cosmology &= ctx->slot[epoch0 + i] == ctx->slot[epoch0];
     const int w = which & 15;
     size_t stream_min = (size_t)1 << 22;           // samples; below this the launches dominate
@@ -811,41 +900,21 @@ int chomp_power_range(chomp_ctx* ctx, int which, size_t epoch0, size_t n, const 
     if (ctx->tune[CHOMP_TUNE_E_STREAM_MIN] >= 0) stream_min = (size_t)ctx->tune[CHOMP_TUNE_E_STREAM_MIN];
     int parity = 0;
     if (one_cosmology && w != CHOMP_P_LIN && nk % 2 == 0 && nk * n >= stream_min) {
-      // k groups that cannot take the streaming kernel go on a compact list for the per-lane
-      // pass.  Its counters ping-pong on a host-side parity bit (a launch appends through one
-      // and clears the other for the next streaming call).  A call captured into a HIP graph
-      // would replay ONE parity for ever and run its counter past the list, so under capture
-      // the call clears both counters itself (a memset node) and keeps the bit still.
-      const size_t had = ctx->cap_slow;
-      rc = ensure(ctx, &ctx->d_slow, &ctx->cap_slow, groups + 2);
-      if (rc) return rc;
-      if (ctx->cap_slow != had)                      // fresh buffer: clear both counters
-        HIPCHK(hipMemsetAsync(ctx->d_slow, 0, 2 * sizeof(int), ctx->stream));
-      parity = ctx->slow_parity;
-      if (capturing(ctx)) ctx->slow_by_memset = true;
-      if (ctx->slow_by_memset) {     // (sticky: a graph may be replayed between any two calls)
-        HIPCHK(hipMemsetAsync(ctx->d_slow, 0, 2 * sizeof(int), ctx->stream));
-        parity = 0;
-      } else {
-        ctx->slow_parity ^= 1;
-      }
-      const unsigned gx8 = (gx + 7) / 8 * 8;
-      rc = ensure(ctx, &ctx->d_winfo, &ctx->cap_winfo, (size_t)gx8 * 4);
-      if (rc) return rc;
-      rc = ensure(ctx, &ctx->d_ktab, &ctx->cap_ktab, (size_t)gx8 * 1024);
-      if (rc) return rc;
+      // (a k grid registered with chomp_power_plan keeps its k-only table: no prep launch)
+      const bool planned = mem == CHOMP_DEVICE && plan_matches(ctx, epoch0, dk, nk);
       const bool timed = ctx->timing != 0;
       ctx->timing_valid = false;
       if (timed) HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
-      if (ctx->with_bao)
-        hipLaunchKernelGGL(k_power_prep<true>, dim3(gx8), dim3(256), 0, ctx->stream, ctx->cfg, L,
-                           ctx->d_epochs, (int)epoch0, w, dk, nk, ctx->d_ktab, ctx->d_winfo,
-                           ctx->d_slow, parity);
-      else
-        hipLaunchKernelGGL(k_power_prep<false>, dim3(gx8), dim3(256), 0, ctx->stream, ctx->cfg, L,
-                           ctx->d_epochs, (int)epoch0, w, dk, nk, ctx->d_ktab, ctx->d_winfo,
-                           ctx->d_slow, parity);
+      if (planned) {
+        parity = ctx->plan.parity;
+        lanes_needed = ctx->plan.n_slow != 0;
+      } else {
+        ctx->plan.valid = false;                   // (this call overwrites the table)
+        rc = stage_e_prep(ctx, epoch0, w, dk, nk, &parity);
+        if (rc) return rc;
+      }
       if (timed) HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
+      const unsigned gx8 = (gx + 7) / 8 * 8;
       int per = n % 2 == 0 ? 2 : 1;
       // (chomp_set_tuning: rows per block of the streaming kernel; 2 measured best on MI355X)
       {
@@ -882,8 +951,9 @@ int chomp_power_range(chomp_ctx* ctx, int which, size_t epoch0, size_t n, const 
                            dout, ctx->d_slow, parity, 1, extrap);
       streaming = false;
     }
-    // per-lane pass over the listed k groups (streaming shape only)
-    if (streaming) {
+    // per-lane pass over the listed k groups (streaming shape only; a planned grid knows
+    // whether it has any)
+    if (streaming && lanes_needed) {
       if (ctx->with_bao)
         hipLaunchKernelGGL(k_power_grid_lanes<true>, dim3(1024), dim3(256), 0, ctx->stream, ctx->cfg,
                            L, ctx->d_epochs, ctx->d_tab, w, extrap, (int)epoch0, (int)n, dk, nk, dout,

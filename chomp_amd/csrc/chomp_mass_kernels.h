@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void k_sigma_nodes(chomp_config cfg,
     E.om0 = c.omega_m0; E.ob0 = c.omega_b0; E.ol0 = c.omega_l0; E.or0 = c.omega_r0;
     E.tcmb = c.cmb_temp; E.h = c.h; E.sigma8 = c.sigma_8; E.ns = c.n_scalar;
     E.z = zin[e];
-    epoch_background(E, cfg.cosmo_precision, cfg.k_min, cfg.k_max, BAO ? 1 : 0);
+    epoch_shape_only(E, cfg.k_min, cfg.k_max, BAO ? 1 : 0);    // (amp = 1: bare integrals)
   }
   __syncthreads();
   double* n = snodes + (size_t)slot * kSigmaStride;
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void k_sigma_nodes(chomp_config cfg,
     //  probes certify anyway)
     const double s2 = romberg1<4>(f, lo, hi, cfg.global_precision, 1e-5,
                                   cfg.divmax < 10 ? cfg.divmax : 10, red);
-    if (threadIdx.x == 0) n[kSigmaOffLnS + i] = log(s2 / E.amp);
+    if (threadIdx.x == 0) n[kSigmaOffLnS + i] = log(s2);
     return;
   }
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void k_sigma_nodes(chomp_config cfg,
     SigmaIntegrandT<BAO> f{&E, 8.0};              // sigma_norm = 1: amp * integral
     const double s2 = romberg1<4>(f, lo, hi, cfg.global_precision, cfg.cosmo_precision,
                                   cfg.divmax, red);
-    if (threadIdx.x == 0) i8 = s2 / E.amp;
+    if (threadIdx.x == 0) i8 = s2;
   }
   if (threadIdx.x == 0) n[kSigmaOffI8] = i8;
 }

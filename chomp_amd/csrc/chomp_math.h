@@ -547,6 +547,30 @@ CHOMP_HD void epoch_background(Epoch& e, double cosmo_precision, double k_min,
   if (e.with_bao) bao_constants(e);
 }
 
+// What the cosmology-only integrals (sigma node table, sigma_8, ln S(R)) need of an epoch
+// record: the transfer-function constants, n_s, H0 and the k limits -- with amp = 1 and
+// sigma_norm = 1, so that SigmaIntegrandT integrates the bare shape (k/H0)^(3+n) T^2 W^2.
+// A third of epoch_background's dependent instruction chain (no delta_H, delta_c, delta_v,
+// rho_bar, growth): it sits at the head of every block of k_sigma_nodes.
+CHOMP_HD void epoch_shape_only(Epoch& e, double k_min, double k_max, int with_bao) {
+  e.H0 = 100.0 / (2.998 * 100000.0);
+  e.ln_H0 = log(e.H0);
+  e.k_min = k_min;
+  e.k_max = k_max;
+  const double Omh2 = e.om0 * e.h * e.h;
+  const double ratio = e.ob0 / e.om0;
+  e.eh_theta = e.tcmb / 2.7;
+  e.eh_s = 44.5 * log(9.83 / Omh2) / sqrt(1.0 + 10.0 * 1.0);
+  e.eh_alpha = 1.0 - 0.328 * log(431.0 * Omh2) * ratio +
+               0.38 * log(22.3 * Omh2) * ratio * ratio;
+  e.eh_omh = e.om0 * e.h;
+  e.sigma_norm = 1.0;
+  e.amp = 1.0;
+  e.with_bao = with_bao ? 1 : 0;
+  e.pad_bao = 0;
+  if (e.with_bao) bao_constants(e);
+}
+
 // Constants of the wiggle transfer function (cosmology.py:484-527).
 CHOMP_HD void bao_constants(Epoch& e) {
   const double theta = e.tcmb / 2.7;

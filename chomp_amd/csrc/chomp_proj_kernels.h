@@ -933,15 +933,74 @@ struct CellIntegrand {
   }
 };
 
+// Every multipole integrates over the same chi range, so all of them visit the same Romberg
+// nodes and everything in the integrand that depends on chi alone -- both windows, the growth
+// factor (two spline look-ups each), 1 / chi^2, 1 / D_z^2 -- is tabulated once per call on
+// the level-LT grid (level-major, as w(theta)'s k-only factor): F_j, ln chi_j and chi_j.  A
+// multipole then only evaluates P(l / chi_j) per node, with ln k = ln l - ln chi_j for free.
+// grid ceil((2^LT + 1) / 256), block 256; dynamic LDS ProjLds::doubles(L).
+constexpr int kCellTabLevel = 14;       // 3 x (2^14 + 1) doubles = 384 KiB
+__global__ __launch_bounds__(256) void k_cell_nodes(ProjLayout L, const ProjDev* __restrict__ pdg,
+                                                    const double* __restrict__ ptab, double D_z,
+                                                    int LT, double* __restrict__ nodes) {
+  extern __shared__ __align__(16) double sm[];
+  __shared__ ProjDev pd;
+  copy_doubles(reinterpret_cast<double*>(&pd), reinterpret_cast<const double*>(pdg), kProjDoubles);
+  __syncthreads();
+  ProjLds G;
+  G.stage(L, pd, ptab, sm);
+  G.bess = nullptr;
+  __syncthreads();
+  const long N = (1L << LT) + 1;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N) return;
+  const double a = pd.chi_min, b = pd.chi_max, intrange = b - a;
+  double chi;
+  if (idx < 2) {
+    chi = idx == 0 ? a : b;
+  } else {                                   // the node arithmetic of chomp_romberg.h
+    const unsigned m = (unsigned)(idx - 1);
+    const int lev = 32 - __builtin_clz(m);
+    const long j = (long)m - (1L << (lev - 1));
+    const double h = intrange / (double)(1L << (lev - 1));
+    chi = (a + 0.5 * h) + h * (double)j;
+  }
+  const double D = G.me.growth_factor(G.me.redshift(chi));
+  nodes[idx] = (1.0 / (D_z * D_z)) * G.wa(chi) * G.wb(chi) * D * D / (chi * chi);
+  nodes[N + idx] = log(chi);
+  nodes[2 * N + idx] = chi;
+}
+
+// correlation.py:387-392 from the node table (levels <= LT), directly beyond
+template <bool HF, bool BAO>
+struct CellTabIntegrand {
+  const PowerEval* P;
+  const double* nodes;
+  long N;
+  int LT;
+  double ell, ln_ell;
+  CellIntegrand<BAO> direct;
+  __device__ __forceinline__ void operator()(double chi, double (&out)[1], int lev, long j) const {
+    if (lev <= LT) {
+      const long idx = lev == 0 ? j : 1 + (1L << (lev - 1)) + j;
+      const double kv = ell / nodes[2 * N + idx];
+      out[0] = P->template at_ln<HF, BAO>(ln_ell - nodes[N + idx], kv) * nodes[idx];
+    } else {
+      out[0] = direct(chi);
+    }
+  }
+};
+
 // grid n_ell, block 256: one multipole per workgroup.
-template <bool BAO>
+template <bool HF, bool BAO>
 __global__ __launch_bounds__(256) void k_cell(chomp_config cfg, TabLayout HL, ProjLayout L,
                                               const Epoch* __restrict__ epochs, int e,
                                               const double* __restrict__ htab, int which,
                                               const ProjDev* __restrict__ pdg,
                                               const double* __restrict__ ptab, double D_z,
                                               const double* __restrict__ ell,
-                                              double* __restrict__ out) {
+                                              double* __restrict__ out,
+                                              const double* __restrict__ nodes, int LT) {
   extern __shared__ __align__(16) double sm[];
   __shared__ Epoch E;
   __shared__ ProjDev pd;
@@ -957,10 +1016,11 @@ __global__ __launch_bounds__(256) void k_cell(chomp_config cfg, TabLayout HL, Pr
   G.bess = nullptr;
   __syncthreads();
   P.template finish_t<BAO>();
-  CellIntegrand<BAO> f{&P, &G, ell[blockIdx.x], 1.0 / (D_z * D_z)};
-  const double v = romberg1<4>(f, pd.chi_min, pd.chi_max, cfg.global_precision,
-                               cfg.corr_precision, cfg.divmax, red);
-  if (threadIdx.x == 0) out[blockIdx.x] = v;
+  const double l = ell[blockIdx.x];
+  CellTabIntegrand<HF, BAO> f{&P, nodes, (1L << LT) + 1, LT, l, log(l), {&P, &G, l, 1.0 / (D_z * D_z)}};
+  const RombergOut<1> r = romberg_group<4, 1>(f, pd.chi_min, pd.chi_max, cfg.global_precision,
+                                              cfg.corr_precision, cfg.divmax, red);
+  if (threadIdx.x == 0) out[blockIdx.x] = r.value[0];
 }
 
 // ---------------------------------------------------------------------------

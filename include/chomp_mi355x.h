@@ -113,6 +113,11 @@ const char* chomp_last_error(chomp_ctx* ctx);
 int chomp_set_timing(chomp_ctx* ctx, int on);
 int chomp_get_timing(chomp_ctx* ctx, double* us, size_t n);
 
+/* The HIP stream every call of this context is queued on (the one given to chomp_ctx_create,
+ * or the one it created): a caller that works on another stream orders the two with events
+ * (hipEventRecord / hipStreamWaitEvent) around calls that pass device buffers. */
+int chomp_get_stream(chomp_ctx* ctx, void** out);
+
 /* Block until everything queued on the context's stream has finished. */
 int chomp_sync(chomp_ctx* ctx);
 
@@ -165,6 +170,16 @@ int chomp_power(chomp_ctx* ctx, int which, const double* k, size_t nk,
 /* Same for the epoch range [epoch0, epoch0 + n). */
 int chomp_power_range(chomp_ctx* ctx, int which, size_t epoch0, size_t n,
                       const double* k, size_t nk, double* out, int mem);
+
+/* Register a k grid (device memory, 16-byte aligned, even length) for repeated chomp_power /
+ * chomp_power_range calls over the same cosmology: everything that depends on k alone -- ln k,
+ * its knot interval, the Eisenstein-Hu shape of the linear spectrum (halo.py:649-672,
+ * cosmology.py:449-472) -- is tabulated now, and calls that pass the same pointer and length
+ * for epochs of the same cosmology skip that step.  The caller promises not to modify k[]
+ * while the registration lasts; it ends with the next chomp_power call on another grid (or a
+ * host buffer) that takes the streaming launch shape, or with the context.  No counterpart in
+ * the reference, where every power_mm(k) call recomputes log(k) and the linear spectrum. */
+int chomp_power_plan(chomp_ctx* ctx, size_t epoch0, const double* k, size_t nk);
 
 /* SingleEpoch.sigma_r (cosmology.py:602-642) at n scales for one epoch (host). */
 int chomp_sigma_r(chomp_ctx* ctx, size_t epoch, const double* scale, size_t n,

@@ -516,3 +516,38 @@ def test_graph_capture_refuses_what_a_replay_cannot_honour():
         hg.power("power_mm", k, out=out)
         torch.cuda.synchronize()
         assert torch.equal(out, ref)
+
+
+def test_power_plan_reuses_the_k_table(torch_mod):
+    """chomp_power_plan: a registered k grid skips the k-only step (and, when it holds no k
+    group for the per-lane pass, that launch too).  Same bits as unregistered calls, across
+    spectra and set-ups of the same cosmology; another cosmology or grid ends it silently."""
+    torch = torch_mod
+    from chomp_amd import grid, _lib
+    hg = grid.HaloGrid(numpy.linspace(0.0, 1.5, 8), mass_function="tinker")
+    hg.setup("power_gg")
+    hg.ctx.set_tuning(_lib.TUNE_E_STREAM_MIN, 0)              # streaming shape on a small grid
+    clean = torch.logspace(-3, 2, 1 << 14, dtype=torch.float64, device="cuda")
+    ragged = torch.logspace(-4, 3, 1 << 14, dtype=torch.float64, device="cuda")   # out-of-range ends
+    for k in (clean, ragged):
+        ref = {w: hg.power(w, k).clone() for w in ("power_mm", "power_gm", "power_gg")}
+        hg.ctx.power_plan(k)
+        for _ in range(2):
+            for w, r in ref.items():
+                assert torch.equal(torch.nan_to_num(hg.power(w, k), nan=-7.0),
+                                   torch.nan_to_num(r, nan=-7.0)), w
+        hg.setup("power_gg")                                  # same cosmology: still registered
+        assert torch.equal(hg.power("power_gm", k), ref["power_gm"])
+    # another grid in between, then the registered one again (now unregistered: recomputed)
+    other = hg.power("power_mm", clean)
+    assert torch.equal(hg.power("power_mm", ragged), ref["power_mm"])
+    assert torch.isfinite(other).all()
+    # another cosmology under the same pointer: the registration must not be used
+    hg.ctx.power_plan(clean)
+    cd = dict(__import__("chomp_amd").defaults.default_cosmo_dict, sigma_8=0.75)
+    hg2 = grid.HaloGrid(numpy.linspace(0.0, 1.5, 8), cosmo_dict=cd, mass_function="tinker")
+    hg2.ctx = hg.ctx
+    hg2.setup("power_mm")
+    got = hg2.power("power_mm", clean)
+    fresh = grid.HaloGrid(numpy.linspace(0.0, 1.5, 8), cosmo_dict=cd, mass_function="tinker")
+    assert torch.equal(got, fresh.power("power_mm", clean))
