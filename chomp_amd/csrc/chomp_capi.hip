@@ -6,6 +6,8 @@
 // splines of a fixed 9-row table).
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstddef>
@@ -44,8 +46,28 @@ struct StagedBlock {
   }
 };
 
+// roctx ranges around the stages (chomp_set_tuning CHOMP_TUNE_ROCTX; rocprofv3 --marker-trace):
+// the marker library is looked up at run time, so nothing links against a profiler.
+struct RoctxApi {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  bool load() {
+    if (push) return true;
+    for (const char* lib : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+      void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+      if (!h) continue;
+      push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+      pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+      if (push && pop) return true;
+      push = nullptr; pop = nullptr;
+    }
+    return false;
+  }
+};
+
 struct chomp_ctx {
   chomp_config cfg;
+  RoctxApi roctx;
   int device = 0;
   hipStream_t stream = nullptr;
   bool owns_stream = false;
@@ -80,7 +102,7 @@ struct chomp_ctx {
   unsigned* d_status = nullptr;    // per-epoch status word (chomp_get_status)
   double* d_endp = nullptr;        // integrand pairs of the knots at the upper end point
   int* d_npend = nullptr;          // per epoch: listed knots + 1 token (k_halo_knots_fast)
-  long long tune[CHOMP_TUNE_COUNT] = {-1, -1, -1};   // chomp_set_tuning
+  long long tune[CHOMP_TUNE_COUNT] = {-1, -1, -1, -1};   // chomp_set_tuning
   bool have_epochs = false, have_mass = false, have_halo = false;
   unsigned fam_mask = 0;          // families (F_* bits) with valid splines
   std::vector<char> have_halofit;
@@ -131,6 +153,15 @@ struct chomp_ctx {
 };
 
 namespace {
+
+// Scope of one stage on the host timeline (a no-op unless ranges are switched on).
+struct StageRange {
+  chomp_ctx* ctx;
+  StageRange(chomp_ctx* c, const char* name) : ctx(c && c->roctx.push ? c : nullptr) {
+    if (ctx) ctx->roctx.push(name);
+  }
+  ~StageRange() { if (ctx) ctx->roctx.pop(); }
+};
 
 int fail(chomp_ctx* c, int code, const std::string& msg) {
   if (c) c->err = msg;
@@ -470,6 +501,13 @@ int chomp_set_tuning(chomp_ctx* ctx, int what, long long value) {
   if (!ctx) return CHOMP_ERR_ARG;
   if (what < 0 || what >= CHOMP_TUNE_COUNT) return fail(ctx, CHOMP_ERR_ARG, "set_tuning: unknown knob");
   ctx->tune[what] = value < 0 ? -1 : value;
+  if (what == CHOMP_TUNE_ROCTX) {
+    if (value > 0) {
+      if (!ctx->roctx.load()) return fail(ctx, CHOMP_ERR_STATE, "set_tuning: no roctx library found");
+    } else {
+      ctx->roctx.push = nullptr;
+    }
+  }
   return CHOMP_OK;
 }
 
@@ -499,6 +537,7 @@ int chomp_get_status(chomp_ctx* ctx, size_t epoch0, size_t n, unsigned* out) {
 
 int chomp_epochs_set(chomp_ctx* ctx, size_t n_epoch, const chomp_cosmo* cosmo,
                      const double* z) {
+  StageRange range_(ctx, "chomp:epochs_set (Stage K: sigma tables, mass-limit search)");
   if (!ctx || !cosmo || !z || n_epoch == 0) return fail(ctx, CHOMP_ERR_ARG, "epochs_set: bad args");
   for (size_t i = 0; i < n_epoch; ++i) {
     if (cosmo[i].w0 != -1.0 || cosmo[i].wa != 0.0)
@@ -666,6 +705,7 @@ static int launch_halo_knots(chomp_ctx* ctx, const HaloPlan& P) {
 }
 
 int chomp_mass_setup(chomp_ctx* ctx, const chomp_halo_par* par, int mf_kind) {
+  StageRange range_(ctx, "chomp:mass_setup (Stage K: nu table, mass function)");
   if (!ctx || !par) return fail(ctx, CHOMP_ERR_ARG, "mass_setup: bad args");
   if (!ctx->have_epochs) return fail(ctx, CHOMP_ERR_STATE, "mass_setup before epochs_set");
   if (mf_kind != CHOMP_MF_ST && mf_kind != CHOMP_MF_TINKER)
@@ -683,6 +723,7 @@ int chomp_mass_setup(chomp_ctx* ctx, const chomp_halo_par* par, int mf_kind) {
 
 int chomp_halo_setup(chomp_ctx* ctx, const chomp_halo_par* profile,
                      const chomp_hod_par* hod, unsigned tables) {
+  StageRange range_(ctx, "chomp:halo_setup (Stage K: node tables, knot integrals)");
   if (!ctx || !profile || !hod) return fail(ctx, CHOMP_ERR_ARG, "halo_setup: bad args");
   if (!ctx->have_mass) return fail(ctx, CHOMP_ERR_STATE, "halo_setup before mass_setup");
   HIPCHK(hipSetDevice(ctx->device));
@@ -701,6 +742,7 @@ int chomp_halo_setup(chomp_ctx* ctx, const chomp_halo_par* profile,
 
 int chomp_stage_k(chomp_ctx* ctx, const chomp_halo_par* mass_par, int mf_kind,
                   const chomp_halo_par* profile, const chomp_hod_par* hod, unsigned tables) {
+  StageRange range_(ctx, "chomp:stage_k (Stage K: mass function + halo model)");
   if (!ctx || !mass_par || !profile || !hod) return fail(ctx, CHOMP_ERR_ARG, "stage_k: bad args");
   if (!ctx->have_epochs) return fail(ctx, CHOMP_ERR_STATE, "stage_k before epochs_set");
   if (mf_kind != CHOMP_MF_ST && mf_kind != CHOMP_MF_TINKER)
@@ -862,6 +904,7 @@ int chomp_power_plan(chomp_ctx* ctx, size_t epoch0, const double* k, size_t nk) 
 
 int chomp_power_range(chomp_ctx* ctx, int which, size_t epoch0, size_t n, const double* k,
                       size_t nk, double* out, int mem) {
+  StageRange range_(ctx, "chomp:power (Stage E)");
   int rc = check_power(ctx, which, epoch0, n);
   if (rc) return rc;
   if (!k || !out || nk == 0) return fail(ctx, CHOMP_ERR_ARG, "power: null buffer");

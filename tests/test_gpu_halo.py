@@ -192,7 +192,7 @@ def test_romberg_levels_match_reference(lib):
              "_pp_gm_integrand", "_pp_gg_integrand")
     for i, n in enumerate(names):
         same = numpy.mean(lev[i] == numpy.array(t.levels[n]))
-        assert same >= 0.9, (n, lev[i], t.levels[n])
+        assert same == 1.0, (n, lev[i], t.levels[n])
 
 
 def test_mass_function_and_hod_lookups(lib):

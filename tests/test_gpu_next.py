@@ -337,7 +337,7 @@ def test_gaussian_covariance():
     lev = []
     ocv = o.covariance_table(kt, lambda k: o.halo_power(t, "gg", k), levels=lev)
     agree = numpy.mean(numpy.asarray(lev) == cv._halo_a_levels)
-    assert agree >= 0.9, (lev, cv._halo_a_levels)
+    assert agree == 1.0, (lev, cv._halo_a_levels)
     with pytest.raises(Exception):
         covariance.Covariance(corr, corr)                  # trispectrum terms: scope error
 

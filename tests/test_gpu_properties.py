@@ -551,3 +551,18 @@ def test_power_plan_reuses_the_k_table(torch_mod):
     got = hg2.power("power_mm", clean)
     fresh = grid.HaloGrid(numpy.linspace(0.0, 1.5, 8), cosmo_dict=cd, mass_function="tinker")
     assert torch.equal(got, fresh.power("power_mm", clean))
+
+
+def test_roctx_ranges_switch_on_and_off():
+    """CHOMP_TUNE_ROCTX: the stage ranges (roctxRangePush / Pop through a dlopen'ed marker
+    library) can be switched on and off around a step without changing a result."""
+    from chomp_amd import grid, _lib
+    hg = grid.HaloGrid(numpy.array([0.0, 0.7]))
+    k = numpy.logspace(-2, 1, 16)
+    ref = hg.power("power_mm", k)
+    hg.ctx.set_tuning(_lib.TUNE_ROCTX, 1)
+    hg.setup("power_mm")
+    assert numpy.array_equal(hg.power("power_mm", k), ref)
+    hg.ctx.set_tuning(_lib.TUNE_ROCTX, 0)
+    hg.setup("power_mm")
+    assert numpy.array_equal(hg.power("power_mm", k), ref)

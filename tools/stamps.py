@@ -27,3 +27,10 @@ print("phase durations, mean:", numpy.nanmean(d, axis=(0, 1)), " max:", numpy.na
 print("last-block: certified-arrived mean %.1f  searched-certified mean %.1f max %.1f  end-searched %.1f" % (
     numpy.nanmean(rel[:, :, 5] - rel[:, :, 4]), numpy.nanmean(rel[:, :, 6] - rel[:, :, 5]),
     numpy.nanmax(rel[:, :, 6] - rel[:, :, 5]), numpy.nanmean(rel[:, :, 7] - rel[:, :, 6])))
+pd = rel[:, :, 3] - rel[:, :, 2]
+print("probe duration per role: mean", numpy.nanmean(pd, axis=0), "max", numpy.nanmax(pd, axis=0))
+print("probe duration per epoch (max over roles), every 4th epoch:", numpy.nanmax(pd, axis=1)[::4])
+print("side-0 probes per epoch (mean):", numpy.nanmean(pd[:, :4], axis=1)[::4])
+print("side-1 probes per epoch (mean):", numpy.nanmean(pd[:, 4:], axis=1)[::4])
+pl = rel[:, :, 2] - rel[:, :, 1]
+print("plan duration per role mean", numpy.nanmean(pl, axis=0))
