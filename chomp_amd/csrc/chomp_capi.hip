@@ -692,7 +692,7 @@ static int launch_halo_knots(chomp_ctx* ctx, const HaloPlan& P) {
   size_t shf = deep_fast_lds<kDeepCoarse>(L.NM);
   if (shf < (size_t)finalize_lds_doubles(L.NK) * sizeof(double))
     shf = (size_t)finalize_lds_doubles(L.NK) * sizeof(double);
-  hipLaunchKernelGGL(k_halo_knots_fast<kDeepCoarse>, dim3(gd), dim3(256), shf, ctx->stream,
+  hipLaunchKernelGGL(k_halo_knots_fast<kDeepCoarse>, dim3(gd), dim3(kDeepThreads), shf, ctx->stream,
                      ctx->cfg, L, ctx->d_epochs,
                      ctx->d_tab, ctx->d_profile, ctx->d_hod, ctx->d_sici, P.groups[0],
                      P.groups[1], P.groups[2], P.kmask, (int)n, ctx->d_pending, ctx->d_npend,

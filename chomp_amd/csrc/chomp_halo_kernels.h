@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256) void k_halo_knots(
 }
 
 // ---------------------------------------------------------------------------
-// halo_finalize_block: the end of an epoch's halo set-up by a whole block of 256 threads,
+// halo_finalize_block: the end of an epoch's halo set-up by a whole block (>= 256 threads),
 // once all its knots are final: normalise the families of fam_mask, build their not-a-knot
 // splines over ln k (the builds run in lockstep, one wavefront each, parallel cyclic
 // reduction), the Stage-E record, n_bar into the epoch record.  sm: 51 NK doubles.
@@ -577,8 +577,8 @@ __device__ __forceinline__ void halo_finalize_block(const chomp_config& cfg, con
   }
   const int rounds = (fam_mask >> 4) ? 2 : 1;          // (family 4 = pp_gg is the only one of round 1)
   for (int round = 0; round < rounds; ++round) {
-    const int f = wave + 4 * round;
-    const bool active = f < 5 && ((fam_mask >> f) & 1u);
+    const int f = wave + 4 * round;                      // (wavefronts beyond the fourth only keep
+    const bool active = wave < 4 && f < 5 && ((fam_mask >> f) & 1u);   //  the barriers company)
     if (active) {
       const double n_bar = nbr * rho_bar;
       double scale = 1.0;
@@ -596,8 +596,8 @@ __device__ __forceinline__ void halo_finalize_block(const chomp_config& cfg, con
       if (__any(bad) && lane == 0) atomicOr(&status[e], kStNonfinite);
     }
     __syncthreads();
-    const int fs = f < 5 ? f : 0;
-    spline_build_pcr(xk, yk + fs * NK, NK, t + L.off_kpp[fs], work + wave * 9 * NK, lane, 64,
+    const int fs = active ? f : 0;
+    spline_build_pcr(xk, yk + fs * NK, NK, t + L.off_kpp[fs], work + (wave & 3) * 9 * NK, lane, 64,
                      active);
   }
 }
@@ -629,6 +629,8 @@ __device__ __forceinline__ void halo_finalize_block(const chomp_config& cfg, con
 // break points than expected, the block falls back to the literal evaluation.
 // ---------------------------------------------------------------------------
 constexpr int kDeepCoarse = 11;                            // LC: 2049 coarse samples per knot
+constexpr int kDeepThreads = 256;                          // threads per listed knot
+constexpr int kDeepScratch = romberg_scratch<kDeepThreads / 64, 2>();
 constexpr int kDeepStencil = 8;
 constexpr int kDeepOffsets = kDeepStencil - 1;             // interval o..o+1 of the stencil
 constexpr int kDeepWStride = kDeepOffsets * kDeepStencil;  // weights per level
@@ -793,12 +795,12 @@ __device__ __forceinline__ double deep_coarse_x(double a, double b, int q) {
 template <int LC>
 inline size_t deep_fast_lds(int NM) {
   constexpr int NC = 1 << LC;
-  const size_t deep = (size_t)(NM + 8 * (NM - 1) + kKnotScratch + 2 * (NC + 1) + kDeepWStride) *
+  const size_t deep = (size_t)(NM + 8 * (NM - 1) + kDeepScratch + 2 * (NC + 1) + kDeepWStride) *
                           sizeof(double) + (size_t)((NC + 1 + 15) & ~15);
   return deep;                     // (> finalize_lds_doubles(NK) for any NK <= 512 at LC >= 11)
 }
 
-// grid >= n_epoch (blocks draw knots from the list k_halo_knots left), block 256.  An epoch's
+// grid >= n_epoch (blocks draw knots from the list k_halo_knots left), block kDeepThreads.  An epoch's
 // set-up ends with halo_finalize_block once all its knots are final: npend[e] counts its
 // listed knots plus one token, which block e takes first -- an epoch with nothing listed
 // (every P_mm epoch at the default precision) is finalised right there, otherwise by the
@@ -810,7 +812,10 @@ inline size_t deep_fast_lds(int NM) {
 // points, [3] too many node-by-node intervals, [4] self-check; [5] largest self-check
 // estimate seen (float bits).
 template <int LC>
-__global__ __launch_bounds__(256) void k_halo_knots_fast(
+// (two blocks per CU: the phases of one knot are latency chains -- a few nodes per level in the
+//  break-point intervals -- and a second block fills them; measured 349 vs 417 us on C3
+//  although the register cap spills)
+__global__ __launch_bounds__(kDeepThreads, 2) void k_halo_knots_fast(
     chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs, double* __restrict__ tab,
     const chomp_halo_par* __restrict__ profile, const HodDev* __restrict__ hod,
     const SiCiTab* __restrict__ sici_g, int g0, int g1, int g2, unsigned mask, int n_epoch,
@@ -818,6 +823,7 @@ __global__ __launch_bounds__(256) void k_halo_knots_fast(
     unsigned fam_mask, unsigned* __restrict__ status, const double* __restrict__ deepw,
     int force_literal, int* __restrict__ stats) {
   constexpr int NC = 1 << LC;
+  constexpr int NT = kDeepThreads, NWV = NT / 64;
   extern __shared__ __align__(16) double sm[];
   __shared__ Epoch E;
   __shared__ SiCiTab S;
@@ -868,7 +874,7 @@ __global__ __launch_bounds__(256) void k_halo_knots_fast(
     HaloLds H;
     H.stage(L, E, S, epochs, e, t, profile, hod, sici_g, sm);
     double* red = H.rest;
-    double* F0 = red + kKnotScratch;
+    double* F0 = red + kDeepScratch;
     double* F1 = F0 + (NC + 1);
     double* W = F1 + (NC + 1);
     unsigned char* code = reinterpret_cast<unsigned char*>(W + kDeepWStride);
@@ -883,7 +889,7 @@ __global__ __launch_bounds__(256) void k_halo_knots_fast(
     RombergRows2 R;
     if (!literal) {
       // ---- coarse samples
-      for (int q = tid; q <= NC; q += 256) {
+      for (int q = tid; q <= NC; q += NT) {
         double o[2];
         int st;
         halo_eval_coded(group, c, deep_coarse_x<LC>(a, b, q), o, &st);
@@ -893,24 +899,32 @@ __global__ __launch_bounds__(256) void k_halo_knots_fast(
       }
       if (tid == 0) { n_rough_sh = 0; n_fine_sh = 0; n_seg_sh = 0; }
       __syncthreads();
-      // ---- levels 0..LC from the samples
-      R.start(b - a, cfg.global_precision, cfg.halo_precision, 0.5 * (F0[0] + F0[NC]),
-              0.5 * (F1[0] + F1[NC]), pa, pb);
-      for (int l = 1; l <= LC && !R.all_done(); ++l) {
-        const int stride = NC >> l, cnt = 1 << (l - 1);
-        double s0 = 0.0, s1 = 0.0;
-        for (int j = tid; j < cnt; j += 256) {
-          const int q = stride * (2 * j + 1);
-          s0 += F0[q];
-          s1 += F1[q];
+      // ---- levels 0..LC from the samples: wavefront w sums the levels w + 1, w + 5, ...
+      // (lane-strided, then one butterfly: no block barrier per level), the rows follow
+      {
+        double* lsum = W;                                      // [2][LC + 1], W is free until later
+        const int wv = tid >> 6, ln = tid & 63;
+        for (int l = 1 + wv; l <= LC; l += NWV) {
+          const int stride = NC >> l, cnt = 1 << (l - 1);
+          double s0 = 0.0, s1 = 0.0;
+          for (int j = ln; j < cnt; j += 64) {
+            const int q = stride * (2 * j + 1);
+            s0 += F0[q];
+            s1 += F1[q];
+          }
+          s0 = wave_sum(s0);
+          s1 = wave_sum(s1);
+          if (ln == 0) { lsum[l] = s0; lsum[LC + 1 + l] = s1; }
         }
-        s0 = group_sum<4>(s0, red, flip);
-        s1 = group_sum<4>(s1, red, flip);
-        R.advance(l, s0, s1);
+        __syncthreads();
+        R.start(b - a, cfg.global_precision, cfg.halo_precision, 0.5 * (F0[0] + F0[NC]),
+                0.5 * (F1[0] + F1[NC]), pa, pb);
+        for (int l = 1; l <= LC && !R.all_done(); ++l) R.advance(l, lsum[l], lsum[LC + 1 + l]);
+        __syncthreads();                                       // (W is reused below)
       }
       if (!R.all_done()) {
         // ---- break points: coarse intervals whose ends are in different states
-        for (int i = tid; i < NC; i += 256)
+        for (int i = tid; i < NC; i += NT)
           if (code[i] != code[i + 1]) {
             const int at = atomicAdd(&n_rough_sh, 1);
             if (at < kDeepMaxRough) rough_sh[at] = i;
@@ -928,11 +942,13 @@ __global__ __launch_bounds__(256) void k_halo_knots_fast(
             bool over = false;
             // (pp_gg starts AT M_0 when that lies inside the mass range, halo.py:1002-1006:
             //  the same singular onset, with no change of state to announce it)
-            if (group == 2 && E.ln_nu_lo_second > log(E.nu_min))
+            // (alpha = 1: N_sat is linear in M - M_0 -- a kink, smooth on either side: no margin)
+            const bool singular_onset = E.hod_alpha != 1.0;
+            if (singular_onset && group == 2 && E.ln_nu_lo_second > log(E.nu_min))
               for (int d = 0; d <= kDeepKinkMargin; ++d) fine_sh[nf++] = d;
             for (int x = 0; x < nr; ++x) {
               const int i = rough_sh[x];
-              const int span = ((code[i] ^ code[i + 1]) & 2) ? kDeepKinkMargin : 0;
+              const int span = (((code[i] ^ code[i + 1]) & 2) && singular_onset) ? kDeepKinkMargin : 0;
               for (int d = 0; d <= span && i + d < NC; ++d) {
                 if (nf < kDeepMaxFine) fine_sh[nf++] = i + d; else over = true;
               }
@@ -970,7 +986,7 @@ __global__ __launch_bounds__(256) void k_halo_knots_fast(
             if (stats && tid == 0) atomicAdd(&stats[3], 1);
           } else {
             // interval -> 1 + its segment (0: node by node); the states are no longer needed
-            for (int i = tid; i < NC; i += 256) {
+            for (int i = tid; i < NC; i += NT) {
               int sg = 0;
               for (int x = 0; x < ns; ++x)
                 if (i >= seg_lo[x] && i < seg_hi[x]) sg = x + 1;
@@ -983,7 +999,7 @@ __global__ __launch_bounds__(256) void k_halo_knots_fast(
             // exactly as below) and compared with its true value; at the spacing actually
             // used the interpolation error is 2^8 times smaller.
             double e0 = 0.0, e1 = 0.0, m0 = 0.0, m1 = 0.0;
-            for (int ep = tid; ep < NC / 2; ep += 256) {
+            for (int ep = tid; ep < NC / 2; ep += NT) {
               const int sg = code[2 * ep];
               if (!sg || code[2 * ep + 1] != sg) continue;     // node by node
               const int lo_e = (seg_lo[sg - 1] + 1) >> 1, hi_e = seg_hi[sg - 1] >> 1;   // even nodes / 2
@@ -1000,11 +1016,11 @@ __global__ __launch_bounds__(256) void k_halo_knots_fast(
               e0 += fabs(p0 - F0[2 * ep + 1]);
               e1 += fabs(p1 - F1[2 * ep + 1]);
             }
-            for (int q = tid; q <= NC; q += 256) { m0 += F0[q]; m1 += F1[q]; }
-            e0 = group_sum<4>(e0, red, flip);
-            e1 = group_sum<4>(e1, red, flip);
-            m0 = group_sum<4>(m0, red, flip);
-            m1 = group_sum<4>(m1, red, flip);
+            for (int q = tid; q <= NC; q += NT) { m0 += F0[q]; m1 += F1[q]; }
+            e0 = group_sum<NWV>(e0, red, flip);
+            e1 = group_sum<NWV>(e1, red, flip);
+            m0 = group_sum<NWV>(m0, red, flip);
+            m1 = group_sum<NWV>(m1, red, flip);
             const bool bad0 = !R.done[0] && !(e0 * (1.0 / 256.0) <= kDeepTol * fabs(m0));
             const bool bad1 = !R.done[1] && !(e1 * (1.0 / 256.0) <= kDeepTol * fabs(m1));
             if (bad0 || bad1) literal = true;
@@ -1026,7 +1042,7 @@ __global__ __launch_bounds__(256) void k_halo_knots_fast(
           __syncthreads();
           const int n = 1 << (lv - 1 - LC);
           double s0 = 0.0, s1 = 0.0;
-          for (int i = tid; i < NC; i += 256) {
+          for (int i = tid; i < NC; i += NT) {
             const int sg = code[i];
             if (!sg) continue;                                 // node by node below
             const int lo = seg_lo[sg - 1], hi = seg_hi[sg - 1];
@@ -1042,7 +1058,7 @@ __global__ __launch_bounds__(256) void k_halo_knots_fast(
           const long numtosum = 1L << (lv - 1);
           const double h = (b - a) / (double)numtosum;
           const double lox = a + 0.5 * h;
-          for (int idx = tid; idx < nf * n; idx += 256) {
+          for (int idx = tid; idx < nf * n; idx += NT) {
             const long j = (long)fine_sh[idx / n] * n + (idx % n);
             double o[2];
             int st;
@@ -1050,8 +1066,8 @@ __global__ __launch_bounds__(256) void k_halo_knots_fast(
             s0 += o[0];
             s1 += o[1];
           }
-          s0 = group_sum<4>(s0, red, flip);
-          s1 = group_sum<4>(s1, red, flip);
+          s0 = group_sum<NWV>(s0, red, flip);
+          s1 = group_sum<NWV>(s1, red, flip);
           R.advance(lv, s0, s1);
         }
         val[0] = R.value[0]; val[1] = R.value[1];
@@ -1061,7 +1077,7 @@ __global__ __launch_bounds__(256) void k_halo_knots_fast(
     }
     if (literal) {
       __syncthreads();
-      deep_literal<4>(cfg, c, E, group, pa, red, val, lev, conv);
+      deep_literal<NWV>(cfg, c, E, group, pa, red, val, lev, conv);
     }
     if (tid == 0) {
       if (pa) { t[L.off_knot[fa] + ik] = val[0]; levs[fa * NK + ik] = (double)lev[0]; }

@@ -558,7 +558,8 @@ __device__ __noinline__ double nu_probe(const Epoch& E, const double* snode, dou
   const double up = 1.0 + kAmbiguous, dn = 1.0 - kAmbiguous;
   const RombergLoose loose{rtol_probe, d2 / thr_hi * dn, d2 / thr_hi * up, d2 / thr_lo * dn,
                            d2 / thr_lo * up};
-  return nu_of_mass_block<NW, 1, BAO>(E, snode, m, cfg, cfg.cosmo_precision, red, nullptr, &loose);
+  // (two nodes in flight: their table loads overlap; more costs registers, not time)
+  return nu_of_mass_block<NW, 2, BAO>(E, snode, m, cfg, cfg.cosmo_precision, red, nullptr, &loose);
 }
 
 // The bracketing secant search on exact integrals (whole block).  Returns the mass the
