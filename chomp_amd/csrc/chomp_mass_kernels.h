@@ -355,30 +355,6 @@ __global__ __launch_bounds__(256) void k_sigma_nodes(chomp_config cfg,
   if (threadIdx.x == 0) n[kSigmaOffI8] = i8;
 }
 
-// Delta^2(k) W(kR)^2 / (amp sigma_norm^2) from the table (levels <= kSigmaLevel),
-// direct evaluation beyond.
-template <bool BAO>
-struct SigmaTabIntegrand {
-  const Epoch* e;
-  const double* node;      // this cosmology's table: k_j, then (k_j/H0)^(3+n) T^2 / k_j^6
-  double scale, inv_amp;
-  double nine_over_r6;     // 9 / R^6
-  __device__ __forceinline__ void operator()(double ln_k, double (&out)[1], int lev,
-                                             long j) const {
-    if (lev <= kSigmaLevel) {
-      const int idx = node_index(lev, j);
-      const double kR = scale * node[idx];
-      double s, c;
-      fast_sincos(kR, &s, &c);
-      const double t = s - kR * c;
-      out[0] = node[kSigmaCount + idx] * nine_over_r6 * (t * t);
-    } else {
-      SigmaIntegrandT<BAO> f{e, scale};
-      out[0] = f(ln_k) * inv_amp;
-    }
-  }
-};
-
 // The same integrand where sigma_r's limits follow R: Delta^2 W^2 with the R-independent
 // factor and k interpolated from the cosmology's uniform ln k table (kGTab*; 6-point
 // Lagrange, k through a short series of exp over the fraction of a step).
@@ -417,6 +393,36 @@ struct SigmaInterpIntegrand {
   }
 };
 
+// Delta^2(k) W(kR)^2 / (amp sigma_norm^2) from the table (levels <= kSigmaLevel); beyond it
+// the nodes no longer come from the level-major table but the R-independent factor is still
+// interpolated (SigmaInterpIntegrand; the wiggle transfer function: evaluated directly) --
+// the integrals of the largest masses walk on to level 14, whose 8192 new nodes would
+// otherwise cost four times a table node each.
+template <bool BAO>
+struct SigmaTabIntegrand {
+  const Epoch* e;
+  const double* node;      // this cosmology's table: k_j, then (k_j/H0)^(3+n) T^2 / k_j^6
+  double scale, inv_amp;
+  double nine_over_r6;     // 9 / R^6
+  SigmaInterpIntegrand deep;   // (same normalisation: amp2 = 1)
+  __device__ __forceinline__ void operator()(double ln_k, double (&out)[1], int lev,
+                                             long j) const {
+    if (lev <= kSigmaLevel) {
+      const int idx = node_index(lev, j);
+      const double kR = scale * node[idx];
+      double s, c;
+      fast_sincos(kR, &s, &c);
+      const double t = s - kR * c;
+      out[0] = node[kSigmaCount + idx] * nine_over_r6 * (t * t);
+    } else if (BAO) {
+      SigmaIntegrandT<BAO> f{e, scale};
+      out[0] = f(ln_k) * inv_amp;
+    } else {
+      out[0] = deep(ln_k);
+    }
+  }
+};
+
 // sigma^2(R) = int dlnk Delta^2 W^2 (cosmology.py:602-642) with the whole group on
 // one Romberg integral; `rtol` is cosmo_precision for reference-exact values.
 // UNROLL > 1 overlaps the table loads of several nodes (worth it where few blocks share a
@@ -432,7 +438,10 @@ __device__ __forceinline__ double sigma2_block(const Epoch& E, const double* sno
   const double amp2 = E.amp * E.sigma_norm * E.sigma_norm;
   if (need_min > E.k_min && need_max < E.k_max) {          // fixed range: table path
     const double r3 = R * R * R;
-    SigmaTabIntegrand<BAO> f{&E, snode, R, 1.0 / amp2, 9.0 / (r3 * r3)};
+    const double txlo = log(E.k_min / 100.0), tdx = (log(E.k_max * 100.0) - txlo) / (double)kGTabN;
+    SigmaTabIntegrand<BAO> f{&E, snode, R, 1.0 / amp2, 9.0 / (r3 * r3),
+                             SigmaInterpIntegrand{snode + kSigmaOffG, txlo, tdx, 1.0 / tdx, R,
+                                                  9.0 / (r3 * r3), 1.0, false}};
     RombergLoose ls{0.0, 0.0, 0.0, 0.0, 0.0};          // (the integral is sigma^2 / amp2 here)
     if (loose) ls = RombergLoose{loose->rtol, loose->lo1 / amp2, loose->hi1 / amp2,
                                  loose->lo2 / amp2, loose->hi2 / amp2};
