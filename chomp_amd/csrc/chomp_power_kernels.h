@@ -165,9 +165,9 @@ struct PowerEval {
   __device__ __forceinline__ double at_ln(double lk, double kv) const {
     const bool in = kv >= k_min && kv <= k_max;
     if (HF) {
+      if (w != CHOMP_P_MM && !in) return 0.0;             // halo.py:649-672 range rule
       const double pmm = halofit_mm_ln<BAO>(*E, amp2, lk, kv);
       if (w == CHOMP_P_MM) return pmm;
-      if (!in) return 0.0;                                // halo.py:649-672 range rule
       int i = (int)floor((lk - x0) * inv_dx);
       i = i < 0 ? 0 : (i > NK - 2 ? NK - 2 : i);
       const double d = lk - (x0 + dx * (double)i);

@@ -124,36 +124,122 @@ __global__ __launch_bounds__(256) void k_halofit_sigma(chomp_config cfg, TabLayo
   if (threadIdx.x == 0) tab[(size_t)e * L.stride + L.off_hf_lns2 + i] = log(s2);
 }
 
-// grid 1, block 64 (one lane works, on LDS copies: the serial spline and quintic solves
-// are chains of dependent loads): k_sigma, n_eff, C and the Takahashi et al. coefficients
-// (halo.py:1285-1317) of epoch `src` stored into epoch `dst`.  Dynamic LDS: 25 NK + 64 doubles.
-__global__ void k_halofit_finalize(TabLayout L, Epoch* __restrict__ epochs, int dst, int src,
-                                   const double* __restrict__ tab, double f1, double f2,
-                                   double f3, double omega_l, double w) {
+// First two derivatives at xq of the quintic interpolating spline through (x, y) -- what
+// quintic_derivs (chomp_math.h) computes -- by one wavefront: the collocation rows are set up
+// one per lane, the banded elimination runs its (row, column) updates of a pivot step in
+// parallel lanes, the back substitution its five products.  Same row operations in the same
+// order as the serial routine (only the 5-term sums of the back substitution are added in
+// another order).  x, y: LDS or global; work: (n + 6) + 11 n + n doubles of LDS; n <= 64 rows
+// per pass are handled by striding the lanes.  All 64 lanes call; barriers inside (the block
+// is one wavefront).
+__device__ __forceinline__ void quintic_derivs_wave(const double* x, const double* y, int n,
+                                                    double xq, double* work, double* d1,
+                                                    double* d2) {
+  const int lane = threadIdx.x & 63;
+  double* t = work;               // [n + 6]
+  double* ab = t + (n + 6);       // [n][11] band storage, column j at j - i + 5
+  double* c = ab + 11 * n;        // [n]
+  for (int i = lane; i < 6; i += 64) { t[i] = x[0]; t[n + i] = x[n - 1]; }
+  for (int i = lane; i < n - 6; i += 64) t[6 + i] = x[3 + i];
+  for (int i = lane; i < 11 * n; i += 64) ab[i] = 0.0;
+  __syncthreads();
+  for (int i = lane; i < n; i += 64) {
+    int m = 5;
+    while (m < n - 1 && x[i] >= t[m + 1]) ++m;
+    double N[6];
+    bspline_basis(t, m, 5, x[i], N);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) ab[11 * i + (m - 5 + r - i + 5)] = N[r];
+    c[i] = y[i];
+  }
+  __syncthreads();
+  // banded elimination without pivoting (the collocation matrix is totally positive):
+  // lane = 6 (r - col - 1) + (j - col) updates element (r, j); lanes 30..34 the right-hand side
+  for (int col = 0; col < n; ++col) {
+    const int rr = lane < 30 ? lane / 6 : lane - 30, jj = lane < 30 ? lane % 6 : 0;
+    const int r = col + 1 + rr, j = col + jj;
+    const bool row_ok = lane < 35 && r < n;
+    double f = 0.0;
+    if (row_ok) {
+      const double a = ab[11 * r + (col - r + 5)];
+      f = a == 0.0 ? 0.0 : a / ab[11 * col + 5];
+    }
+    __syncthreads();               // (every lane has read its factor before (r, col) is cleared)
+    if (row_ok && f != 0.0) {
+      if (lane < 30) {
+        if (j < n) ab[11 * r + (j - r + 5)] -= f * ab[11 * col + (j - col + 5)];
+      } else {
+        c[r] -= f * c[col];
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    const int j = i + 1 + lane;
+    double term = (lane < 5 && j < n) ? ab[11 * i + (j - i + 5)] * c[j] : 0.0;
+    term += __shfl_xor(term, 1, 64);
+    term += __shfl_xor(term, 2, 64);
+    term += __shfl_xor(term, 4, 64);
+    if (lane == 0) c[i] = (c[i] - term) / ab[11 * i + 5];
+    __syncthreads();
+  }
+  if (lane == 0) {
+    int m = 5;
+    while (m < n - 1 && xq >= t[m + 1]) ++m;
+    double c1[6], c2[5], N[6];
+    for (int r = 1; r <= 5; ++r) {          // j = m-5+r = m-4 .. m
+      const int j = m - 5 + r;
+      c1[r] = 5.0 * (c[j] - c[j - 1]) / (t[j + 5] - t[j]);
+    }
+    for (int r = 2; r <= 5; ++r) {          // j = m-3 .. m
+      const int j = m - 5 + r;
+      c2[r - 1] = 4.0 * (c1[r] - c1[r - 1]) / (t[j + 4] - t[j]);
+    }
+    bspline_basis(t, m, 4, xq, N);
+    double s1 = 0.0;
+    for (int r = 0; r < 5; ++r) s1 += c1[r + 1] * N[r];
+    bspline_basis(t, m, 3, xq, N);
+    double s2 = 0.0;
+    for (int r = 0; r < 4; ++r) s2 += c2[r + 1] * N[r];
+    *d1 = s1;
+    *d2 = s2;
+  }
+  __syncthreads();
+}
+
+// grid 1, block 64 (one wavefront, on LDS copies): k_sigma, n_eff, C and the Takahashi et al.
+// coefficients (halo.py:1285-1317) of epoch `src` stored into epoch `dst`.  The cubic spline of
+// ln R over ln sigma^2 by parallel cyclic reduction, the quintic one of ln sigma^2 over ln R
+// by quintic_derivs_wave.  Dynamic LDS: 25 NK + 64 doubles.
+__global__ __launch_bounds__(64) void k_halofit_finalize(TabLayout L, Epoch* __restrict__ epochs,
+                                                         int dst, int src,
+                                                         const double* __restrict__ tab, double f1,
+                                                         double f2, double f3, double omega_l,
+                                                         double w) {
   extern __shared__ __align__(16) double work[];
+  __shared__ double sh_d[2];
   const int n = L.NK;
   double* lns2 = work + 24 * n + 64;
-  for (int i = threadIdx.x; i < n; i += blockDim.x)
-    lns2[i] = tab[(size_t)src * L.stride + L.off_hf_lns2 + i];
-  __syncthreads();
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double* xr = work;             // reversed ln sigma^2 (increasing)
   double* yr = xr + n;           // reversed ln R
   double* lnR = yr + n;
   double* c = lnR + n;           // [4(n-1)]
-  double* w2 = c + 4 * (n - 1);  // scratch: max(2n, (n+6) + 12 n)
-  for (int i = 0; i < n; ++i) {
+  double* w2 = c + 4 * (n - 1);  // scratch: max(9 n, (n + 6) + 12 n)
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    lns2[i] = tab[(size_t)src * L.stride + L.off_hf_lns2 + i];
     lnR[i] = linspace_at(log(0.1), log(10.0), n, i);
   }
-  for (int i = 0; i < n; ++i) {
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
     xr[i] = lns2[n - 1 - i];
     yr[i] = lnR[n - 1 - i];
   }
-  spline_build(xr, yr, n, c, w2);
+  __syncthreads();
+  spline_build_pcr(xr, yr, n, c, w2, (int)threadIdx.x, 64, true);
   const double k_s = 1.0 / exp(spline_eval(xr, c, n, 0.0));            // halo.py:1285-1287
-  double d1, d2;
-  quintic_derivs(lnR, lns2, n, log(1.0 / k_s), w2, &d1, &d2);          // :1289-1292
-  const double ne = -d1 - 3.0, C = -d2;
+  quintic_derivs_wave(lnR, lns2, n, log(1.0 / k_s), w2, &sh_d[0], &sh_d[1]);   // :1289-1292
+  if (threadIdx.x != 0) return;
+  const double ne = -sh_d[0] - 3.0, C = -sh_d[1];
   Epoch& E = epochs[dst];
   E.hf_f1 = f1; E.hf_f2 = f2; E.hf_f3 = f3;
   E.hf_k_s = k_s; E.hf_n_eff = ne; E.hf_C = C;
@@ -971,6 +1057,39 @@ __global__ __launch_bounds__(256) void k_cell_nodes(ProjLayout L, const ProjDev*
   nodes[2 * N + idx] = chi;
 }
 
+// P(k) of the spectrum a C_l call integrates, on a uniform grid of kPTabN intervals in ln k
+// over [ln k_min, ln k_max] (one evaluation of PowerEval::at_ln per point, once per call):
+// inside that range a multipole's node then reads P(l / chi) off a 6-point Lagrange stencil
+// (~1e-16 relative at this spacing: the spectrum is smooth in ln k) instead of evaluating
+// three knot splines and the linear spectrum -- or the HaloFit formula -- per node.  Outside
+// the range (zero / the rescaled linear spectrum / the extrapolations, halo.py:300-320) and
+// within two points of its ends the node is evaluated directly.  No-wiggle spectra only.
+// grid ceil((kPTabN + 1) / 256), block 256; dynamic LDS 12 (NK - 1) doubles.
+constexpr int kPTabN = 8192;
+template <bool HF, bool BAO>
+__global__ __launch_bounds__(256) void k_cell_ptab(chomp_config cfg, TabLayout HL,
+                                                   const Epoch* __restrict__ epochs, int e,
+                                                   const double* __restrict__ htab, int which,
+                                                   double* __restrict__ ptab_out) {
+  extern __shared__ __align__(16) double sm[];
+  __shared__ Epoch E;
+  copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
+               kEpochDoubles);
+  PowerEval P;
+  P.stage(cfg, HL, &E, htab + (size_t)e * HL.stride, which, sm);
+  __syncthreads();
+  P.template finish_t<BAO>();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > kPTabN) return;
+  const double x0 = log(cfg.k_min), x1 = log(cfg.k_max);
+  double x = x0 + (x1 - x0) * ((double)i / (double)kPTabN);
+  double k = exp(x);
+  // (the end points exactly: exp(log(k_max)) may round past k_max, where the spectrum is 0)
+  if (i == 0) { k = cfg.k_min; x = x0; }
+  if (i == kPTabN) { k = cfg.k_max; x = x1; }
+  ptab_out[i] = P.template at_ln<HF, BAO>(x, k);
+}
+
 // correlation.py:387-392 from the node table (levels <= LT), directly beyond
 template <bool HF, bool BAO>
 struct CellTabIntegrand {
@@ -979,12 +1098,30 @@ struct CellTabIntegrand {
   long N;
   int LT;
   double ell, ln_ell;
+  const double* ptab;      // k_cell_ptab (nullptr: evaluate the spectrum at every node)
+  double px0, pdx, pinv_dx;
   CellIntegrand<BAO> direct;
+  __device__ __forceinline__ double spectrum(double lk, double kv) const {
+    if (ptab != nullptr) {
+      const double u = (lk - px0) * pinv_dx;
+      const int i = (int)u;
+      if (u >= 2.0 && i <= kPTabN - 4) {                       // full stencil inside the range
+        const double t = u - (double)i;
+        const double* q = ptab + i - 2;
+        const double a = t + 2.0, b = t + 1.0, d = t - 1.0, e = t - 2.0, f = t - 3.0;
+        const double ab = a * b, ef = e * f, cd = t * d;
+        return q[0] * (b * cd * ef) * (-1.0 / 120.0) + q[1] * (a * cd * ef) * (1.0 / 24.0) +
+               q[2] * (ab * d * ef) * (-1.0 / 12.0) + q[3] * (ab * t * ef) * (1.0 / 12.0) +
+               q[4] * (ab * cd * f) * (-1.0 / 24.0) + q[5] * (ab * cd * e) * (1.0 / 120.0);
+      }
+    }
+    return P->template at_ln<HF, BAO>(lk, kv);
+  }
   __device__ __forceinline__ void operator()(double chi, double (&out)[1], int lev, long j) const {
     if (lev <= LT) {
       const long idx = lev == 0 ? j : 1 + (1L << (lev - 1)) + j;
       const double kv = ell / nodes[2 * N + idx];
-      out[0] = P->template at_ln<HF, BAO>(ln_ell - nodes[N + idx], kv) * nodes[idx];
+      out[0] = spectrum(ln_ell - nodes[N + idx], kv) * nodes[idx];
     } else {
       out[0] = direct(chi);
     }
@@ -1000,7 +1137,8 @@ __global__ __launch_bounds__(256) void k_cell(chomp_config cfg, TabLayout HL, Pr
                                               const double* __restrict__ ptab, double D_z,
                                               const double* __restrict__ ell,
                                               double* __restrict__ out,
-                                              const double* __restrict__ nodes, int LT) {
+                                              const double* __restrict__ nodes, int LT,
+                                              const double* __restrict__ pk_tab) {
   extern __shared__ __align__(16) double sm[];
   __shared__ Epoch E;
   __shared__ ProjDev pd;
@@ -1017,7 +1155,9 @@ __global__ __launch_bounds__(256) void k_cell(chomp_config cfg, TabLayout HL, Pr
   __syncthreads();
   P.template finish_t<BAO>();
   const double l = ell[blockIdx.x];
-  CellTabIntegrand<HF, BAO> f{&P, nodes, (1L << LT) + 1, LT, l, log(l), {&P, &G, l, 1.0 / (D_z * D_z)}};
+  const double px0 = log(cfg.k_min), pdx = (log(cfg.k_max) - px0) / (double)kPTabN;
+  CellTabIntegrand<HF, BAO> f{&P, nodes, (1L << LT) + 1, LT, l, log(l), pk_tab, px0, pdx, 1.0 / pdx,
+                              {&P, &G, l, 1.0 / (D_z * D_z)}};
   const RombergOut<1> r = romberg_group<4, 1>(f, pd.chi_min, pd.chi_max, cfg.global_precision,
                                               cfg.corr_precision, cfg.divmax, red);
   if (threadIdx.x == 0) out[blockIdx.x] = r.value[0];
