@@ -740,6 +740,234 @@ __global__ __launch_bounds__(64 * kWthetaNW) void k_wtheta(chomp_config cfg, Tab
 }
 
 // ---------------------------------------------------------------------------
+// w(theta) without visiting the nodes.  The kernel K(ln k + ln theta) is a 50-knot cubic
+// spline -- a piecewise cubic -- and the rest of the integrand is the theta-independent node
+// table g_j of k_wtheta_nodes.  Over the nodes that fall into one piece of the spline the
+// level sum is therefore sum_j g_j (c0 + c1 d_j + c2 d_j^2 + c3 d_j^3), d_j = x_j + ln theta -
+// X_i: a combination of the MOMENTS sum g_j u_j^q (q = 0..3) of the node table over an index
+// range, and those come from prefix sums that do not depend on theta.  A Romberg level of
+// 2^19 nodes then costs a theta one prefix lookup per spline knot (50) instead of 2^19 spline
+// evaluations -- the same sum up to rounding, SciPy's rows and stopping test unchanged.
+//
+// Conditioning: a moment about a far origin would be recombined with large cancellation
+// ((x - X)^3 from powers of x ~ 6), so the ln k range is cut into segments about as wide as a
+// spline piece (never narrower: a piece then meets at most two of them), each with its own
+// origin, and the prefix sums restart at every segment.  Recombination shifts a segment's
+// moments by |delta| <= two piece widths.  Segment membership is integer arithmetic on the node
+// index (wth_seg_of / wth_seg_start), so that both kernels agree on it exactly.
+// Measured agreement with the node-by-node kernel: tests/test_gpu_projection.py.
+// ---------------------------------------------------------------------------
+constexpr int kWthItems = 8;                 // nodes per thread and tile of k_wtheta_moments
+
+// Node j of a level (x_j = a + (b - a)(j + 1/2) / n, n = 2^(lev - 1)) belongs to the segment its
+// abscissa falls into, m = floor((2 j + 1) nseg / 2^lev): 0 <= x_j - O_m < the segment width.
+__device__ __forceinline__ int wth_seg_of(long j, int nseg, int lev) {
+  return (int)(((2 * j + 1) * nseg) >> lev);
+}
+// ... and the first node of segment m, the same statement solved for j (m = nseg: n).
+__device__ __forceinline__ long wth_seg_start(int m, int nseg, int lev) {
+  const long p = ((long)m << lev) - nseg, q = 2L * nseg;
+  return p <= 0 ? 0 : (p + q - 1) / q;
+}
+__device__ __forceinline__ double wth_origin(int m, int nseg, double a, double b) {
+  return a + (b - a) * ((double)m / (double)nseg);
+}
+
+// grid (nseg, LT), block 256: inclusive prefix sums of g_j u_j^q, q = 0..3, u_j = x_j - O_m,
+// over the nodes of segment m of level blockIdx.y + 1, into mom[4 idx + q] (idx: the node's
+// index in the level-major table).  Tiles of 256 * kWthItems nodes with a running carry.
+__global__ __launch_bounds__(256) void k_wtheta_moments(const double* __restrict__ nodes, int LT,
+                                                        int nseg, double a, double b,
+                                                        double* __restrict__ mom) {
+  __shared__ double wtot[2][4][4];
+  const int m = blockIdx.x, lev = blockIdx.y + 1, t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const long n = 1L << (lev - 1);
+  const long j0 = wth_seg_start(m, nseg, lev), j1 = wth_seg_start(m + 1, nseg, lev);
+  if (j0 >= j1) return;                                     // (block-uniform)
+  const double h = (b - a) / (double)n, lox = a + 0.5 * h;
+  const double O = wth_origin(m, nseg, a, b);
+  const long base = 1 + n;                                  // level-major index of j = 0
+  double carry[4] = {0.0, 0.0, 0.0, 0.0};
+  int buf = 0;
+  for (long tile = j0; tile < j1; tile += 256L * kWthItems, buf ^= 1) {
+    const long c0 = tile + (long)t * kWthItems;
+    double v[kWthItems][4];
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < kWthItems; ++i) {
+      const long j = c0 + i;
+      if (j < j1) {
+        const double g = nodes[base + j], u = (lox + h * (double)j) - O;
+        s[0] += g; s[1] += g * u; s[2] += g * (u * u); s[3] += g * (u * u * u);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[i][q] = s[q];
+    }
+    double inc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) inc[q] = s[q];
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double y = __shfl_up(inc[q], off, 64);
+        if (lane >= off) inc[q] += y;
+      }
+    }
+    if (lane == 63) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wtot[buf][w][q] = inc[q];
+    }
+    __syncthreads();
+    double pre[4], next[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double before = 0.0, all = 0.0;
+#pragma unroll
+      for (int ww = 0; ww < 4; ++ww) {
+        const double x = wtot[buf][ww][q];
+        if (ww < w) before += x;
+        all += x;
+      }
+      pre[q] = carry[q] + before + (inc[q] - s[q]);
+      next[q] = carry[q] + all;
+    }
+#pragma unroll
+    for (int i = 0; i < kWthItems; ++i) {
+      const long j = c0 + i;
+      if (j < j1) {
+        double2* o = reinterpret_cast<double2*>(mom + 4 * (base + j));
+        o[0] = make_double2(pre[0] + v[i][0], pre[1] + v[i][1]);
+        o[1] = make_double2(pre[2] + v[i][2], pre[3] + v[i][3]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) carry[q] = next[q];
+  }
+}
+
+// Moments of the whole of segment m (0 for an empty one).
+__device__ __forceinline__ void wth_seg_total(const double* __restrict__ mom, long base, int m,
+                                              int nseg, int lev, double (&T)[4]) {
+  const long g0 = wth_seg_start(m, nseg, lev), g1 = wth_seg_start(m + 1, nseg, lev);
+  if (g1 > g0) {
+    const double2* p = reinterpret_cast<const double2*>(mom + 4 * (base + g1 - 1));
+    const double2 x = p[0], y = p[1];
+    T[0] = x.x; T[1] = x.y; T[2] = y.x; T[3] = y.y;
+  } else {
+    T[0] = T[1] = T[2] = T[3] = 0.0;
+  }
+}
+// sum over a range of c0 + c1 d + c2 d^2 + c3 d^3, d = u + dl, from the range's moments in u.
+__device__ __forceinline__ double wth_combine(const double (&D)[4], double dl, double c0, double c1,
+                                              double c2, double c3) {
+  const double p1 = D[1] + dl * D[0];
+  const double p2 = D[2] + dl * (2.0 * D[1] + dl * D[0]);
+  const double p3 = D[3] + dl * (3.0 * D[2] + dl * (3.0 * D[1] + dl * D[0]));
+  return c0 * D[0] + c1 * p1 + c2 * p2 + c3 * p3;
+}
+
+// grid n_theta, block 256: one theta per workgroup, one Romberg level per wavefront and round
+// (four levels a round); lane i <= NP holds knot i of the kernel spline: the first node at or
+// beyond it and the prefix moments just below.  Levels <= LT only (the host keeps the
+// node-by-node kernel for a divmax beyond the table).  Needs NKT <= 63.
+__global__ __launch_bounds__(256) void k_wtheta_fast(chomp_config cfg, ProjLayout L,
+                                                     const ProjDev* __restrict__ pd,
+                                                     const double* __restrict__ ptab, double k_min,
+                                                     double k_max, const double* __restrict__ theta,
+                                                     double* __restrict__ out,
+                                                     const double* __restrict__ nodes,
+                                                     const double* __restrict__ mom, int LT,
+                                                     int nseg) {
+  __shared__ double level_sum[2][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double a = log(k_min), b = log(k_max);
+  const double lo = pd->ln_kt_min, hi = pd->ln_kt_max;
+  const int NP = L.NKT - 1;                              // spline pieces
+  const double dxK = (hi - lo) / (double)NP;
+  const double s = log(theta[blockIdx.x]);
+  const double* pp = ptab + L.k_pp;
+  const int piece = lane < NP ? lane : NP - 1;
+  const double c0 = pp[4 * piece], c1 = pp[4 * piece + 1], c2 = pp[4 * piece + 2],
+               c3 = pp[4 * piece + 3];
+  const double k_lo = pp[0];                             // K below its range (kernel.py:723-725)
+  const double X = lo + dxK * (double)lane;              // knot i (= hi for lane NP, up to rounding)
+  const KernelView K{pp, L.NKT, lo, hi};
+  RombergRows2 R;
+  R.start(b - a, cfg.global_precision, cfg.corr_precision,
+          0.5 * (nodes[0] * K(a + s) + nodes[1] * K(b + s)), 0.0, true, false);
+  for (int g = 0; 4 * g < LT && !R.all_done(); ++g) {
+    const int lv = 4 * g + 1 + wave;
+    double contrib = 0.0;
+    if (lv <= LT) {                                      // (wave-uniform)
+      const long n = 1L << (lv - 1);
+      const double h = (b - a) / (double)n, lox = a + 0.5 * h, inv_h = 1.0 / h;
+      const long base = 1 + n;
+      // B: the first node of this lane's region (piece i, or beyond the range for lane NP)
+      long B = 0;
+      if (lane < NP) {
+        const double q = ceil((X - s - lox) * inv_h);
+        B = q <= 0.0 ? 0 : (q >= (double)n ? n : (long)q);
+      } else if (lane == NP) {                           // x + s == hi still inside (kernel.py:728)
+        const double q = floor((hi - s - lox) * inv_h) + 1.0;
+        B = q <= 0.0 ? 0 : (q >= (double)n ? n : (long)q);
+      }
+      int mB = 0;
+      double P[4] = {0.0, 0.0, 0.0, 0.0};
+      if (lane <= NP && B >= 1) {
+        mB = wth_seg_of(B - 1, nseg, lv);
+        const double2* p = reinterpret_cast<const double2*>(mom + 4 * (base + B - 1));
+        const double2 x = p[0], y = p[1];
+        P[0] = x.x; P[1] = x.y; P[2] = y.x; P[3] = y.y;
+      }
+      // the next knot's
+      const long Bn = __shfl_down((long long)B, 1, 64);
+      const int mn = __shfl_down(mB, 1, 64);
+      double Pn[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Pn[q] = __shfl_down(P[q], 1, 64);
+      if (lane < NP && Bn > B) {
+        if (mn == mB && B >= 1) {
+          const double D[4] = {Pn[0] - P[0], Pn[1] - P[1], Pn[2] - P[2], Pn[3] - P[3]};
+          contrib = wth_combine(D, wth_origin(mB, nseg, a, b) + s - X, c0, c1, c2, c3);
+        } else {
+          // the rest of segment mB, whole segments between, the head of segment mn
+          double T[4];
+          if (B >= 1) {
+            wth_seg_total(mom, base, mB, nseg, lv, T);
+            const double D[4] = {T[0] - P[0], T[1] - P[1], T[2] - P[2], T[3] - P[3]};
+            contrib = wth_combine(D, wth_origin(mB, nseg, a, b) + s - X, c0, c1, c2, c3);
+          }
+          for (int m = B >= 1 ? mB + 1 : 0; m < mn; ++m) {
+            wth_seg_total(mom, base, m, nseg, lv, T);
+            contrib += wth_combine(T, wth_origin(m, nseg, a, b) + s - X, c0, c1, c2, c3);
+          }
+          contrib += wth_combine(Pn, wth_origin(mn, nseg, a, b) + s - X, c0, c1, c2, c3);
+        }
+      }
+      // nodes below the kernel's range: K(lo) times the plain sum of g over [0, B_0)
+      const long B0 = __shfl((long long)B, 0, 64);
+      if (B0 >= 1) {
+        const int m0 = __shfl(mB, 0, 64);
+        double below = lane == 0 ? P[0] : 0.0;
+        for (int m = lane; m < m0; m += 64) {
+          double T[4];
+          wth_seg_total(mom, base, m, nseg, lv, T);
+          below += T[0];
+        }
+        contrib += k_lo * below;
+      }
+    }
+    const double S = wave_sum(contrib);
+    if (lane == 0) level_sum[g & 1][wave] = S;
+    __syncthreads();
+    for (int q = 0; q < 4 && 4 * g + 1 + q <= LT && !R.all_done(); ++q)
+      R.advance(4 * g + 1 + q, level_sum[g & 1][q], 0.0);
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = R.value[0];
+}
+
+// ---------------------------------------------------------------------------
 // Precision sweep of w(theta) (BASELINE.json configs[4]): the same
 // integral with parts of the arithmetic in fp32.
 //   CHOMP_PREC_F32_EVAL    integrand evaluated in fp32 from the fp64 tables, fp64 sums

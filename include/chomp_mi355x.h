@@ -290,6 +290,8 @@ int chomp_get_status(chomp_ctx* ctx, size_t epoch0, size_t n, unsigned* out);
  *   CHOMP_TUNE_E_ROWS        rows per block of the streaming kernel (1, 2 or 4)
  *   CHOMP_TUNE_DEEP_LITERAL  1: knots beyond the node tables by literal evaluation of every
  *                            Romberg node (the checker of the fast deep-level sums)
+ *   CHOMP_TUNE_WTHETA_DIRECT 1: w(theta) by evaluating the kernel spline at every Romberg node
+ *                            (the checker of the moment route of chomp_wtheta)
  *   CHOMP_TUNE_ROCTX         1: roctx ranges around the stages on the host timeline (one per
  *                            entry point: "chomp:epochs_set", "chomp:stage_k", "chomp:power",
  *                            "chomp:wtheta", ...; rocprofv3 --marker-trace shows them over
@@ -299,7 +301,8 @@ int chomp_get_status(chomp_ctx* ctx, size_t epoch0, size_t n, unsigned* out);
 #define CHOMP_TUNE_E_ROWS 1
 #define CHOMP_TUNE_DEEP_LITERAL 2
 #define CHOMP_TUNE_ROCTX 3
-#define CHOMP_TUNE_COUNT 4
+#define CHOMP_TUNE_WTHETA_DIRECT 4
+#define CHOMP_TUNE_COUNT 5
 int chomp_set_tuning(chomp_ctx* ctx, int what, long long value);
 /* Measurement aid: out[6] <- knots beyond the node tables done so far (since the context was
  * created) by [0] the fast deep-level sums, [1] literal evaluation of every node; why literal:

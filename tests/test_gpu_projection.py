@@ -148,3 +148,30 @@ def test_c5_precision_sweep(mods):
     assert errs["fp32_tables"] < 1e-6
     assert errs["fp32_eval"] < RTOL and errs["fp32_all"] < RTOL
     assert errs["fp64"] <= min(errs["fp32_eval"], errs["fp32_all"])
+
+
+@pytest.mark.parametrize("ggl", [False, True])
+def test_wtheta_moment_route_matches_node_by_node(mods, ggl):
+    """chomp_wtheta sums each Romberg level from prefix sums of the node table's moments
+    (k_wtheta_moments / k_wtheta_fast); CHOMP_TUNE_WTHETA_DIRECT evaluates the kernel spline at
+    every node instead.  Same rows, same stopping rule: the two agree to rounding, over a theta
+    range wider than the binned one (kernel range partly and wholly outside the ln k range)."""
+    from chomp_amd import _lib
+    cosmology, kernel, correlation, halo = mods
+    cm, kern = _projection(mods, ggl)
+    h = halo.HaloFit(0.0) if ggl else halo.Halo(0.0)
+    corr = correlation.Correlation(0.001, 1.0, kern, input_halo=h,
+                                   power_spec="power_gm" if ggl else "power_gg")
+    ctx, _ = corr._prepare()
+    theta = numpy.logspace(-6.5, 0.5, 97) * D2R
+    try:
+        ctx.set_tuning(_lib.TUNE_WTHETA_DIRECT, 1)
+        direct = corr.correlation(theta)
+    finally:
+        ctx.set_tuning(_lib.TUNE_WTHETA_DIRECT, -1)
+    fast = corr.correlation(theta)
+    scale = numpy.max(numpy.abs(direct))
+    assert numpy.all(numpy.isfinite(fast))
+    assert numpy.max(numpy.abs(fast - direct)) < 1e-10 * scale
+    ok = numpy.abs(direct) > 1e-6 * scale
+    assert numpy.max(numpy.abs(fast[ok] / direct[ok] - 1)) < 1e-8
