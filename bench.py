@@ -225,7 +225,7 @@ def projection_leg(D, ggl, steps, warmup):
         h._reset_flags(all_tables=True)
         if ggl:
             h._initialized_sigma_spline = False
-        ctx, code = corr._prepare()
+        ctx, code = corr._prepare(defer_status=True)   # (device in, device out: no sync)
         w = ctx.wtheta(code, 0, corr._k_lim[0], corr._k_lim[1], corr.D_z, my_theta)
         c = ctx.cell(code, 0, corr.D_z, my_ell)
         if D.world > 1:                      # one all-gather per output array

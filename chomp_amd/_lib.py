@@ -102,7 +102,8 @@ EXPORTS = [
     "chomp_set_precision", "chomp_xi3d", "chomp_spline_eval", "chomp_hod_stats",
     "chomp_set_transfer", "chomp_kernel_raw",
     "chomp_covariance_table", "chomp_covariance_gaussian",
-    "chomp_set_timing", "chomp_get_timing", "chomp_get_status", "chomp_set_tuning",
+    "chomp_set_timing", "chomp_get_timing", "chomp_get_status", "chomp_status_post",
+    "chomp_status_wait", "chomp_set_tuning",
     "chomp_get_deep_stats", "chomp_stage_k", "chomp_power_plan", "chomp_get_stream",
 ]
 
@@ -289,6 +290,8 @@ def lib():
         L.chomp_set_timing.argtypes = [vp, i]
         L.chomp_get_timing.argtypes = [vp, c_double_p, sz]
         L.chomp_get_status.argtypes = [vp, sz, sz, ctypes.POINTER(ctypes.c_uint)]
+        L.chomp_status_post.argtypes = [vp]
+        L.chomp_status_wait.argtypes = [vp, sz, sz, ctypes.POINTER(ctypes.c_uint)]
         L.chomp_set_tuning.argtypes = [vp, i, ctypes.c_longlong]
         L.chomp_get_deep_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_longlong)]
         L.chomp_covariance_table.argtypes = [vp, i, sz, d, c_double_p, c_double_p,
@@ -593,12 +596,27 @@ class Context(object):
                 self._h, epoch0, n, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint))))
         return out
 
-    def warn_status(self, epoch0=0, n=None, stacklevel=3):
+    def status_post(self):
+        """Enqueue a copy of the status words to pinned host memory (chomp_status_post): no
+        synchronisation; status_wait / warn_status(posted=True) pick it up."""
+        self._check(self._L.chomp_status_post(self._h))
+
+    def status_wait(self, epoch0=0, n=None):
+        """The words of the last status_post (waits for that copy only, not for the stream)."""
+        n = self.n_epoch - epoch0 if n is None else n
+        out = numpy.zeros(n, dtype=numpy.uint32)
+        if n:
+            self._check(self._L.chomp_status_wait(
+                self._h, epoch0, n, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint))))
+        return out
+
+    def warn_status(self, epoch0=0, n=None, stacklevel=3, posted=False):
         """Turn the status words of the epochs into Python warnings, as the reference's
         scipy.integrate.romberg did for an exhausted divmax (AccuracyWarning); a saturated
-        mass-limit search gets a ChompParityWarning.  Returns the words."""
+        mass-limit search gets a ChompParityWarning.  Returns the words.  posted: the words of
+        the last status_post instead of a fresh (synchronising) read."""
         import warnings
-        words = self.status(epoch0, n)
+        words = self.status_wait(epoch0, n) if posted else self.status(epoch0, n)
         for i, w in enumerate(words):
             w = int(w)
             if not w:

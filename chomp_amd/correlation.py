@@ -107,15 +107,16 @@ class Correlation(object):
     def set_hod_object(self, input_hod):
         self.halo.set_hod_object(input_hod)
 
-    def _prepare(self, power_name=None):
-        """Halo tables and projection tables in ONE device context."""
+    def _prepare(self, power_name=None, defer_status=False):
+        """Halo tables and projection tables in ONE device context.  defer_status: see
+        Halo._sync (the device-resident evaluation path synchronises nowhere)."""
         code, need = _POWER[self._power_name if power_name is None else power_name]
         if isinstance(self.halo, halo_mod.HaloFit) and code != _lib.P_LIN:
-            self.halo._ensure_halofit()
+            self.halo._ensure_halofit(defer_status=defer_status)
             code |= _lib.P_HALOFIT
             if (code & 15) == _lib.P_MM:
                 need = 0
-        ctx = self.halo._sync(need)
+        ctx = self.halo._sync(need, defer_status=defer_status)
         self.kernel._setup_on(ctx)
         return ctx, self.halo._power_code(code)
 
@@ -124,9 +125,10 @@ class Correlation(object):
 
     def correlation(self, theta_rad):
         th = numpy.asarray(theta_rad, dtype=numpy.float64)
-        ctx, code = self._prepare()
+        ctx, code = self._prepare(defer_status=True)
         out = ctx.wtheta(code, 0, self._k_lim[0], self._k_lim[1], self.D_z,
                          numpy.ascontiguousarray(th).ravel())
+        self.halo._resolve_status()            # (the result is on the host: nothing to hide)
         return float(out[0]) if th.ndim == 0 else out.reshape(th.shape)
 
     def write(self, output_file_name):
@@ -170,8 +172,9 @@ class CorrelationFourier(Correlation):
 
     def correlation(self, l):
         la = numpy.asarray(l, dtype=numpy.float64)
-        ctx, code = self._prepare()
+        ctx, code = self._prepare(defer_status=True)
         out = ctx.cell(code, 0, self.D_z, numpy.ascontiguousarray(la).ravel())
+        self.halo._resolve_status()
         return float(out[0]) if la.ndim == 0 else out.reshape(la.shape)
 
     def write(self, output_file_name):
@@ -217,7 +220,7 @@ class Correlation3d(Correlation):
     def _prepare(self):
         code, need = _POWER[self._power_name]
         if isinstance(self.halo, halo_mod.HaloFit) and code != _lib.P_LIN:
-            self.halo._ensure_halofit()
+            self.halo._ensure_halofit(defer_status=defer_status)
             code |= _lib.P_HALOFIT
             if (code & 15) == _lib.P_MM:
                 need = 0

@@ -109,6 +109,9 @@ struct chomp_ctx {
   StagedBlock sh_cosmo, sh_z, sh_mass, sh_profile, sh_hod, sh_slot, sh_first;
   StagedBlock sh_proj, sh_pp[2];   // projection scalars, tabulated redshift distributions
   // pinned host mirrors of the staging buffers of host-pointer calls (chomp_power)
+  unsigned* h_status = nullptr;    // chomp_status_post: pinned copy of d_status ...
+  size_t cap_hstatus = 0, n_hstatus = 0;
+  hipEvent_t ev_status = nullptr;  // ... complete when this event is
   double* h_stage_in = nullptr;
   double* h_stage_out = nullptr;
   size_t cap_hin = 0, cap_hout = 0;
@@ -447,6 +450,8 @@ void chomp_ctx_destroy(chomp_ctx* ctx) {
                          &ctx->sh_slot, &ctx->sh_first, &ctx->sh_proj, &ctx->sh_pp[0],
                          &ctx->sh_pp[1]})
     b->release();
+  if (ctx->h_status) (void)hipHostFree(ctx->h_status);
+  if (ctx->ev_status) (void)hipEventDestroy(ctx->ev_status);
   if (ctx->h_stage_in) (void)hipHostFree(ctx->h_stage_in);
   if (ctx->h_stage_out) (void)hipHostFree(ctx->h_stage_out);
   proj_free(ctx->proj);
@@ -532,6 +537,37 @@ int chomp_get_status(chomp_ctx* ctx, size_t epoch0, size_t n, unsigned* out) {
   HIPCHK(hipMemcpyAsync(out, ctx->d_status + epoch0, n * sizeof(unsigned), hipMemcpyDeviceToHost,
                         ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  return CHOMP_OK;
+}
+
+int chomp_status_post(chomp_ctx* ctx) {
+  if (!ctx) return CHOMP_ERR_ARG;
+  if (!ctx->have_epochs) return fail(ctx, CHOMP_ERR_STATE, "status_post before epochs_set");
+  HIPCHK(hipSetDevice(ctx->device));
+  if (capturing(ctx)) return fail(ctx, CHOMP_ERR_STATE, "status_post during stream capture");
+  if (ctx->n_epoch > ctx->cap_hstatus || !ctx->h_status) {
+    if (ctx->ev_status) HIPCHK(hipEventSynchronize(ctx->ev_status));   // (a copy may be in flight)
+    if (ctx->h_status) HIPCHK(hipHostFree(ctx->h_status));
+    ctx->h_status = nullptr;
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_status), ctx->n_epoch * sizeof(unsigned),
+                         hipHostMallocDefault));
+    ctx->cap_hstatus = ctx->n_epoch;
+  }
+  if (!ctx->ev_status) HIPCHK(hipEventCreateWithFlags(&ctx->ev_status, hipEventDisableTiming));
+  HIPCHK(hipMemcpyAsync(ctx->h_status, ctx->d_status, ctx->n_epoch * sizeof(unsigned),
+                        hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipEventRecord(ctx->ev_status, ctx->stream));
+  ctx->n_hstatus = ctx->n_epoch;
+  return CHOMP_OK;
+}
+
+int chomp_status_wait(chomp_ctx* ctx, size_t epoch0, size_t n, unsigned* out) {
+  if (!ctx || !out || n == 0) return fail(ctx, CHOMP_ERR_ARG, "status_wait: bad args");
+  if (!ctx->n_hstatus) return fail(ctx, CHOMP_ERR_STATE, "status_wait before status_post");
+  if (epoch0 + n > ctx->n_hstatus) return fail(ctx, CHOMP_ERR_ARG, "status_wait: epoch range");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipEventSynchronize(ctx->ev_status));
+  std::memcpy(out, ctx->h_status + epoch0, n * sizeof(unsigned));
   return CHOMP_OK;
 }
 
@@ -692,12 +728,15 @@ static int launch_halo_knots(chomp_ctx* ctx, const HaloPlan& P) {
   size_t shf = deep_fast_lds<kDeepCoarse>(L.NM);
   if (shf < (size_t)finalize_lds_doubles(L.NK) * sizeof(double))
     shf = (size_t)finalize_lds_doubles(L.NK) * sizeof(double);
-  hipLaunchKernelGGL(k_halo_knots_fast<kDeepCoarse>, dim3(gd), dim3(kDeepThreads), shf, ctx->stream,
-                     ctx->cfg, L, ctx->d_epochs,
-                     ctx->d_tab, ctx->d_profile, ctx->d_hod, ctx->d_sici, P.groups[0],
-                     P.groups[1], P.groups[2], P.kmask, (int)n, ctx->d_pending, ctx->d_npend,
-                     ctx->d_epochs, P.fam, ctx->d_status, ctx->d_deepw,
-                     ctx->tune[CHOMP_TUNE_DEEP_LITERAL] > 0 ? 1 : 0, ctx->d_deepstat);
+#define CHOMP_KNOTS_FAST(NT)                                                                     \
+  hipLaunchKernelGGL((k_halo_knots_fast<kDeepCoarse, NT>), dim3(gd), dim3(NT), shf, ctx->stream,    \
+                     ctx->cfg, L, ctx->d_epochs, ctx->d_tab, ctx->d_profile, ctx->d_hod,            \
+                     ctx->d_sici, P.groups[0], P.groups[1], P.groups[2], P.kmask, (int)n,           \
+                     ctx->d_pending, ctx->d_npend, ctx->d_epochs, P.fam, ctx->d_status,             \
+                     ctx->d_deepw, ctx->tune[CHOMP_TUNE_DEEP_LITERAL] > 0 ? 1 : 0, ctx->d_deepstat)
+  if ((size_t)L.NK * n * ng <= 768) CHOMP_KNOTS_FAST(kDeepThreadsFew);
+  else CHOMP_KNOTS_FAST(kDeepThreads);
+#undef CHOMP_KNOTS_FAST
   HIPCHK(hipGetLastError());
   ctx->have_halo = true;
   ctx->fam_mask |= P.fam;

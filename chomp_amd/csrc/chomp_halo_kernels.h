@@ -629,8 +629,9 @@ __device__ __forceinline__ void halo_finalize_block(const chomp_config& cfg, con
 // break points than expected, the block falls back to the literal evaluation.
 // ---------------------------------------------------------------------------
 constexpr int kDeepCoarse = 11;                            // LC: 2049 coarse samples per knot
-constexpr int kDeepThreads = 256;                          // threads per listed knot
-constexpr int kDeepScratch = romberg_scratch<kDeepThreads / 64, 2>();
+constexpr int kDeepThreads = 256;                          // threads per listed knot ...
+constexpr int kDeepThreadsFew = 512;                       // ... and when the list cannot fill the chip
+constexpr int kDeepScratch = romberg_scratch<kDeepThreadsFew / 64, 2>();
 constexpr int kDeepStencil = 8;
 constexpr int kDeepOffsets = kDeepStencil - 1;             // interval o..o+1 of the stencil
 constexpr int kDeepWStride = kDeepOffsets * kDeepStencil;  // weights per level
@@ -811,11 +812,13 @@ inline size_t deep_fast_lds(int NM) {
 // [0] knots done by the fast path, [1] by the literal one; why literal: [2] too many break
 // points, [3] too many node-by-node intervals, [4] self-check; [5] largest self-check
 // estimate seen (float bits).
-template <int LC>
-// (two blocks per CU: the phases of one knot are latency chains -- a few nodes per level in the
-//  break-point intervals -- and a second block fills them; measured 349 vs 417 us on C3
+// NT: kDeepThreads, or kDeepThreadsFew when there are at most about two knots per CU to do (one
+// epoch): the launch then lasts as long as one knot, and a knot's phases are spread wider.
+template <int LC, int NT>
+// (eight wavefronts per CU: the phases of one knot are latency chains -- a few nodes per level in
+//  the break-point intervals -- and a second block fills them; measured 349 vs 417 us on C3
 //  although the register cap spills)
-__global__ __launch_bounds__(kDeepThreads, 2) void k_halo_knots_fast(
+__global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
     chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs, double* __restrict__ tab,
     const chomp_halo_par* __restrict__ profile, const HodDev* __restrict__ hod,
     const SiCiTab* __restrict__ sici_g, int g0, int g1, int g2, unsigned mask, int n_epoch,
@@ -823,7 +826,7 @@ __global__ __launch_bounds__(kDeepThreads, 2) void k_halo_knots_fast(
     unsigned fam_mask, unsigned* __restrict__ status, const double* __restrict__ deepw,
     int force_literal, int* __restrict__ stats) {
   constexpr int NC = 1 << LC;
-  constexpr int NT = kDeepThreads, NWV = NT / 64;
+  constexpr int NWV = NT / 64;
   extern __shared__ __align__(16) double sm[];
   __shared__ Epoch E;
   __shared__ SiCiTab S;

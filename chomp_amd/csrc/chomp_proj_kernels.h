@@ -754,7 +754,7 @@ __global__ __launch_bounds__(64 * kWthetaNW) void k_wtheta(chomp_config cfg, Tab
 // spline piece (never narrower: a piece then meets at most two of them), each with its own
 // origin, and the prefix sums restart at every segment.  Recombination shifts a segment's
 // moments by |delta| <= two piece widths.  Segment membership is integer arithmetic on the node
-// index (wth_seg_of / wth_seg_start), so that both kernels agree on it exactly.
+// index (wth_seg_of / WthSeg::start), so that both kernels agree on it exactly.
 // Measured agreement with the node-by-node kernel: tests/test_gpu_projection.py.
 // ---------------------------------------------------------------------------
 constexpr int kWthItems = 8;                 // nodes per thread and tile of k_wtheta_moments
@@ -764,39 +764,87 @@ constexpr int kWthItems = 8;                 // nodes per thread and tile of k_w
 __device__ __forceinline__ int wth_seg_of(long j, int nseg, int lev) {
   return (int)(((2 * j + 1) * nseg) >> lev);
 }
-// ... and the first node of segment m, the same statement solved for j (m = nseg: n).
-__device__ __forceinline__ long wth_seg_start(int m, int nseg, int lev) {
-  const long p = ((long)m << lev) - nseg, q = 2L * nseg;
-  return p <= 0 ? 0 : (p + q - 1) / q;
-}
-__device__ __forceinline__ double wth_origin(int m, int nseg, double a, double b) {
-  return a + (b - a) * ((double)m / (double)nseg);
-}
+// ... and the first node of segment m, the same statement solved for j (m = nseg: n):
+// ceil((m 2^lev - nseg) / (2 nseg)), by a floating-point quotient made exact by three integer
+// corrections (a 64-bit integer division costs a wavefront a few hundred instructions).
+struct WthSeg {
+  int nseg;
+  double inv_q, a, seg_w;
+  __device__ __forceinline__ WthSeg(int nseg_, double a_, double b_)
+      : nseg(nseg_), inv_q(0.5 / (double)nseg_), a(a_), seg_w((b_ - a_) / (double)nseg_) {}
+  __device__ __forceinline__ long start(int m, int lev) const {
+    const long p = ((long)m << lev) - nseg, q = 2L * nseg;
+    if (p <= 0) return 0;
+    long c = (long)((double)p * inv_q) - 1;                // <= floor(p / q), short by 2 at most
+    c += (c * q < p) ? 1 : 0;
+    c += (c * q < p) ? 1 : 0;
+    c += (c * q < p) ? 1 : 0;
+    return c;
+  }
+  __device__ __forceinline__ double origin(int m) const { return a + seg_w * (double)m; }
+};
 
-// grid (nseg, LT), block 256: inclusive prefix sums of g_j u_j^q, q = 0..3, u_j = x_j - O_m,
-// over the nodes of segment m of level blockIdx.y + 1, into mom[4 idx + q] (idx: the node's
-// index in the level-major table).  Tiles of 256 * kWthItems nodes with a running carry.
+// grid (nseg, LT, kWthParts), block 256: inclusive prefix sums of g_j u_j^q, q = 0..3, u_j = x_j
+// - O_m, over the nodes of segment m of level blockIdx.y + 1, into mom[4 idx + q] (idx: the
+// node's index in the level-major table).  A long segment (deep levels) is cut into up to
+// kWthParts parts, one block each: a part first sums the moments of the parts before it (a plain
+// strided reduction of nodes already in L2) for its carry, then scans its own tiles of
+// 256 * kWthItems nodes.  No block waits for another.
+constexpr int kWthParts = 8;
 __global__ __launch_bounds__(256) void k_wtheta_moments(const double* __restrict__ nodes, int LT,
                                                         int nseg, double a, double b,
                                                         double* __restrict__ mom) {
   __shared__ double wtot[2][4][4];
+  __shared__ double ctot[4][4];
   const int m = blockIdx.x, lev = blockIdx.y + 1, t = threadIdx.x, lane = t & 63, w = t >> 6;
   const long n = 1L << (lev - 1);
-  const long j0 = wth_seg_start(m, nseg, lev), j1 = wth_seg_start(m + 1, nseg, lev);
-  if (j0 >= j1) return;                                     // (block-uniform)
+  const WthSeg G(nseg, a, b);
+  const long j0 = G.start(m, lev), j1 = G.start(m + 1, lev);
+  constexpr long kTile = 256L * kWthItems;
+  const long len = j1 - j0;
+  long parts = (len + kTile - 1) / kTile;
+  parts = parts > kWthParts ? kWthParts : parts;
+  if ((long)blockIdx.z >= parts) return;                    // (block-uniform; also len == 0)
+  const long plen = (len + parts - 1) / parts;
+  const long p0 = j0 + plen * blockIdx.z;
+  const long p1 = p0 + plen < j1 ? p0 + plen : j1;
   const double h = (b - a) / (double)n, lox = a + 0.5 * h;
-  const double O = wth_origin(m, nseg, a, b);
+  const double O = G.origin(m);
   const long base = 1 + n;                                  // level-major index of j = 0
   double carry[4] = {0.0, 0.0, 0.0, 0.0};
+  if (p0 > j0) {                                            // (block-uniform)
+    double r[4] = {0.0, 0.0, 0.0, 0.0};
+    for (long jj = j0 + t; jj < p0; jj += 256 * 8) {       // (eight loads in flight)
+      double g[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const long j = jj + 256L * i;
+        g[i] = j < p0 ? nodes[base + j] : 0.0;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const double u = (lox + h * (double)(jj + 256L * i)) - O;
+        r[0] += g[i]; r[1] += g[i] * u; r[2] += g[i] * (u * u); r[3] += g[i] * (u * u * u);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double x = wave_sum(r[q]);
+      if (lane == 0) ctot[w][q] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) carry[q] = (ctot[0][q] + ctot[1][q]) + (ctot[2][q] + ctot[3][q]);
+  }
   int buf = 0;
-  for (long tile = j0; tile < j1; tile += 256L * kWthItems, buf ^= 1) {
+  for (long tile = p0; tile < p1; tile += kTile, buf ^= 1) {
     const long c0 = tile + (long)t * kWthItems;
     double v[kWthItems][4];
     double s[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int i = 0; i < kWthItems; ++i) {
       const long j = c0 + i;
-      if (j < j1) {
+      if (j < p1) {
         const double g = nodes[base + j], u = (lox + h * (double)j) - O;
         s[0] += g; s[1] += g * u; s[2] += g * (u * u); s[3] += g * (u * u * u);
       }
@@ -835,7 +883,7 @@ __global__ __launch_bounds__(256) void k_wtheta_moments(const double* __restrict
 #pragma unroll
     for (int i = 0; i < kWthItems; ++i) {
       const long j = c0 + i;
-      if (j < j1) {
+      if (j < p1) {
         double2* o = reinterpret_cast<double2*>(mom + 4 * (base + j));
         o[0] = make_double2(pre[0] + v[i][0], pre[1] + v[i][1]);
         o[1] = make_double2(pre[2] + v[i][2], pre[3] + v[i][3]);
@@ -848,8 +896,8 @@ __global__ __launch_bounds__(256) void k_wtheta_moments(const double* __restrict
 
 // Moments of the whole of segment m (0 for an empty one).
 __device__ __forceinline__ void wth_seg_total(const double* __restrict__ mom, long base, int m,
-                                              int nseg, int lev, double (&T)[4]) {
-  const long g0 = wth_seg_start(m, nseg, lev), g1 = wth_seg_start(m + 1, nseg, lev);
+                                              const WthSeg& G, int lev, double (&T)[4]) {
+  const long g0 = G.start(m, lev), g1 = G.start(m + 1, lev);
   if (g1 > g0) {
     const double2* p = reinterpret_cast<const double2*>(mom + 4 * (base + g1 - 1));
     const double2 x = p[0], y = p[1];
@@ -896,12 +944,13 @@ __global__ __launch_bounds__(256) void k_wtheta_fast(chomp_config cfg, ProjLayou
   RombergRows2 R;
   R.start(b - a, cfg.global_precision, cfg.corr_precision,
           0.5 * (nodes[0] * K(a + s) + nodes[1] * K(b + s)), 0.0, true, false);
+  const WthSeg G(nseg, a, b);
   for (int g = 0; 4 * g < LT && !R.all_done(); ++g) {
     const int lv = 4 * g + 1 + wave;
     double contrib = 0.0;
     if (lv <= LT) {                                      // (wave-uniform)
       const long n = 1L << (lv - 1);
-      const double h = (b - a) / (double)n, lox = a + 0.5 * h, inv_h = 1.0 / h;
+      const double h = (b - a) / (double)n, lox = a + 0.5 * h, inv_h = (double)n / (b - a);
       const long base = 1 + n;
       // B: the first node of this lane's region (piece i, or beyond the range for lane NP)
       long B = 0;
@@ -912,14 +961,26 @@ __global__ __launch_bounds__(256) void k_wtheta_fast(chomp_config cfg, ProjLayou
         const double q = floor((hi - s - lox) * inv_h) + 1.0;
         B = q <= 0.0 ? 0 : (q >= (double)n ? n : (long)q);
       }
-      int mB = 0;
-      double P[4] = {0.0, 0.0, 0.0, 0.0};
-      if (lane <= NP && B >= 1) {
-        mB = wth_seg_of(B - 1, nseg, lv);
-        const double2* p = reinterpret_cast<const double2*>(mom + 4 * (base + B - 1));
-        const double2 x = p[0], y = p[1];
-        P[0] = x.x; P[1] = x.y; P[2] = y.x; P[3] = y.y;
+      // prefix moments just below B, and the total of that segment (both loads issued before
+      // anything waits for them; for B = 0 a valid address whose value is not used)
+      const bool has = lane <= NP && B >= 1;
+      const int mB = has ? wth_seg_of(B - 1, nseg, lv) : 0;
+      const long end = has ? G.start(mB + 1, lv) : 1;    // (>= B: the segment holds node B - 1)
+      const double2* pP = reinterpret_cast<const double2*>(mom + 4 * (base + (has ? B - 1 : 0)));
+      const double2* pT = reinterpret_cast<const double2*>(mom + 4 * (base + end - 1));
+      const double2 P01 = pP[0], P23 = pP[1], T01 = pT[0], T23 = pT[1];
+      const long B0 = __shfl((long long)B, 0, 64);
+      const int m0 = __shfl(mB, 0, 64);
+      double below = 0.0;                                // plain sum of g over the segments < m0
+      if (B0 >= 1) {
+        for (int m = lane; m < m0; m += 64) {
+          double T[4];
+          wth_seg_total(mom, base, m, G, lv, T);
+          below += T[0];
+        }
       }
+      const double P[4] = {has ? P01.x : 0.0, has ? P01.y : 0.0, has ? P23.x : 0.0,
+                           has ? P23.y : 0.0};
       // the next knot's
       const long Bn = __shfl_down((long long)B, 1, 64);
       const int mn = __shfl_down(mB, 1, 64);
@@ -929,34 +990,24 @@ __global__ __launch_bounds__(256) void k_wtheta_fast(chomp_config cfg, ProjLayou
       if (lane < NP && Bn > B) {
         if (mn == mB && B >= 1) {
           const double D[4] = {Pn[0] - P[0], Pn[1] - P[1], Pn[2] - P[2], Pn[3] - P[3]};
-          contrib = wth_combine(D, wth_origin(mB, nseg, a, b) + s - X, c0, c1, c2, c3);
+          contrib = wth_combine(D, G.origin(mB) + s - X, c0, c1, c2, c3);
         } else {
           // the rest of segment mB, whole segments between, the head of segment mn
-          double T[4];
           if (B >= 1) {
-            wth_seg_total(mom, base, mB, nseg, lv, T);
-            const double D[4] = {T[0] - P[0], T[1] - P[1], T[2] - P[2], T[3] - P[3]};
-            contrib = wth_combine(D, wth_origin(mB, nseg, a, b) + s - X, c0, c1, c2, c3);
+            const double D[4] = {T01.x - P[0], T01.y - P[1], T23.x - P[2], T23.y - P[3]};
+            contrib = wth_combine(D, G.origin(mB) + s - X, c0, c1, c2, c3);
           }
           for (int m = B >= 1 ? mB + 1 : 0; m < mn; ++m) {
-            wth_seg_total(mom, base, m, nseg, lv, T);
-            contrib += wth_combine(T, wth_origin(m, nseg, a, b) + s - X, c0, c1, c2, c3);
+            double T[4];
+            wth_seg_total(mom, base, m, G, lv, T);
+            contrib += wth_combine(T, G.origin(m) + s - X, c0, c1, c2, c3);
           }
-          contrib += wth_combine(Pn, wth_origin(mn, nseg, a, b) + s - X, c0, c1, c2, c3);
+          contrib += wth_combine(Pn, G.origin(mn) + s - X, c0, c1, c2, c3);
         }
       }
       // nodes below the kernel's range: K(lo) times the plain sum of g over [0, B_0)
-      const long B0 = __shfl((long long)B, 0, 64);
-      if (B0 >= 1) {
-        const int m0 = __shfl(mB, 0, 64);
-        double below = lane == 0 ? P[0] : 0.0;
-        for (int m = lane; m < m0; m += 64) {
-          double T[4];
-          wth_seg_total(mom, base, m, nseg, lv, T);
-          below += T[0];
-        }
-        contrib += k_lo * below;
-      }
+      if (lane == 0) below += P[0];
+      contrib += k_lo * below;
     }
     const double S = wave_sum(contrib);
     if (lane == 0) level_sum[g & 1][wave] = S;

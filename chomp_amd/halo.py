@@ -83,14 +83,35 @@ class Halo(object):
         # set_cosmology from self.halo_dict as well; set_halo changes neither.
         return self._profile_dict
 
-    def _sync(self, need_tables):
-        """Bring the device tables named by the CHOMP_T_* mask up to date."""
+    _status_pending = False
+    _status_word = 0
+
+    def _resolve_status(self, stacklevel=4):
+        """The status word of the last halo set-up -- posted to pinned host memory right behind
+        the set-up's kernels (chomp_status_post) -- turned into warnings the first time it is
+        looked at: what scipy's AccuracyWarning (divmax exceeded) told the reference's user, plus
+        the saturated mass-limit search (include/chomp_mi355x.h, chomp_get_status).  Waits for
+        that copy, not for work enqueued after it."""
+        if self._status_pending and self._ctx is not None:
+            self._status_pending = False
+            self._status_word = int(
+                self._ctx.warn_status(0, 1, stacklevel=stacklevel, posted=True)[0])
+        return self._status_word
+
+    status = property(lambda self: self._resolve_status())
+
+    def _sync(self, need_tables, defer_status=False):
+        """Bring the device tables named by the CHOMP_T_* mask up to date.  defer_status: leave
+        the status word on the device (no synchronisation here); it is read by whoever next
+        looks at .status, brings a result to the host, or rebuilds the tables."""
         if self._ctx is None:
             self._ctx = cosmology._context()
         ctx = self._ctx
         bao = bool(getattr(self.cosmo, "_with_bao", False))
         esig = (tuple(sorted(self.cosmo.cosmo_dict.items())), self.cosmo._redshift, bao)
         if esig != self._epoch_sig:
+            self._resolve_status(stacklevel=6)     # (the set-up below clears the device's words)
+            self._before_epochs_set()
             ctx.epochs_set(self.cosmo.cosmo_dict, [self.cosmo._redshift], bao)
             self._epoch_sig = esig
             self._mass_sig = None
@@ -106,16 +127,21 @@ class Halo(object):
             if (need_tables & bit) and not getattr(self, flag):
                 build |= bit
         if build or not self._nbar_valid:
+            self._resolve_status(stacklevel=6)     # (the next set-up clears the device's words)
             ctx.halo_setup(self._profile(), self.local_hod,
                            build | (_lib.T_EXCLUSION if self._exclusion else 0))
             for flag, bit in _FLAG_BITS:
                 if build & bit:
                     setattr(self, flag, True)
             self._nbar_valid = True
-            # what scipy's AccuracyWarning (divmax exceeded) told the reference's user, plus
-            # the saturated mass-limit search (include/chomp_mi355x.h, chomp_get_status)
-            self.status = int(ctx.warn_status(0, 1, stacklevel=5)[0])
+            ctx.status_post()
+            self._status_pending = True
+        if not defer_status:
+            self._resolve_status(stacklevel=5)
         return ctx
+
+    def _before_epochs_set(self):
+        pass
 
     def _after_epochs_set(self):
         pass
@@ -376,23 +402,35 @@ class HaloFit(Halo):
         self._omega_l = self.cosmo.omega_l()
         self._w = self.cosmo.w(self._redshift)
 
+    def _hf_values(self):
+        """The HaloFit coefficient block of the device epoch, read back (a synchronisation) the
+        first time anything on the host asks for it."""
+        if not self._initialized_sigma_spline:
+            self._ensure_halofit()
+        if self._hf_coef is None:
+            self._hf_coef = self._ctx.halofit_get(0)
+        return self._hf_coef
+
+    def _before_epochs_set(self):
+        # the block about to be overwritten is the one _after_epochs_set re-installs
+        if self._initialized_sigma_spline and self._hf_coef is None and self._ctx is not None:
+            self._hf_coef = self._ctx.halofit_get(0)
+
     def _after_epochs_set(self):
         # the device epoch was rebuilt: re-install the (possibly stale, as in the
         # reference) HaloFit coefficient block
         if self._initialized_sigma_spline and self._hf_coef is not None:
             self._ctx.halofit_put(self._hf_coef, 0)
 
-    def _ensure_halofit(self):
-        ctx = self._sync(0)
+    def _ensure_halofit(self, defer_status=False):
+        ctx = self._sync(0, defer_status=defer_status)
         if not self._initialized_sigma_spline:
             ctx.halofit_setup(0, 0, float(self._f_1), float(self._f_2),
                               float(self._f_3), float(self._omega_l), float(self._w))
-            self._hf_coef = ctx.halofit_get(0)
+            self._hf_coef = None
             self._initialized_sigma_spline = True
-            (self._k_s, self._n_eff, self._C, self._a_n, self._b_n, self._c_n,
-             self._gamma_n, self._alpha_n, self._beta_n, self._mu_n,
-             self._nu_n) = [float(v) for v in self._hf_coef[3:14]]
         return ctx
+
 
     def power_mm(self, k):
         self._ensure_halofit()
@@ -405,3 +443,11 @@ class HaloFit(Halo):
     def power_gg(self, k):
         self._ensure_halofit()
         return self._power(_lib.P_GG | _lib.P_HALOFIT, _lib.FAM_GG, k)
+
+
+# k_s, n_eff, C and the Takahashi et al. coefficients (halo.py:1289-1330) as the reference's
+# attribute names
+for _i, _name in enumerate(("_k_s", "_n_eff", "_C", "_a_n", "_b_n", "_c_n", "_gamma_n",
+                            "_alpha_n", "_beta_n", "_mu_n", "_nu_n")):
+    setattr(HaloFit, _name, property(lambda self, _i=_i: float(self._hf_values()[3 + _i])))
+del _i, _name

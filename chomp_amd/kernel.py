@@ -319,6 +319,8 @@ class Kernel(object):
         self._force_quad = force_quad
         self._own = None
         self._done = {}
+        self._info = None
+        self._info_ctx = None
         self._z_bar_override = None
 
     # -- device state: the tables can live in several contexts (the kernel's own,
@@ -330,13 +332,16 @@ class Kernel(object):
 
     def _setup_on(self, ctx):
         sig = self._signature()
-        if self._done.get(id(ctx)) != sig:
+        mine = (id(self), sig)           # (another Kernel may have used this context since)
+        if self._done.get(id(ctx)) != sig or getattr(ctx, "_proj_owner", None) != mine:
             ctx.kernel_setup(self.cosmo.cosmo_dict, self.cosmo.z_min, self.cosmo.z_max,
                              self._ktheta[0], self._ktheta[1],
                              self.window_function_a._struct(),
                              self.window_function_b._struct(), self._order)
             self._done[id(ctx)] = sig
-            self._info = ctx.kernel_info()
+            ctx._proj_owner = mine
+            self._info = None            # (read back -- a synchronisation -- when first asked for)
+            self._info_ctx = ctx
         return ctx
 
     def _dev(self):
@@ -345,7 +350,10 @@ class Kernel(object):
         return self._setup_on(self._own)
 
     def _get(self, name):
-        self._dev()
+        if self._info is None and self._info_ctx is None:
+            self._dev()
+        if self._info is None:
+            self._info = self._setup_on(self._info_ctx).kernel_info()
         return float(self._info[name])
 
     chi_min = property(lambda self: self._get("chi_min"))

@@ -283,6 +283,15 @@ int chomp_get_scalars(chomp_ctx* ctx, size_t epoch, double* out);
 #define CHOMP_ST_HALO_DIVMAX_PP_GG 0x1000u
 #define CHOMP_ST_NONFINITE 0x10000u
 int chomp_get_status(chomp_ctx* ctx, size_t epoch0, size_t n, unsigned* out);
+/* The same words without draining the stream.  chomp_status_post enqueues a copy of every epoch's
+ * word to pinned host memory, ordered after the work enqueued so far (call it right after a
+ * set-up); chomp_status_wait blocks until THAT copy has landed -- not until the stream is idle --
+ * and returns the words as they were then.  A caller that keeps its samples on the device posts
+ * after each set-up and waits whenever it next has a reason to look (the reference printed its
+ * AccuracyWarning at the time of the integral; here the time of looking is the caller's choice).
+ * ERR_STATE: wait before any post; post while the stream is being captured. */
+int chomp_status_post(chomp_ctx* ctx);
+int chomp_status_wait(chomp_ctx* ctx, size_t epoch0, size_t n, unsigned* out);
 
 /* Test / tuning hooks (no counterpart in the reference; not needed by a caller): override a
  * launch-shape decision of this context.  value < 0 restores the default.

@@ -208,6 +208,61 @@ def test_status_word_reports_what_scipy_warned_about():
         hs.status(warn=True)
 
 
+def test_posted_status_is_the_status_and_warns_when_looked_at():
+    """chomp_status_post / chomp_status_wait: the words copied behind a set-up equal a
+    synchronous chomp_get_status, later work does not change them, and the drop-in classes'
+    device-resident path (Correlation with torch inputs: no synchronisation anywhere) still
+    delivers the divmax warning -- when the status is looked at."""
+    import torch
+    import warnings
+    from chomp_amd import correlation, cosmology, grid, halo, kernel, _lib
+    hg = grid.HaloGrid(numpy.array([0.0, 1.0]))
+    with pytest.raises(_lib.ChompError, match='status_post'):
+        hg.ctx.status_wait(0, 1)
+    hg.setup("power_gm")
+    hg.ctx.status_post()
+    now = hg.status()
+    assert now.any()
+    hg.setup("power_mm")                     # clears the device's words ...
+    assert list(hg.status()) == [0, 0]
+    assert list(hg.ctx.status_wait(0, 2)) == list(now)     # ... not the posted copy
+    d2r = numpy.pi / 180.0
+    cm = cosmology.MultiEpoch(0.0, 5.0)
+    wa = kernel.WindowFunctionGalaxy(kernel.dNdzMagLim(0.0, 2.0, 2.0, 0.3, 2.0), cm)
+    wb = kernel.WindowFunctionGalaxy(kernel.dNdzMagLim(0.0, 2.0, 2.0, 0.3, 2.0), cm)
+    kern = kernel.Kernel(1e-6 * d2r, 100.0 * d2r, wa, wb, cm)
+    h = halo.Halo(0.0)
+    corr = correlation.Correlation(0.001, 1.0, kern, input_halo=h, power_spec="power_gg")
+    theta = torch.logspace(-3, 0, 16, dtype=torch.float64, device="cuda") * d2r
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")       # nothing may warn (or synchronise) here
+        ctx, code = corr._prepare(defer_status=True)
+        w = ctx.wtheta(code, 0, corr._k_lim[0], corr._k_lim[1], corr.D_z, theta)
+    assert h._status_pending
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        word = h.status                      # (whether pp_gg at z_bar exhausts divmax is not the point)
+    assert not h._status_pending and word == int(ctx.status(0, 1)[0])
+    assert bool(torch.isfinite(w).all())
+    # P_gm at z = 0 does exhaust divmax (test_status_word_...): built without a word to the
+    # caller, reported when looked at
+    h2 = halo.Halo(0.0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        h2._sync(_lib.FAM_GM, defer_status=True)
+    assert h2._status_pending
+    with pytest.warns(_lib.ChompAccuracyWarning, match="divmax"):
+        word = h2.status
+    assert word & _lib.ST_HALO_DIVMAX["pp_gm"] and not h2._status_pending
+    # ... and a rebuild does not lose an unread word: it is delivered first
+    h2._reset_flags(all_tables=True)
+    h2._sync(_lib.FAM_GM, defer_status=True)
+    assert h2._status_pending
+    h2._reset_flags(all_tables=True)
+    with pytest.warns(_lib.ChompAccuracyWarning, match="divmax"):
+        h2._sync(_lib.FAM_GM, defer_status=True)
+
+
 def test_abi_error_codes_and_call_order():
     """The C ABI reports misuse instead of computing garbage: stages called before their
     prerequisites (CHOMP_ERR_STATE), bad arguments (CHOMP_ERR_ARG -> ValueError), features
