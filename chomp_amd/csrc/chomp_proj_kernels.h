@@ -1304,7 +1304,8 @@ struct CellIntegrand {
 // the level-LT grid (level-major, as w(theta)'s k-only factor): F_j, ln chi_j and chi_j.  A
 // multipole then only evaluates P(l / chi_j) per node, with ln k = ln l - ln chi_j for free.
 // grid ceil((2^LT + 1) / 256), block 256; dynamic LDS ProjLds::doubles(L).
-constexpr int kCellTabLevel = 14;       // 3 x (2^14 + 1) doubles = 384 KiB
+constexpr int kCellTabLevel = 16;       // 3 x (2^16 + 1) doubles = 1.5 MiB (the C_l integrals of
+                                        // configs[3] / [4] stop at levels 7..15, a few at 14, 15)
 __global__ __launch_bounds__(256) void k_cell_nodes(ProjLayout L, const ProjDev* __restrict__ pdg,
                                                     const double* __restrict__ ptab, double D_z,
                                                     int LT, double* __restrict__ nodes) {
@@ -1405,6 +1406,26 @@ struct CellTabIntegrand {
       out[0] = direct(chi);
     }
   }
+  // The same value for a node of the table whose l / chi has the full stencil inside the
+  // spectrum table, as straight-line code (detail::fast_f); false otherwise.
+  __device__ __forceinline__ bool fast(double, double (&out)[1], int lev, long j) const {
+    if (ptab == nullptr || lev > LT || lev == 0) return false;     // (uniform over the batch)
+    const long idx = 1 + (1L << (lev - 1)) + j;
+    const double g = nodes[idx], lk = ln_ell - nodes[N + idx];
+    const double u = (lk - px0) * pinv_dx;
+    const int i = (int)u;
+    const bool ok = u >= 2.0 && i <= kPTabN - 4;
+    const int ic = ok ? i : 2;
+    const double t = u - (double)ic;
+    const double* q = ptab + ic - 2;
+    const double q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5];
+    const double a = t + 2.0, b = t + 1.0, d = t - 1.0, e = t - 2.0, f = t - 3.0;
+    const double ab = a * b, ef = e * f, cd = t * d;
+    out[0] = (q0 * (b * cd * ef) * (-1.0 / 120.0) + q1 * (a * cd * ef) * (1.0 / 24.0) +
+              q2 * (ab * d * ef) * (-1.0 / 12.0) + q3 * (ab * t * ef) * (1.0 / 12.0) +
+              q4 * (ab * cd * f) * (-1.0 / 24.0) + q5 * (ab * cd * e) * (1.0 / 120.0)) * g;
+    return ok;
+  }
 };
 
 // grid n_ell, block 256: one multipole per workgroup.
@@ -1437,8 +1458,11 @@ __global__ __launch_bounds__(256) void k_cell(chomp_config cfg, TabLayout HL, Pr
   const double px0 = log(cfg.k_min), pdx = (log(cfg.k_max) - px0) / (double)kPTabN;
   CellTabIntegrand<HF, BAO> f{&P, nodes, (1L << LT) + 1, LT, l, log(l), pk_tab, px0, pdx, 1.0 / pdx,
                               {&P, &G, l, 1.0 / (D_z * D_z)}};
-  const RombergOut<1> r = romberg_group<4, 1>(f, pd.chi_min, pd.chi_max, cfg.global_precision,
-                                              cfg.corr_precision, cfg.divmax, red);
+  // (four nodes per thread in flight: a node is two dependent table reads -- its chi, then the
+  //  spectrum stencil at l / chi -- and a multipole that runs to level 14 walks 64 of them per
+  //  thread; measured 65 us for such a block before, the launch's duration)
+  const RombergOut<1> r = romberg_group<4, 1, CellTabIntegrand<HF, BAO>, 4>(
+      f, pd.chi_min, pd.chi_max, cfg.global_precision, cfg.corr_precision, cfg.divmax, red);
   if (threadIdx.x == 0) out[blockIdx.x] = r.value[0];
 }
 

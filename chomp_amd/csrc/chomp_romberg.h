@@ -103,6 +103,21 @@ template <class F, int NF>
 __device__ __forceinline__ void call_f(const F& f, double x, double (&o)[NF], int, long, long) {
   f(x, o);
 }
+// An integrand may offer `bool fast(x, out, level, j) const`: the common case as straight-line
+// code (no branch that depends on the node), false when the node needs the general operator().
+// The unrolled level loop then issues UNROLL of them back to back -- their table reads overlap,
+// which a branch per node prevents -- and repairs the rare refusals afterwards.
+template <class F, int NF>
+__device__ __forceinline__ auto fast_f(const F& f, double x, double (&o)[NF], int lev, long j,
+                                       int) -> decltype(f.fast(x, o, lev, j)) {
+  return f.fast(x, o, lev, j);
+}
+template <class F, int NF>
+__device__ __forceinline__ bool fast_f(const F& f, double x, double (&o)[NF], int lev, long j,
+                                       long) {
+  call_f<F, NF>(f, x, o, lev, j, 0);
+  return true;
+}
 }  // namespace detail
 
 // F: void operator()(double x, double (&out)[NF]) const
@@ -298,10 +313,16 @@ __device__ __forceinline__ RombergOut<NF> romberg_group(const F& f, double a, do
     if (UNROLL > 1) {
       for (; j + (UNROLL - 1) * (long)NT < numtosum; j += UNROLL * (long)NT) {
         double v[UNROLL][NF];
+        bool ok = true;
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u)
-          detail::call_f<F, NF>(f, lox + h * (double)(j + u * (long)NT), v[u], i,
-                                j + u * (long)NT, 0);
+          ok = detail::fast_f<F, NF>(f, lox + h * (double)(j + u * (long)NT), v[u], i,
+                                     j + u * (long)NT, 0) && ok;
+        if (!ok) {                                 // (rare: some node of the batch refused)
+          for (int u = 0; u < UNROLL; ++u)
+            detail::call_f<F, NF>(f, lox + h * (double)(j + u * (long)NT), v[u], i,
+                                  j + u * (long)NT, 0);
+        }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
