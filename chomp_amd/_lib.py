@@ -113,6 +113,7 @@ ST_HALO_DIVMAX = {"h_m": 0x100, "pp_mm": 0x200, "h_g": 0x400, "pp_gm": 0x800, "p
 ST_NONFINITE = 0x10000
 ST_SATURATED = ST_MASS_MIN_SATURATED | ST_MASS_MAX_SATURATED
 TUNE_E_STREAM_MIN, TUNE_E_ROWS, TUNE_DEEP_LITERAL, TUNE_ROCTX, TUNE_WTHETA_DIRECT = 0, 1, 2, 3, 4
+TUNE_CELL_ONE_KERNEL = 5
 
 
 class ChompAccuracyWarning(UserWarning):

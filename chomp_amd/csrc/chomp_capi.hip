@@ -102,7 +102,7 @@ struct chomp_ctx {
   unsigned* d_status = nullptr;    // per-epoch status word (chomp_get_status)
   double* d_endp = nullptr;        // integrand pairs of the knots at the upper end point
   int* d_npend = nullptr;          // per epoch: listed knots + 1 token (k_halo_knots_fast)
-  long long tune[CHOMP_TUNE_COUNT] = {-1, -1, -1, -1, -1};   // chomp_set_tuning
+  long long tune[CHOMP_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1};   // chomp_set_tuning
   bool have_epochs = false, have_mass = false, have_halo = false;
   unsigned fam_mask = 0;          // families (F_* bits) with valid splines
   std::vector<char> have_halofit;

@@ -1308,9 +1308,11 @@ constexpr int kCellTabLevel = 16;       // 3 x (2^16 + 1) doubles = 1.5 MiB (the
                                         // configs[3] / [4] stop at levels 7..15, a few at 14, 15)
 __global__ __launch_bounds__(256) void k_cell_nodes(ProjLayout L, const ProjDev* __restrict__ pdg,
                                                     const double* __restrict__ ptab, double D_z,
-                                                    int LT, double* __restrict__ nodes) {
+                                                    int LT, double* __restrict__ nodes,
+                                                    int* __restrict__ deep) {
   extern __shared__ __align__(16) double sm[];
   __shared__ ProjDev pd;
+  if (blockIdx.x == 0 && threadIdx.x < 2) deep[threadIdx.x] = 0;   // k_cell's list: count, head
   copy_doubles(reinterpret_cast<double*>(&pd), reinterpret_cast<const double*>(pdg), kProjDoubles);
   __syncthreads();
   ProjLds G;
@@ -1342,8 +1344,8 @@ __global__ __launch_bounds__(256) void k_cell_nodes(ProjLayout L, const ProjDev*
 // inside that range a multipole's node then reads P(l / chi) off a 6-point Lagrange stencil
 // (~1e-16 relative at this spacing: the spectrum is smooth in ln k) instead of evaluating
 // three knot splines and the linear spectrum -- or the HaloFit formula -- per node.  Outside
-// the range (zero / the rescaled linear spectrum / the extrapolations, halo.py:300-320) and
-// within two points of its ends the node is evaluated directly.  No-wiggle spectra only.
+// the range: zero where the spectrum is identically zero, else evaluated directly (the rescaled
+// linear spectrum / the extrapolations, halo.py:300-320).  No-wiggle spectra only.
 // grid ceil((kPTabN + 1) / 256), block 256; dynamic LDS 12 (NK - 1) doubles.
 constexpr int kPTabN = 8192;
 template <bool HF, bool BAO>
@@ -1381,54 +1383,63 @@ struct CellTabIntegrand {
   const double* ptab;      // k_cell_ptab (nullptr: evaluate the spectrum at every node)
   double px0, pdx, pinv_dx;
   CellIntegrand<BAO> direct;
-  __device__ __forceinline__ double spectrum(double lk, double kv) const {
-    if (ptab != nullptr) {
-      const double u = (lk - px0) * pinv_dx;
-      const int i = (int)u;
-      if (u >= 2.0 && i <= kPTabN - 4) {                       // full stencil inside the range
-        const double t = u - (double)i;
-        const double* q = ptab + i - 2;
-        const double a = t + 2.0, b = t + 1.0, d = t - 1.0, e = t - 2.0, f = t - 3.0;
-        const double ab = a * b, ef = e * f, cd = t * d;
-        return q[0] * (b * cd * ef) * (-1.0 / 120.0) + q[1] * (a * cd * ef) * (1.0 / 24.0) +
-               q[2] * (ab * d * ef) * (-1.0 / 12.0) + q[3] * (ab * t * ef) * (1.0 / 12.0) +
-               q[4] * (ab * cd * f) * (-1.0 / 24.0) + q[5] * (ab * cd * e) * (1.0 / 120.0);
-      }
-    }
-    return P->template at_ln<HF, BAO>(lk, kv);
+  // The spectrum at ln k = lk from the table, as straight-line code: inside [ln k_min, ln k_max]
+  // the 6-point stencil, shifted at the two ends so that it never leaves the table (P drops to
+  // zero beyond k_max: a stencil must not straddle that); outside the range the value where it
+  // is identically zero (halo.py:300-320 without extrapolation above k_max; :649-672 for the
+  // HaloFit cross spectra on both sides).  *ok = false: neither -- the caller evaluates
+  // PowerEval::at_ln.  ptab must not be null.
+  __device__ __forceinline__ double from_table(double lk, bool* ok) const {
+    const double u = (lk - px0) * pinv_dx;
+    const bool in = u >= 0.0 && u <= (double)kPTabN;
+    const bool zero_out = HF ? P->w != CHOMP_P_MM
+                             : (u > 0.0 && !P->extrap && P->w != CHOMP_P_LIN);
+    int i = (int)u;
+    i = (in && i > 2) ? (i < kPTabN - 3 ? i : kPTabN - 3) : 2;
+    const double t = u - (double)i;
+    const double* q = ptab + i - 2;
+    const double q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5];
+    const double a = t + 2.0, b = t + 1.0, d = t - 1.0, e = t - 2.0, f = t - 3.0;
+    const double ab = a * b, ef = e * f, cd = t * d;
+    const double v = q0 * (b * cd * ef) * (-1.0 / 120.0) + q1 * (a * cd * ef) * (1.0 / 24.0) +
+                     q2 * (ab * d * ef) * (-1.0 / 12.0) + q3 * (ab * t * ef) * (1.0 / 12.0) +
+                     q4 * (ab * cd * f) * (-1.0 / 24.0) + q5 * (ab * cd * e) * (1.0 / 120.0);
+    *ok = in || zero_out;
+    return in ? v : 0.0;
   }
   __device__ __forceinline__ void operator()(double chi, double (&out)[1], int lev, long j) const {
     if (lev <= LT) {
       const long idx = lev == 0 ? j : 1 + (1L << (lev - 1)) + j;
-      const double kv = ell / nodes[2 * N + idx];
-      out[0] = spectrum(ln_ell - nodes[N + idx], kv) * nodes[idx];
+      const double lk = ln_ell - nodes[N + idx];
+      bool ok = false;
+      double p = 0.0;
+      if (ptab != nullptr) p = from_table(lk, &ok);
+      if (!ok) p = P->template at_ln<HF, BAO>(lk, ell / nodes[2 * N + idx]);
+      out[0] = p * nodes[idx];
     } else {
       out[0] = direct(chi);
     }
   }
-  // The same value for a node of the table whose l / chi has the full stencil inside the
-  // spectrum table, as straight-line code (detail::fast_f); false otherwise.
+  // The same value for a node of the table that from_table answers, as straight-line code
+  // (detail::fast_f); false otherwise.
   __device__ __forceinline__ bool fast(double, double (&out)[1], int lev, long j) const {
     if (ptab == nullptr || lev > LT || lev == 0) return false;     // (uniform over the batch)
     const long idx = 1 + (1L << (lev - 1)) + j;
     const double g = nodes[idx], lk = ln_ell - nodes[N + idx];
-    const double u = (lk - px0) * pinv_dx;
-    const int i = (int)u;
-    const bool ok = u >= 2.0 && i <= kPTabN - 4;
-    const int ic = ok ? i : 2;
-    const double t = u - (double)ic;
-    const double* q = ptab + ic - 2;
-    const double q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5];
-    const double a = t + 2.0, b = t + 1.0, d = t - 1.0, e = t - 2.0, f = t - 3.0;
-    const double ab = a * b, ef = e * f, cd = t * d;
-    out[0] = (q0 * (b * cd * ef) * (-1.0 / 120.0) + q1 * (a * cd * ef) * (1.0 / 24.0) +
-              q2 * (ab * d * ef) * (-1.0 / 12.0) + q3 * (ab * t * ef) * (1.0 / 12.0) +
-              q4 * (ab * cd * f) * (-1.0 / 24.0) + q5 * (ab * cd * e) * (1.0 / 120.0)) * g;
+    bool ok;
+    out[0] = from_table(lk, &ok) * g;
     return ok;
   }
 };
 
-// grid n_ell, block 256: one multipole per workgroup.
+// grid n_ell, block 256: one multipole per workgroup, up to Romberg level `split` (= divmax: the
+// whole integral).  A multipole not converged there is listed for k_cell_deep with its Romberg
+// state: deep[0] counts them, deep[2 + i] names them, state[kRombergDump * multipole].
+// (Most multipoles of configs[3] / [4] stop at levels 7..9, a few dozen of the highest run to
+//  14, 15: in one 256-thread block those walk 64..128 nodes per thread, each two dependent
+//  reads of tables another kernel wrote -- a microsecond a piece on a CU whose L2 has not seen
+//  them -- and set the launch's duration: 65 us measured against 9 us for a level-8 block.)
+constexpr int kCellSplitLevel = 11;
 template <bool HF, bool BAO>
 __global__ __launch_bounds__(256) void k_cell(chomp_config cfg, TabLayout HL, ProjLayout L,
                                               const Epoch* __restrict__ epochs, int e,
@@ -1438,7 +1449,8 @@ __global__ __launch_bounds__(256) void k_cell(chomp_config cfg, TabLayout HL, Pr
                                               const double* __restrict__ ell,
                                               double* __restrict__ out,
                                               const double* __restrict__ nodes, int LT,
-                                              const double* __restrict__ pk_tab) {
+                                              const double* __restrict__ pk_tab, int split,
+                                              int* __restrict__ deep, double* __restrict__ state) {
   extern __shared__ __align__(16) double sm[];
   __shared__ Epoch E;
   __shared__ ProjDev pd;
@@ -1458,12 +1470,105 @@ __global__ __launch_bounds__(256) void k_cell(chomp_config cfg, TabLayout HL, Pr
   const double px0 = log(cfg.k_min), pdx = (log(cfg.k_max) - px0) / (double)kPTabN;
   CellTabIntegrand<HF, BAO> f{&P, nodes, (1L << LT) + 1, LT, l, log(l), pk_tab, px0, pdx, 1.0 / pdx,
                               {&P, &G, l, 1.0 / (D_z * D_z)}};
-  // (four nodes per thread in flight: a node is two dependent table reads -- its chi, then the
-  //  spectrum stencil at l / chi -- and a multipole that runs to level 14 walks 64 of them per
-  //  thread; measured 65 us for such a block before, the launch's duration)
+  const bool hand_over = split < cfg.divmax;
   const RombergOut<1> r = romberg_group<4, 1, CellTabIntegrand<HF, BAO>, 4>(
-      f, pd.chi_min, pd.chi_max, cfg.global_precision, cfg.corr_precision, cfg.divmax, red);
-  if (threadIdx.x == 0) out[blockIdx.x] = r.value[0];
+      f, pd.chi_min, pd.chi_max, cfg.global_precision, cfg.corr_precision, split, red,
+      hand_over ? state + (size_t)blockIdx.x * kRombergDump : nullptr);
+  if (threadIdx.x == 0) {
+    out[blockIdx.x] = r.value[0];
+    if (hand_over && !r.converged[0]) deep[2 + atomicAdd(&deep[0], 1)] = (int)blockIdx.x;
+  }
+}
+
+// One node by the general route (inlined: a call would put a stack -- scratch memory -- behind
+// every launch of the kernel, used or not).
+template <bool HF, bool BAO>
+__device__ __forceinline__ double cell_node_general(const CellTabIntegrand<HF, BAO>& f, double chi,
+                                                    int lev, long j) {
+  double v[1];
+  f(chi, v, lev, j);
+  return v[0];
+}
+
+// grid <= n_ell (blocks draw multipoles from the list until it is empty), block 512: the
+// levels beyond `split` of the multipoles k_cell listed.  The spectrum table (64 KiB) is staged
+// in LDS -- the second of a node's two dependent reads then costs an LDS access -- and a level's
+// nodes are spread over eight wavefronts, four to a thread in flight.
+// dynamic LDS: 12 (NK - 1) + ProjLds::doubles(L) + kPTabN + 1 doubles.
+constexpr int kCellDeepThreads = 512;
+template <bool HF, bool BAO>
+__global__ __launch_bounds__(kCellDeepThreads) void k_cell_deep(
+    chomp_config cfg, TabLayout HL, ProjLayout L, const Epoch* __restrict__ epochs, int e,
+    const double* __restrict__ htab, int which, const ProjDev* __restrict__ pdg,
+    const double* __restrict__ ptab, double D_z, const double* __restrict__ ell,
+    double* __restrict__ out, const double* __restrict__ nodes, int LT,
+    const double* __restrict__ pk_tab, int split, int* __restrict__ deep,
+    const double* __restrict__ state) {
+  constexpr int NW = kCellDeepThreads / 64, NT = kCellDeepThreads, U = 4;
+  extern __shared__ __align__(16) double sm[];
+  __shared__ Epoch E;
+  __shared__ ProjDev pd;
+  __shared__ double red[2 * NW];
+  __shared__ int item_sh;
+  const int count = deep[0];
+  if ((int)blockIdx.x >= count) return;                  // (block-uniform)
+  copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
+               kEpochDoubles);
+  copy_doubles(reinterpret_cast<double*>(&pd), reinterpret_cast<const double*>(pdg), kProjDoubles);
+  __syncthreads();
+  PowerEval P;
+  P.stage(cfg, HL, &E, htab + (size_t)e * HL.stride, which, sm);
+  ProjLds G;
+  double* pk_lds = G.stage(L, pd, ptab, sm + 12 * (HL.NK - 1));
+  G.bess = nullptr;
+  if (pk_tab != nullptr) copy_doubles(pk_lds, pk_tab, kPTabN + 1);
+  __syncthreads();
+  P.template finish_t<BAO>();
+  const double px0 = log(cfg.k_min), pdx = (log(cfg.k_max) - px0) / (double)kPTabN;
+  const double a = pd.chi_min, b = pd.chi_max;
+  int flip = 0;
+  for (;;) {
+    __syncthreads();                                     // (the previous item's item_sh is read)
+    if (threadIdx.x == 0) item_sh = atomicAdd(&deep[1], 1);
+    __syncthreads();
+    if (item_sh >= count) return;                        // (block-uniform)
+    const int il = deep[2 + item_sh];
+    const double l = ell[il];
+    const CellTabIntegrand<HF, BAO> f{&P, nodes, (1L << LT) + 1, LT, l, log(l),
+                                      pk_tab != nullptr ? pk_lds : nullptr, px0, pdx, 1.0 / pdx,
+                                      {&P, &G, l, 1.0 / (D_z * D_z)}};
+    RombergResume R;
+    R.load(state + (size_t)il * kRombergDump, split, b - a, cfg.global_precision,
+           cfg.corr_precision);
+    for (int lv = split + 1; lv <= cfg.divmax && !R.done; ++lv) {
+      const long numtosum = 1L << (lv - 1);
+      const double h = (b - a) / (double)numtosum, lox = a + 0.5 * h;
+      double part = 0.0;
+      long j = threadIdx.x;
+      for (; j + (U - 1) * (long)NT < numtosum; j += U * (long)NT) {
+        double v[U][1];
+        bool ok = true;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          ok = f.fast(lox + h * (double)(j + u * (long)NT), v[u], lv, j + u * (long)NT) && ok;
+        if (!ok) {
+          for (int u = 0; u < U; ++u)
+            v[u][0] = cell_node_general<HF, BAO>(f, lox + h * (double)(j + u * (long)NT), lv,
+                                                 j + u * (long)NT);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) part += v[u][0];
+      }
+      for (; j < numtosum; j += NT) {
+        double v[1];
+        if (!f.fast(lox + h * (double)j, v, lv, j))
+          v[0] = cell_node_general<HF, BAO>(f, lox + h * (double)j, lv, j);
+        part += v[0];
+      }
+      R.advance(lv, group_sum<NW>(part, red, flip));
+    }
+    if (threadIdx.x == 0) out[il] = R.value;
+  }
 }
 
 // ---------------------------------------------------------------------------

@@ -146,6 +146,42 @@ struct RombergLoose {
     return err < rtol * fabs(cur) && !(cur > lo1 && cur < hi1) && !(cur > lo2 && cur < hi2);
   }
 };
+// An integral carried on by another kernel from the state romberg_group dumped when it ran out
+// of its divmax at `level` (dump: kRombergDump doubles of one integrand): the same rows and
+// stopping test from the sums of the further levels.  Every lane of every wavefront holds the
+// same state.
+struct RombergResume {
+  double ordsum, Tl, prev, value, range, n, tol, rtol;
+  int level;
+  bool done;
+  __device__ __forceinline__ void load(const double* dump, int level_, double range_, double tol_,
+                                       double rtol_) {
+    const int lane = threadIdx.x & 63;
+    Tl = lane < 32 ? dump[lane] : 0.0;
+    ordsum = dump[32];
+    prev = dump[33];
+    value = prev;
+    range = range_; tol = tol_; rtol = rtol_;
+    level = level_;
+    n = (double)(1L << level_);
+    done = false;
+  }
+  __device__ __forceinline__ void advance(int i, double S) {
+    const int lane = threadIdx.x & 63;
+    const double c_il = CHOMP_ROMBERG_C[i][lane & 31];
+    n *= 2.0;
+    ordsum += S;
+    const double Ti = range * ordsum / n;
+    if (lane == i) Tl = Ti;
+    const double cur = wave_sum(lane < 32 ? c_il * Tl : 0.0);
+    const double err = fabs(cur - prev);
+    prev = cur;
+    value = cur;
+    level = i;
+    if (err < tol || err < rtol * fabs(cur)) done = true;
+  }
+};
+
 template <int NW, int NF, class F, int UNROLL = 1>
 __device__ __forceinline__ RombergOut<NF> romberg_group(const F& f, double a, double b,
                                                         double tol, double rtol,

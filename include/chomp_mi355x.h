@@ -301,6 +301,8 @@ int chomp_status_wait(chomp_ctx* ctx, size_t epoch0, size_t n, unsigned* out);
  *                            Romberg node (the checker of the fast deep-level sums)
  *   CHOMP_TUNE_WTHETA_DIRECT 1: w(theta) by evaluating the kernel spline at every Romberg node
  *                            (the checker of the moment route of chomp_wtheta)
+ *   CHOMP_TUNE_CELL_ONE_KERNEL 1: C_l with every Romberg level in the per-multipole kernel (the
+ *                            checker of the hand-over to k_cell_deep)
  *   CHOMP_TUNE_ROCTX         1: roctx ranges around the stages on the host timeline (one per
  *                            entry point: "chomp:epochs_set", "chomp:stage_k", "chomp:power",
  *                            "chomp:wtheta", ...; rocprofv3 --marker-trace shows them over
@@ -311,7 +313,8 @@ int chomp_status_wait(chomp_ctx* ctx, size_t epoch0, size_t n, unsigned* out);
 #define CHOMP_TUNE_DEEP_LITERAL 2
 #define CHOMP_TUNE_ROCTX 3
 #define CHOMP_TUNE_WTHETA_DIRECT 4
-#define CHOMP_TUNE_COUNT 5
+#define CHOMP_TUNE_CELL_ONE_KERNEL 5
+#define CHOMP_TUNE_COUNT 6
 int chomp_set_tuning(chomp_ctx* ctx, int what, long long value);
 /* Measurement aid: out[6] <- knots beyond the node tables done so far (since the context was
  * created) by [0] the fast deep-level sums, [1] literal evaluation of every node; why literal:

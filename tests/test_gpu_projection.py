@@ -175,3 +175,27 @@ def test_wtheta_moment_route_matches_node_by_node(mods, ggl):
     assert numpy.max(numpy.abs(fast - direct)) < 1e-10 * scale
     ok = numpy.abs(direct) > 1e-6 * scale
     assert numpy.max(numpy.abs(fast[ok] / direct[ok] - 1)) < 1e-8
+
+
+@pytest.mark.parametrize("ggl", [False, True])
+def test_cell_hand_over_matches_one_kernel(mods, ggl):
+    """chomp_cell: multipoles not converged at Romberg level 11 are carried on by k_cell_deep from
+    the dumped rows; CHOMP_TUNE_CELL_ONE_KERNEL keeps every level in the per-multipole kernel.
+    Same nodes, same rows, same stopping rule: equal up to the order of the additions."""
+    from chomp_amd import _lib
+    cosmology, kernel, correlation, halo = mods
+    cm, kern = _projection(mods, ggl)
+    h = halo.HaloFit(0.0) if ggl else halo.Halo(0.0)
+    cf = correlation.CorrelationFourier(10, 1e4, kern, input_halo=h,
+                                        powSpec="power_gm" if ggl else "power_gg")
+    ctx, _ = cf._prepare()
+    ell = numpy.logspace(0.5, 4.5, 301)        # beyond the binned range at both ends
+    try:
+        ctx.set_tuning(_lib.TUNE_CELL_ONE_KERNEL, 1)
+        one = cf.correlation(ell)
+    finally:
+        ctx.set_tuning(_lib.TUNE_CELL_ONE_KERNEL, -1)
+    two = cf.correlation(ell)
+    assert numpy.all(numpy.isfinite(two))
+    assert numpy.max(numpy.abs(two / one - 1)) < 1e-12
+    assert (two != one).sum() < ell.size       # (most multipoles never reach the hand-over)
