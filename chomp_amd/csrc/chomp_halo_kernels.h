@@ -635,6 +635,8 @@ constexpr int kDeepScratch = romberg_scratch<kDeepThreadsFew / 64, 2>();
 constexpr int kDeepStencil = 8;
 constexpr int kDeepOffsets = kDeepStencil - 1;             // interval o..o+1 of the stencil
 constexpr int kDeepWStride = kDeepOffsets * kDeepStencil;  // weights per level
+constexpr int kDeepWLevels = kMaxDivmax - kDeepCoarse;     // levels whose weights a block stages
+constexpr int kDeepRound = 3;                              // deep levels summed per pass
 constexpr int kDeepMaxRough = 8;                           // break-point intervals
 constexpr int kDeepMaxFine = 64;                           // node-by-node intervals
 constexpr int kDeepKinkMargin = 16;                        // extra ones above M_0 (see kernel)
@@ -796,7 +798,8 @@ __device__ __forceinline__ double deep_coarse_x(double a, double b, int q) {
 template <int LC>
 inline size_t deep_fast_lds(int NM) {
   constexpr int NC = 1 << LC;
-  const size_t deep = (size_t)(NM + 8 * (NM - 1) + kDeepScratch + 2 * (NC + 1) + kDeepWStride) *
+  const size_t deep = (size_t)(NM + 8 * (NM - 1) + kDeepScratch + 2 * (NC + 1) +
+                               kDeepWLevels * kDeepWStride) *
                           sizeof(double) + (size_t)((NC + 1 + 15) & ~15);
   return deep;                     // (> finalize_lds_doubles(NK) for any NK <= 512 at LC >= 11)
 }
@@ -875,12 +878,20 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
     const bool pb = (mask & (1u << fb)) && levs[fb * NK + ik] == kPendingLevel;
     if (!pa && !pb) { arrive(e, false); continue; }
     HaloLds H;
+    // (the weights of every deep level, behind the same barrier as the epoch's tables: the
+    //  finalisation of an epoch may have used the space since the previous knot)
+    {
+      double* w_all = sm + L.NM + 8 * (L.NM - 1) + kDeepScratch + 2 * (NC + 1);
+      int nlev = cfg.divmax - LC;
+      nlev = nlev < 0 ? 0 : (nlev > kDeepWLevels ? kDeepWLevels : nlev);
+      copy_doubles(w_all, deepw, nlev * kDeepWStride);
+    }
     H.stage(L, E, S, epochs, e, t, profile, hod, sici_g, sm);
     double* red = H.rest;
     double* F0 = red + kDeepScratch;
     double* F1 = F0 + (NC + 1);
-    double* W = F1 + (NC + 1);
-    unsigned char* code = reinterpret_cast<unsigned char*>(W + kDeepWStride);
+    double* W = F1 + (NC + 1);                             // [divmax - LC][kDeepWStride]
+    unsigned char* code = reinterpret_cast<unsigned char*>(W + kDeepWLevels * kDeepWStride);
     const double a = group_lower(E, group), b = log(E.nu_max);
     HaloCtx c{&E, &S, H.nu_knots, H.lnm_pp, L.NM,
               linspace_at(log(cfg.k_min), log(cfg.k_max), NK, ik), (mask & kMaskExclusion) != 0};
@@ -905,7 +916,7 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
       // ---- levels 0..LC from the samples: wavefront w sums the levels w + 1, w + 5, ...
       // (lane-strided, then one butterfly: no block barrier per level), the rows follow
       {
-        double* lsum = W;                                      // [2][LC + 1], W is free until later
+        double* lsum = red + 2 * NWV;                          // [2][LC + 1] (behind group_sum's slots)
         const int wv = tid >> 6, ln = tid & 63;
         for (int l = 1 + wv; l <= LC; l += NWV) {
           const int stride = NC >> l, cnt = 1 << (l - 1);
@@ -923,7 +934,6 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
         R.start(b - a, cfg.global_precision, cfg.halo_precision, 0.5 * (F0[0] + F0[NC]),
                 0.5 * (F1[0] + F1[NC]), pa, pb);
         for (int l = 1; l <= LC && !R.all_done(); ++l) R.advance(l, lsum[l], lsum[LC + 1 + l]);
-        __syncthreads();                                       // (W is reused below)
       }
       if (!R.all_done()) {
         // ---- break points: coarse intervals whose ends are in different states
@@ -995,7 +1005,6 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
                 if (i >= seg_lo[x] && i < seg_hi[x]) sg = x + 1;
               code[i] = (unsigned char)sg;
             }
-            if (tid < kDeepWStride) W[tid] = deepw[tid];       // weights of n = 1 (level LC + 1)
             __syncthreads();
             // ---- self-check: the same machinery one level up.  Every odd sample is predicted
             // from the even ones (stencils of twice the spacing, shifted at segment ends
@@ -1037,41 +1046,83 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
         }
       }
       if (!literal) {
-        // ---- deeper levels: weighted sums of the samples + the break-point intervals
+        // ---- deeper levels, kDeepRound at a time (their sums are independent; what a level
+        // costs here is latency -- a handful of node-by-node evaluations and two reductions --
+        // so a pass over three levels takes little longer than one; a knot that stops at the
+        // first of them has summed two levels for nothing): weighted sums of the samples + the
+        // break-point intervals, then the rows one by one
         const int nf = n_fine_sh;
-        for (int lv = LC + 1; lv <= cfg.divmax && !R.all_done(); ++lv) {
-          __syncthreads();                                     // (previous level done with W)
-          if (tid < kDeepWStride) W[tid] = deepw[(size_t)(lv - LC - 1) * kDeepWStride + tid];
-          __syncthreads();
-          const int n = 1 << (lv - 1 - LC);
-          double s0 = 0.0, s1 = 0.0;
+        for (int lv0 = LC + 1; lv0 <= cfg.divmax && !R.all_done(); lv0 += kDeepRound) {
+          const int ng = cfg.divmax - lv0 + 1 < kDeepRound ? cfg.divmax - lv0 + 1 : kDeepRound;
+          double s0[kDeepRound], s1[kDeepRound];
+#pragma unroll
+          for (int g = 0; g < kDeepRound; ++g) { s0[g] = 0.0; s1[g] = 0.0; }
+          const double* Wl = W + (size_t)(lv0 - LC - 1) * kDeepWStride;
           for (int i = tid; i < NC; i += NT) {
             const int sg = code[i];
             if (!sg) continue;                                 // node by node below
             const int lo = seg_lo[sg - 1], hi = seg_hi[sg - 1];
             int st = i - 3;
             st = st < lo ? lo : (st > hi - 7 ? hi - 7 : st);
-            const double* w = W + (i - st) * kDeepStencil;
+            double f0[kDeepStencil], f1[kDeepStencil];
 #pragma unroll
-            for (int m = 0; m < kDeepStencil; ++m) {
-              s0 = fma(w[m], F0[st + m], s0);
-              s1 = fma(w[m], F1[st + m], s1);
+            for (int m = 0; m < kDeepStencil; ++m) { f0[m] = F0[st + m]; f1[m] = F1[st + m]; }
+#pragma unroll
+            for (int g = 0; g < kDeepRound; ++g) {
+              if (g < ng) {
+                const double* w = Wl + g * kDeepWStride + (i - st) * kDeepStencil;
+#pragma unroll
+                for (int m = 0; m < kDeepStencil; ++m) {
+                  s0[g] = fma(w[m], f0[m], s0[g]);
+                  s1[g] = fma(w[m], f1[m], s1[g]);
+                }
+              }
             }
           }
-          const long numtosum = 1L << (lv - 1);
-          const double h = (b - a) / (double)numtosum;
-          const double lox = a + 0.5 * h;
-          for (int idx = tid; idx < nf * n; idx += NT) {
-            const long j = (long)fine_sh[idx / n] * n + (idx % n);
+          // the break-point intervals: level lv0 + g has n0 << g nodes in each
+          const int n0 = 1 << (lv0 - 1 - LC);
+          const int per0 = nf * n0;                            // nodes of the round's first level
+          const int total = per0 * ((1 << ng) - 1);
+          for (int idx = tid; idx < total; idx += NT) {
+            int g = 0, r = idx;
+            while (r >= (per0 << g)) { r -= per0 << g; ++g; }
+            const int n = n0 << g;
+            const long j = (long)fine_sh[r / n] * n + (r % n);
+            const double h = (b - a) / (double)(1L << (lv0 + g - 1));
             double o[2];
             int st;
-            halo_eval_coded(group, c, lox + h * (double)j, o, &st);
-            s0 += o[0];
-            s1 += o[1];
+            halo_eval_coded(group, c, (a + 0.5 * h) + h * (double)j, o, &st);
+#pragma unroll
+            for (int gg = 0; gg < kDeepRound; ++gg)
+              if (gg == g) { s0[gg] += o[0]; s1[gg] += o[1]; }
           }
-          s0 = group_sum<NWV>(s0, red, flip);
-          s1 = group_sum<NWV>(s1, red, flip);
-          R.advance(lv, s0, s1);
+          // one exchange for the 2 ng sums
+          {
+            double* slot = red + (flip ? 2 * kDeepRound * NWV : 0);
+#pragma unroll
+            for (int g = 0; g < kDeepRound; ++g) {
+              const double x0 = wave_sum(s0[g]), x1 = wave_sum(s1[g]);
+              if ((tid & 63) == 0) {
+                slot[(2 * g) * NWV + (tid >> 6)] = x0;
+                slot[(2 * g + 1) * NWV + (tid >> 6)] = x1;
+              }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int g = 0; g < kDeepRound; ++g) {
+              double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+              for (int wv = 0; wv < NWV; ++wv) {
+                t0 += slot[(2 * g) * NWV + wv];
+                t1 += slot[(2 * g + 1) * NWV + wv];
+              }
+              s0[g] = t0; s1[g] = t1;
+            }
+            flip ^= 1;
+          }
+#pragma unroll
+          for (int g = 0; g < kDeepRound; ++g)
+            if (g < ng && !R.all_done()) R.advance(lv0 + g, s0[g], s1[g]);
         }
         val[0] = R.value[0]; val[1] = R.value[1];
         lev[0] = R.level[0]; lev[1] = R.level[1];
