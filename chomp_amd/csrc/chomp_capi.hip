@@ -674,6 +674,9 @@ static int halo_prepare(chomp_ctx* ctx, const chomp_halo_par* profile, const cho
   if (P->fam & ((1u << F_HM) | (1u << F_PPMM))) P->groups[P->ng++] = 0;
   if (P->fam & ((1u << F_HG) | (1u << F_PPGM))) P->groups[P->ng++] = 1;
   if (P->fam & (1u << F_PPGG)) P->groups[P->ng++] = 2;
+  // integrands that can run beyond the node tables (the HOD ones): one level more in the tables
+  if ((P->groups[0] > 0 || P->groups[1] > 0 || P->groups[2] > 0) && ctx->cfg.divmax > kNodeLevel)
+    P->kmask |= kMaskDeepNodes;
   return CHOMP_OK;
 }
 
@@ -733,7 +736,8 @@ static int launch_halo_knots(chomp_ctx* ctx, const HaloPlan& P) {
                      ctx->cfg, L, ctx->d_epochs, ctx->d_tab, ctx->d_profile, ctx->d_hod,            \
                      ctx->d_sici, P.groups[0], P.groups[1], P.groups[2], P.kmask, (int)n,           \
                      ctx->d_pending, ctx->d_npend, ctx->d_epochs, P.fam, ctx->d_status,             \
-                     ctx->d_deepw, ctx->tune[CHOMP_TUNE_DEEP_LITERAL] > 0 ? 1 : 0, ctx->d_deepstat)
+                     ctx->d_deepw, ctx->tune[CHOMP_TUNE_DEEP_LITERAL] > 0 ? 1 : 0, ctx->d_deepstat,     \
+                     ctx->d_nodes)
   if ((size_t)L.NK * n * ng <= 768) CHOMP_KNOTS_FAST(kDeepThreadsFew);
   else CHOMP_KNOTS_FAST(kDeepThreads);
 #undef CHOMP_KNOTS_FAST
@@ -772,7 +776,11 @@ int chomp_halo_setup(chomp_ctx* ctx, const chomp_halo_par* profile,
   const size_t n = ctx->n_epoch;
   const TabLayout& L = ctx->L;
   const size_t sh = (size_t)(L.NM + 8 * (L.NM - 1) + kKnotScratch) * sizeof(double);
-  hipLaunchKernelGGL(k_halo_nodes, dim3((unsigned)n, (unsigned)(P.ng > 0 ? P.ng : 1)), dim3(256), sh,
+  // (few epochs: the table's nodes over several blocks each)
+  const unsigned ngy = (unsigned)(P.ng > 0 ? P.ng : 1);
+  unsigned nchunks = (unsigned)(512 / (n * ngy));
+  nchunks = nchunks < 1 ? 1 : (nchunks > 8 ? 8 : nchunks);
+  hipLaunchKernelGGL(k_halo_nodes, dim3((unsigned)n, ngy, nchunks), dim3(256), sh,
                      ctx->stream, ctx->cfg, L, ctx->d_epochs, ctx->d_tab, ctx->d_profile,
                      ctx->d_hod, ctx->d_sici, ctx->d_nodes, ctx->d_endp, P.groups[0], P.groups[1],
                      P.groups[2], P.kmask, ctx->d_status, ctx->d_npend, ctx->d_pending);

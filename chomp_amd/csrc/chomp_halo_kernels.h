@@ -25,6 +25,7 @@ namespace chomp {
 constexpr double kPendingLevel = -1.0;   // levels-table marker: needs the deep pass
 constexpr int kPendingHead = 4;          // ints in front of the items of the work list
 constexpr unsigned kMaskExclusion = 1u << 8;   // bit of the kernels' family mask: HaloExclusion
+constexpr unsigned kMaskDeepNodes = 1u << 9;   // ... the node tables hold level kNodeTabLevel too
 
 struct HaloCtx {
   const Epoch* e;
@@ -235,38 +236,44 @@ __device__ __forceinline__ void halo_node_fields(const Epoch& E, const double* n
   const double con = exp(ln_c);
   const double cp = 1.0 + con;
   const double ln_cp = log(cp);
-  double wA, wB, flag = 0.0;
+  // state: the discrete state of the integrand at the node (halo_eval_coded's code): bit 0 the
+  // occupation below one (which power of y, halo.py:1038-1041, 1084-1086), bit 1 satellites
+  // on, bit 2 a step-function central occupation above its threshold
+  double wA, wB;
+  int state = 0;
   if (group == 0) {
     wA = nf * bias;
     wB = nf * mass;
   } else {
     double n1, n2;
     zheng_node(E, mass, lnm, &n1, &n2);
+    state = (mass - E.hod_M0 > 0.0) ? 2 : 0;
+    if (E.hod_sigma <= 0.0 && lnm * 0.43429448190325182765 > E.hod_log_M_min) state |= 4;
     if (group == 1) {
       wA = nf * bias * n1 / mass;
       wB = nf * n1;
-      flag = n1 < 1.0 ? 1.0 : 0.0;
+      state |= n1 < 1.0 ? 1 : 0;
     } else {
       wA = 0.0;
       wB = nf * n2 / mass;
-      flag = n2 < 1.0 ? 1.0 : 0.0;
+      state |= n2 < 1.0 ? 1 : 0;
     }
   }
   f[0] = wA; f[1] = wB; f[2] = ln_rv - ln_c; f[3] = con; f[4] = ln_cp;
-  f[5] = 1.0 / (ln_cp - con / cp); f[6] = flag;
+  f[5] = 1.0 / (ln_cp - con / cp); f[6] = (double)state;
 }
 
 // The integrand pair of a knot at one node, from the node's fields (out[0] = wA y,
-// out[1] = wB (flag ? y : y^2); group 2 uses only out[1]).
+// out[1] = wB (flag ? y : y^2), flag = bit 0 of the state; group 2 uses only out[1]).
 __device__ __forceinline__ void node_pair(const SiCiTab& S, double ln_k, bool exclusion,
                                           double wA, double wB, double ln_rs, double con,
-                                          double ln_cp, double inv_mass_k, double flag,
+                                          double ln_cp, double inv_mass_k, double state,
                                           double (&out)[2]) {
   double z;             // k r_s; k * 2 r_v = 2 c z
   const double y = y_nfw_core(S, ln_k, ln_rs, con, ln_cp, inv_mass_k, &z);
   out[0] = wA * y;
   if (exclusion) out[0] *= exclusion_window(S, 2.0 * con * z);
-  out[1] = wB * (flag != 0.0 ? y : y * y);
+  out[1] = wB * (((int)state & 1) ? y : y * y);
 }
 
 // The node table of one (epoch, group) by a whole block: every node of the level-kNodeLevel
@@ -278,11 +285,13 @@ __device__ __forceinline__ void halo_nodes_block(const chomp_config& cfg, const 
                                                  const double* nu_knots, const double* lnm_pp,
                                                  int group, bool exclusion,
                                                  double* __restrict__ node,
-                                                 double* __restrict__ endp, int chunk = 0,
-                                                 int n_chunks = 1) {
+                                                 double* __restrict__ endp, bool deep,
+                                                 int chunk = 0, int n_chunks = 1) {
   const double a = group_lower(E, group), b = log(E.nu_max);
   // (chunk c of n: nodes c, c + n, c + 2 n, ... dealt to the threads; knots likewise)
-  for (int idx = chunk + n_chunks * (int)threadIdx.x; idx < kNodeCount;
+  // deep: level kNodeTabLevel as well (the coarse samples of k_halo_knots_fast)
+  const int count = deep ? kNodeCount : kNodeBase;
+  for (int idx = chunk + n_chunks * (int)threadIdx.x; idx < count;
        idx += n_chunks * (int)blockDim.x) {
     double x;
     if (idx < 2) {
@@ -333,8 +342,10 @@ __device__ __forceinline__ void halo_epoch_begin(Epoch& E, const chomp_halo_par&
 }
 
 // ---------------------------------------------------------------------------
-// k_halo_nodes: grid (n_epoch, n_groups), block 256: chomp_halo_setup on its own (after a
-// chomp_mass_setup; the fused chomp_stage_k does the same in the tail of k_nu_mass).
+// k_halo_nodes: grid (n_epoch, n_groups, n_chunks), block 256: chomp_halo_setup on its own
+// (after a chomp_mass_setup; the fused chomp_stage_k does the same in k_mass_nodes).  Chunk
+// blockIdx.z of the (epoch, group) node table; every block derives the epoch's constants, the
+// first one publishes them.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_halo_nodes(
     chomp_config cfg, TabLayout L, Epoch* __restrict__ epochs, const double* __restrict__ tab,
@@ -353,19 +364,20 @@ __global__ __launch_bounds__(256) void k_halo_nodes(
   __shared__ int scratch_npend;
   if (threadIdx.x < 64) {
     // (every group's block derives the same constants; the first one publishes them)
+    const bool first = blockIdx.y == 0 && blockIdx.z == 0;
     halo_epoch_begin(E, profile[e], hod[e], H.nu_pp, tab[(size_t)e * L.stride + L.off_ln_mass],
-                     L.NM, blockIdx.y == 0 ? &status[e] : &scratch_status,
-                     blockIdx.y == 0 ? &npend[e] : &scratch_npend, pending,
-                     blockIdx.y == 0 && e == 0);
+                     L.NM, first ? &status[e] : &scratch_status,
+                     first ? &npend[e] : &scratch_npend, pending, first && e == 0);
   }
   __syncthreads();
-  if (blockIdx.y == 0)
+  if (blockIdx.y == 0 && blockIdx.z == 0)
     copy_doubles(reinterpret_cast<double*>(&epochs[e]), reinterpret_cast<const double*>(&E),
                  kEpochDoubles);
   if (group < 0 || group > 2) return;            // n_bar only: the record is all it needs
   halo_nodes_block(cfg, L, E, S, H.nu_knots, H.lnm_pp, group, (mask & kMaskExclusion) != 0,
                    nodes + ((size_t)e * 3 + group) * kNodeStride,
-                   endp + ((size_t)e * 3 + group) * 2 * L.NK);
+                   endp + ((size_t)e * 3 + group) * 2 * L.NK, (mask & kMaskDeepNodes) != 0,
+                   (int)blockIdx.z, (int)gridDim.z);
 }
 
 // ---------------------------------------------------------------------------
@@ -415,7 +427,8 @@ __global__ __launch_bounds__(256) void k_mass_nodes(
   if (group < 0 || group > 2) return;            // n_bar only: the record is all it needs
   halo_nodes_block(cfg, L, E, S, M.y_nu, M.c_lnm, group, (mask & kMaskExclusion) != 0,
                    nodes + ((size_t)e * 3 + group) * kNodeStride,
-                   endp + ((size_t)e * 3 + group) * 2 * L.NK, (int)blockIdx.z, (int)gridDim.z);
+                   endp + ((size_t)e * 3 + group) * 2 * L.NK, (mask & kMaskDeepNodes) != 0,
+                   (int)blockIdx.z, (int)gridDim.z);
 }
 
 // Halo.calculate_bias / calculate_m_eff / calculate_f_sat (halo.py:709-838): grid (3, n),
@@ -827,7 +840,8 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
     const SiCiTab* __restrict__ sici_g, int g0, int g1, int g2, unsigned mask, int n_epoch,
     int* __restrict__ pending, int* __restrict__ npend, Epoch* __restrict__ epochs_rw,
     unsigned fam_mask, unsigned* __restrict__ status, const double* __restrict__ deepw,
-    int force_literal, int* __restrict__ stats) {
+    int force_literal, int* __restrict__ stats, const double* __restrict__ nodes) {
+  static_assert(LC == kNodeTabLevel, "the coarse samples are the node table's grid");
   constexpr int NC = 1 << LC;
   constexpr int NWV = NT / 64;
   extern __shared__ __align__(16) double sm[];
@@ -902,14 +916,38 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
     int flip = 0;
     RombergRows2 R;
     if (!literal) {
-      // ---- coarse samples
-      for (int q = tid; q <= NC; q += NT) {
-        double o[2];
-        int st;
-        halo_eval_coded(group, c, deep_coarse_x<LC>(a, b, q), o, &st);
-        F0[q] = o[0];
-        F1[q] = o[1];
-        code[q] = (unsigned char)st;
+      // ---- coarse samples: from the (epoch, group) node table when it reaches level LC (what
+      // does not depend on k is already there -- the lower levels are the very nodes
+      // k_halo_knots summed), else one evaluation each
+      if (mask & kMaskDeepNodes) {
+        const double* nd = nodes + ((size_t)e * 3 + group) * kNodeStride;
+        for (int idx = tid; idx <= NC; idx += NT) {
+          int q;
+          if (idx < 2) {
+            q = idx == 0 ? 0 : NC;
+          } else {                                             // level-major -> position
+            const int m = idx - 1;
+            const int lv = 32 - __builtin_clz((unsigned)m);
+            q = (2 * (m - (1 << (lv - 1))) + 1) << (LC - lv);
+          }
+          double o[2];
+          const double state = nd[6 * kNodeCount + idx];
+          node_pair(S, c.ln_k, c.exclusion, nd[idx], nd[kNodeCount + idx], nd[2 * kNodeCount + idx],
+                    nd[3 * kNodeCount + idx], nd[4 * kNodeCount + idx], nd[5 * kNodeCount + idx],
+                    state, o);
+          F0[q] = o[0];
+          F1[q] = o[1];
+          code[q] = (unsigned char)(int)state;
+        }
+      } else {
+        for (int q = tid; q <= NC; q += NT) {
+          double o[2];
+          int st;
+          halo_eval_coded(group, c, deep_coarse_x<LC>(a, b, q), o, &st);
+          F0[q] = o[0];
+          F1[q] = o[1];
+          code[q] = (unsigned char)st;
+        }
       }
       if (tid == 0) { n_rough_sh = 0; n_fine_sh = 0; n_seg_sh = 0; }
       __syncthreads();

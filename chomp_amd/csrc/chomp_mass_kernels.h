@@ -64,9 +64,14 @@ enum { F_HM = 0, F_PPMM = 1, F_HG = 2, F_PPGM = 3, F_PPGG = 4 };
 // concentration, r_s, HOD moments) is tabulated once per (epoch, integration range)
 // on the level-kNodeLevel Romberg grid, stored level by level so a level's nodes are
 // contiguous.  Deeper levels fall back to direct evaluation.
+// The table has room for one level more (kNodeTabLevel): with integrands that can run beyond
+// the node table (the HOD ones) its nodes are filled in too, and k_halo_knots_fast reads the
+// 2^11 + 1 coarse samples of a listed knot off them instead of evaluating each from scratch.
 constexpr int kNodeLevel = 10;
-constexpr int kNodeCount = (1 << kNodeLevel) + 1;
-constexpr int kNodeFields = 7;   // wA, wB, ln_rs, con, ln_cp, inv_mass_k, flag
+constexpr int kNodeTabLevel = 11;
+constexpr int kNodeBase = (1 << kNodeLevel) + 1;        // nodes k_halo_knots reads
+constexpr int kNodeCount = (1 << kNodeTabLevel) + 1;    // nodes of the table (the field stride)
+constexpr int kNodeFields = 7;   // wA, wB, ln_rs, con, ln_cp, inv_mass_k, state (bit 0: flag)
 constexpr int kNodeStride = kNodeFields * kNodeCount + 8;   // doubles per (epoch, group);
                                                             // tail: integration limits a, b
 __host__ __device__ inline int node_index(int lev, long j) {
