@@ -22,16 +22,16 @@ def build():
         "template <int LC, int NT>\n// (eight wavefronts per CU" % (NB, NS, NB, NS))
     rep("  if (count == 0) return;          // nothing listed: no traffic on the queue head\n  for (;;) {\n",
         "  if (count == 0) return;          // nothing listed: no traffic on the queue head\n  bool first_item = true; int n_items = 0;\n  for (;;) {\n    first_item = (n_items++ == 0);\n")
-    rep("    HaloLds H;\n    H.stage(L, E, S, epochs, e, t, profile, hod, sici_g, sm);\n    double* red = H.rest;\n    double* F0 = red + kDeepScratch;",
-        "    KSTAMP(0);\n    HaloLds H;\n    H.stage(L, E, S, epochs, e, t, profile, hod, sici_g, sm);\n    double* red = H.rest;\n    double* F0 = red + kDeepScratch;")
-    rep("      // ---- coarse samples\n", "      __syncthreads(); KSTAMP(1);\n      // ---- coarse samples\n")
+    rep("    HaloLds H;\n    // (the weights of every deep level", "    KSTAMP(0);\n    HaloLds H;\n    // (the weights of every deep level")
+    rep("      // ---- coarse samples: from the", "      __syncthreads(); KSTAMP(1);\n      // ---- coarse samples: from the")
     rep("      if (tid == 0) { n_rough_sh = 0; n_fine_sh = 0; n_seg_sh = 0; }\n      __syncthreads();\n",
         "      if (tid == 0) { n_rough_sh = 0; n_fine_sh = 0; n_seg_sh = 0; }\n      __syncthreads();\n      KSTAMP(2);\n")
     rep("      if (!R.all_done()) {\n        // ---- break points", "      KSTAMP(3);\n      if (!R.all_done()) {\n        // ---- break points")
     rep("            // ---- self-check: the same machinery one level up.", "            KSTAMP(4);\n            // ---- self-check: the same machinery one level up.")
-    rep("      if (!literal) {\n        // ---- deeper levels: weighted sums of the samples + the break-point intervals\n        const int nf = n_fine_sh;\n",
-        "      KSTAMP(5);\n      if (!literal) {\n        // ---- deeper levels: weighted sums of the samples + the break-point intervals\n        const int nf = n_fine_sh;\n        if (first_item && tid == 0 && blockIdx.x < %d) g_ks[blockIdx.x * %d + 22] = nf;\n" % (NB, NS))
-    rep("          R.advance(lv, s0, s1);\n        }\n        val[0] = R.value[0];", "          R.advance(lv, s0, s1);\n          KSTAMP(5 + lv - LC);\n        }\n        val[0] = R.value[0];")
+    rep("      if (!literal) {\n        // ---- deeper levels, kDeepRound at a time",
+        "      KSTAMP(5);\n      if (!literal) {\n        if (first_item && tid == 0 && blockIdx.x < %d) g_ks[blockIdx.x * %d + 22] = n_fine_sh;\n        // ---- deeper levels, kDeepRound at a time" % (NB, NS))
+    rep("            if (g < ng && !R.all_done()) R.advance(lv0 + g, s0[g], s1[g]);\n        }\n",
+        "            if (g < ng && !R.all_done()) R.advance(lv0 + g, s0[g], s1[g]);\n          KSTAMP(5 + (lv0 - LC - 1) / kDeepRound + 1);\n        }\n")
     rep("    arrive(e, false);\n  }   // next item", "    KSTAMP(16);\n    if (first_item && tid == 0 && blockIdx.x < %d) g_ks[blockIdx.x * %d + 23] = lev[0] > lev[1] ? lev[0] : lev[1];\n    arrive(e, false);\n    KSTAMP(17);\n  }   // next item" % (NB, NS))
     c = c0.replace('int chomp_set_tuning(chomp_ctx* ctx, int what, long long value) {',
                    'int chomp_debug_ks(long long* out, int n, int clear) {\n  if (clear) { static long long z[%d]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(chomp::g_ks), z, sizeof(z)); }\n'
@@ -73,11 +73,11 @@ def run():
             ok = a[:, i + 1] > 0
             d = (a[ok, i + 1] - a[ok, i]) / T
             print("  %-16s n %4d  mean %6.2f  max %6.2f us" % (nm, ok.sum(), d.mean() if ok.sum() else 0, d.max() if ok.sum() else 0))
-        for lv in range(1, 10):
+        for lv in range(1, 5):
             ok = (a[:, 5 + lv] > 0) & (a[:, 4 + lv] > 0)
             if ok.sum():
                 d = (a[ok, 5 + lv] - a[ok, 4 + lv]) / T
-                print("  level %2d         n %4d  mean %6.2f  max %6.2f us   (nf mean %.1f)" % (11 + lv, ok.sum(), d.mean(), d.max(), a[ok, 22].mean()))
+                print("  round %2d         n %4d  mean %6.2f  max %6.2f us   (nf mean %.1f)" % (lv, ok.sum(), d.mean(), d.max(), a[ok, 22].mean()))
         ok = a[:, 16] > 0
         tot = (a[ok, 16] - a[ok, 0]) / T
         print("  whole knot       n %4d  mean %6.2f  max %6.2f us;  arrive %5.2f us" % (ok.sum(), tot.mean(), tot.max(), ((a[ok, 17] - a[ok, 16]) / T).mean()))
