@@ -537,7 +537,7 @@ def main():
                        "stage_k_ms": ts3 * 1e3,
                        "frac": f3["frac"] if f3 else None,
                        "frac_of": "vector-fp64 peak, Stage K (profiles/round2_stage_k_counters.json)",
-                       "deep_knots_fast_literal": list(hg3.ctx.deep_stats())}
+                       "deep_knots_fast_literal_cumulative": list(hg3.ctx.deep_stats())}
         del hg3
         for name, ggl in (("c4", False), ("c5", True)):
             ep = projection_leg(D, ggl, 10, 2)
@@ -546,8 +546,10 @@ def main():
                                else "clustering J0 kernel + power_gg"),
                            "ms_per_step": 1e3 * ep / 10, "value": (N_THETA + N_ELL) * 10 / ep,
                            "unit": "samples/s", "steps": 10,
-                           "dominant_kernel": "k_wtheta (one theta per 1024-thread block, "
-                                              "Romberg on the tabulated k-only factor)",
+                           "dominant_kernel": "none above a fifth of the step: k_halo_knots_fast "
+                                              "(knots beyond the node tables), k_cell + k_cell_deep, "
+                                              "k_wtheta_nodes / _moments / _fast (level sums from "
+                                              "prefix moments)",
                            "frac": None,
                            "profile": "profiles/round2_kernel_stats_%s.csv" % name}
         res["other_configs"] = other
