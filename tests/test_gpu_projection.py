@@ -199,3 +199,50 @@ def test_cell_hand_over_matches_one_kernel(mods, ggl):
     assert numpy.all(numpy.isfinite(two))
     assert numpy.max(numpy.abs(two / one - 1)) < 1e-12
     assert (two != one).sum() < ell.size       # (most multipoles never reach the hand-over)
+
+
+@pytest.mark.parametrize("over", [dict(divmax=8), dict(divmax=11), dict(divmax=12), dict(divmax=22),
+                                  dict(kernel_npoints=72)])
+def test_shortened_routes_at_other_depths(mods, over):
+    """The moment route of w(theta) and the hand-over of C_l against their checkers
+    (CHOMP_TUNE_WTHETA_DIRECT, CHOMP_TUNE_CELL_ONE_KERNEL) with the Romberg depth below, at and
+    just above the hand-over level (11), beyond the w(theta) node table (20: the node-by-node
+    kernel is the route), and with more kernel knots than a wavefront has lanes (ditto); a single
+    sample; HaloFit P_mm, which is defined outside [k_min, k_max] (the spectrum table does not
+    answer there) and Halo(extrapolate=True)."""
+    import copy
+    from chomp_amd import _lib, defaults
+    cosmology, kernel, correlation, halo = mods
+    saved = copy.deepcopy(defaults.default_precision)
+    try:
+        defaults.default_precision.update(over)
+        theta = numpy.logspace(-4.5, 0.3, 41) * D2R
+        ell = numpy.logspace(0.3, 4.7, 67)
+        for spec, h in (("power_gg", halo.Halo(0.0)), ("power_mm", halo.HaloFit(0.0)),
+                        ("power_gm", halo.Halo(0.0, extrapolate=True))):
+            cm, kern = _projection(mods, False)
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")          # (divmax warnings of the shallow set-ups)
+                corr = correlation.Correlation(0.001, 1.0, kern, input_halo=h, power_spec=spec)
+                cf = correlation.CorrelationFourier(10, 1e4, kern, input_halo=h, powSpec=spec)
+                ctx, _ = corr._prepare()
+                try:
+                    ctx.set_tuning(_lib.TUNE_WTHETA_DIRECT, 1)
+                    ctx.set_tuning(_lib.TUNE_CELL_ONE_KERNEL, 1)
+                    w_ref, c_ref = corr.correlation(theta), cf.correlation(ell)
+                    w_one, c_one = corr.correlation(theta[7]), cf.correlation(ell[-1])
+                finally:
+                    ctx.set_tuning(_lib.TUNE_WTHETA_DIRECT, -1)
+                    ctx.set_tuning(_lib.TUNE_CELL_ONE_KERNEL, -1)
+                w, c = corr.correlation(theta), cf.correlation(ell)
+            assert numpy.all(numpy.isfinite(w)) and numpy.all(numpy.isfinite(c)), (over, spec)
+            assert numpy.max(numpy.abs(w - w_ref)) < 1e-10 * numpy.max(numpy.abs(w_ref)), (over, spec)
+            ok = c_ref != 0
+            assert numpy.array_equal(ok, c != 0)
+            assert numpy.max(numpy.abs(c[ok] / c_ref[ok] - 1)) < 1e-12, (over, spec)
+            assert abs(corr.correlation(theta[7]) - w_one) < 1e-10 * numpy.max(numpy.abs(w_ref))
+            assert cf.correlation(ell[-1]) == pytest.approx(c_one, rel=1e-12)
+    finally:
+        defaults.default_precision.clear()
+        defaults.default_precision.update(saved)
