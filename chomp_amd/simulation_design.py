@@ -26,13 +26,16 @@ _BATCHED_METHODS = ("linear_power", "power_mm", "power_gm", "power_mg", "power_g
 
 
 def random_lhs(n, k):
-    """Random Latin Hypercube Sample (simulation_design.py:17-33, the randomLHS
-    algorithm of the R package 'lhs'): n design points, k variables."""
-    P = numpy.zeros((n, k), dtype='float64')
-    for i in range(k):
-        P[:, i] = numpy.random.permutation(range(n))
-    P = P + numpy.random.uniform(size=(n, k))
-    return P / n
+    """n points of a random Latin hypercube in k variables (what simulation_design.py:17-33 takes
+    from the R package 'lhs'): every variable's range is cut into n strata, each stratum is used
+    by exactly one point, and a point sits uniformly inside its stratum.  Draws from numpy's
+    global generator in the reference's order (the k orderings first, then the positions), so a
+    seeded design is the reference's design."""
+    strata = numpy.empty((n, k), dtype=numpy.float64)
+    for col in range(k):
+        strata[:, col] = numpy.random.permutation(n)
+    inside = numpy.random.uniform(size=(n, k))
+    return (strata + inside) / float(n)
 
 
 class _Recorder(object):
