@@ -53,6 +53,10 @@ def run():
     print("mean duration by mass index (50):"); print(d.mean(axis=0))
     print("max duration by mass index:"); print(d.max(axis=0))
     print("start time of blocks (us after first): min/mean/max by mass index 0, 25, 49:", [(float((a[:, i, 0].min() - t0) / T), float((a[:, i, 0].mean() - t0) / T), float((a[:, i, 0].max() - t0) / T)) for i in (0, 25, 49)])
+    print("mean duration by epoch (64):"); print(d.mean(axis=1))
+    print("max duration by epoch:"); print(d.max(axis=1))
+    print("the 12 longest: (epoch, mass index, us)", sorted(((float(d[e, i]), e, i) for e in range(64) for i in range(50)), reverse=True)[:12])
+    print("histogram of durations (us, 5-us bins from 0):", numpy.histogram(d, bins=numpy.arange(0, 60, 5))[0])
     print("sum of durations %.0f us -> /1024 SIMDs = %.1f us of perfectly packed single-wave time" % (d.sum(), d.sum() / 1024))
 
 
