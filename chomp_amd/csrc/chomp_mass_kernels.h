@@ -450,8 +450,21 @@ __device__ __forceinline__ double sigma2_block(const Epoch& E, const double* sno
     RombergLoose ls{0.0, 0.0, 0.0, 0.0, 0.0};          // (the integral is sigma^2 / amp2 here)
     if (loose) ls = RombergLoose{loose->rtol, loose->lo1 / amp2, loose->hi1 / amp2,
                                  loose->lo2 / amp2, loose->hi2 / amp2};
-    const RombergOut<1> r = romberg_group<NW, 1, SigmaTabIntegrand<BAO>, UNROLL>(
-        f, lo, hi, cfg.global_precision, rtol, cfg.divmax, red, nullptr, loose ? &ls : nullptr);
+    RombergOut<1> r;
+    bool fused = false;
+    if constexpr (NW == 1) fused = loose == nullptr && cfg.divmax >= 6;
+    if (fused) {
+      // one wavefront: levels 0..6 in ONE pass (lane p on node p of the level-6 grid, the upper
+      // end point by every lane) and their rows replayed -- walked one by one they are seven
+      // dependent round trips of ~2 us each with a node or less per lane, half of a typical
+      // integral of the nu table
+      double fb[1];
+      f(hi, fb, 0, 1);
+      r = romberg_wave6<1>(f, lo, hi, fb, cfg.global_precision, rtol, cfg.divmax);
+    } else {
+      r = romberg_group<NW, 1, SigmaTabIntegrand<BAO>, UNROLL>(
+          f, lo, hi, cfg.global_precision, rtol, cfg.divmax, red, nullptr, loose ? &ls : nullptr);
+    }
     if (converged) *converged = r.converged[0];
     return amp2 * r.value[0];
   }
@@ -462,8 +475,15 @@ __device__ __forceinline__ double sigma2_block(const Epoch& E, const double* sno
     SigmaInterpIntegrand f{snode + kSigmaOffG, xlo, dx, 1.0 / dx, R, amp2 * 9.0 / (r3 * r3), amp2,
                            100.0 * E.k_max * R < 1.0};
     Scalar1<SigmaInterpIntegrand> w{f};
-    const RombergOut<1> r = romberg_group<NW, 1>(w, lo, hi, cfg.global_precision, rtol, cfg.divmax, red,
-                                                 nullptr, loose);
+    RombergOut<1> r;
+    bool fused = false;
+    if constexpr (NW == 1) fused = loose == nullptr && cfg.divmax >= 6;
+    if (fused) {
+      const double fb[1] = {f(hi)};
+      r = romberg_wave6<1>(w, lo, hi, fb, cfg.global_precision, rtol, cfg.divmax);
+    } else {
+      r = romberg_group<NW, 1>(w, lo, hi, cfg.global_precision, rtol, cfg.divmax, red, nullptr, loose);
+    }
     if (converged) *converged = r.converged[0];
     return r.value[0];
   } else {
