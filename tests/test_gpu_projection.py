@@ -8,6 +8,9 @@ from conftest import load_golden, rel_err
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-4
+# w(theta) and C_l against the reference's vectors: measured 4e-11 (G6) and 7e-12 (G7) on MI355X
+# (tools/parity_numbers.py): the same Romberg rows on the same integrand values
+PROJ_RTOL = 1e-9
 D2R = numpy.pi / 180.0
 
 
@@ -82,11 +85,11 @@ def test_c4_wtheta_and_cell(mods):
         assert abs(corr.D_z / float(g["D_z"]) - 1) < 1e-9
         assert numpy.allclose(corr.theta_array, g["theta_bins"], rtol=1e-14)
         w = corr.correlation(g["theta"])
-        assert rel_err(w, g["w_" + ps]) < RTOL, ps
+        assert rel_err(w, g["w_" + ps]) < PROJ_RTOL, ps
         assert numpy.shape(corr.correlation(g["theta"][3])) == ()
         cf = correlation.CorrelationFourier(10, 1e4, kern, input_halo=h, powSpec=ps)
         cl = cf.correlation(g["ell"])
-        assert rel_err(cl, g["cl_" + ps]) < RTOL, ps
+        assert rel_err(cl, g["cl_" + ps]) < PROJ_RTOL, ps
 
 
 def test_c5_halofit_ggl(mods):
@@ -105,10 +108,10 @@ def test_c5_halofit_ggl(mods):
     assert numpy.allclose(mine, g["hf_z0_pars"], rtol=2e-5)
     corr = correlation.Correlation(0.001, 1.0, kern, input_halo=hf, power_spec="power_gm")
     w = corr.correlation(g["theta"])
-    assert rel_err(w, g["w_ggl"]) < RTOL
+    assert rel_err(w, g["w_ggl"]) < PROJ_RTOL
     assert rel_err(hf.power_gm(g["k"]), g["hf_gm_zbar"]) < RTOL
     cf = correlation.CorrelationFourier(10, 1e4, kern, input_halo=hf, powSpec="power_gm")
-    assert rel_err(cf.correlation(g["ell"]), g["cl_ggl"]) < RTOL
+    assert rel_err(cf.correlation(g["ell"]), g["cl_ggl"]) < PROJ_RTOL
 
 
 def test_c5_precision_sweep(mods):
@@ -142,7 +145,7 @@ def test_c5_precision_sweep(mods):
         json.dump({"case": "G7 w_GGL(theta), 33 theta, HaloFit power_gm, J2 kernel",
                    "max_rel_err_vs_reference": errs}, fh, indent=1)
     print("precision sweep:", errs)
-    assert errs["fp64"] < RTOL
+    assert errs["fp64"] < PROJ_RTOL
     # measured on MI355X (profiles/round1_c5_precision_sweep.json): fp64 7e-12, fp32 tables
     # 3e-8, fp32 evaluation 2e-6, all-fp32 2e-6 -- every mode is inside the 1e-4 bar here
     assert errs["fp32_tables"] < 1e-6
