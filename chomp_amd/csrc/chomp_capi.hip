@@ -738,6 +738,18 @@ static int launch_halo_knots(chomp_ctx* ctx, const HaloPlan& P) {
                      ctx->d_pending, ctx->d_npend, ctx->d_epochs, P.fam, ctx->d_status,             \
                      ctx->d_deepw, ctx->tune[CHOMP_TUNE_DEEP_LITERAL] > 0 ? 1 : 0, ctx->d_deepstat,     \
                      ctx->d_nodes)
+  if (shf > 64 * 1024) {            // (more than 64 KiB of dynamic LDS: opt in, once)
+    static bool lds_set = false;
+    if (!lds_set) {
+      HIPCHK(hipFuncSetAttribute(
+          reinterpret_cast<const void*>(&k_halo_knots_fast<kDeepCoarse, kDeepThreadsFew>),
+          hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+      HIPCHK(hipFuncSetAttribute(
+          reinterpret_cast<const void*>(&k_halo_knots_fast<kDeepCoarse, kDeepThreads>),
+          hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+      lds_set = true;
+    }
+  }
   if ((size_t)L.NK * n * ng <= 768) CHOMP_KNOTS_FAST(kDeepThreadsFew);
   else CHOMP_KNOTS_FAST(kDeepThreads);
 #undef CHOMP_KNOTS_FAST

@@ -717,12 +717,22 @@ __device__ __forceinline__ void halo_eval_coded(int group, const HaloCtx& c, dou
   *code = st;
 }
 
+// Rows 0..top of CHOMP_ROMBERG_C into LDS ((top + 1) * 32 doubles; all threads; a barrier must
+// follow before RombergRows2::ctab is used).
+__device__ __forceinline__ void romberg_weights_to_lds(double* dst, int top) {
+  const double* src = &CHOMP_ROMBERG_C[0][0];
+  for (int i = threadIdx.x; i < (top + 1) * 32; i += blockDim.x) dst[i] = src[i];
+}
+
 // scipy.integrate.romberg's rows and stopping test on level sums (the replay of
 // chomp_romberg.h): every lane of every wavefront holds the same state.
 struct RombergRows2 {
   double ordsum[2], Tl[2], prev[2], value[2], range, n, tol, rtol;
   int level[2];
   bool done[2];
+  // CHOMP_ROMBERG_C's rows in LDS (romberg_weights_to_lds), or nullptr: read from the constant
+  // table -- a dependent global read per row, ~1 us each on a CU that has not seen the line
+  const double* ctab = nullptr;
   __device__ __forceinline__ void start(double range_, double tol_, double rtol_, double s0,
                                         double s1, bool want0, bool want1) {
     range = range_; tol = tol_; rtol = rtol_; n = 1.0;
@@ -743,7 +753,7 @@ struct RombergRows2 {
   // level i with the sums of its new nodes
   __device__ __forceinline__ void advance(int i, double s0, double s1) {
     const int lane = threadIdx.x & 63;
-    const double c_il = CHOMP_ROMBERG_C[i][lane & 31];
+    const double c_il = ctab != nullptr ? ctab[i * 32 + (lane & 31)] : CHOMP_ROMBERG_C[i][lane & 31];
     n *= 2.0;
     const double s[2] = {s0, s1};
 #pragma unroll
@@ -812,7 +822,7 @@ template <int LC>
 inline size_t deep_fast_lds(int NM) {
   constexpr int NC = 1 << LC;
   const size_t deep = (size_t)(NM + 8 * (NM - 1) + kDeepScratch + 2 * (NC + 1) +
-                               kDeepWLevels * kDeepWStride) *
+                               kDeepWLevels * kDeepWStride + (kMaxDivmax + 1) * 32) *
                           sizeof(double) + (size_t)((NC + 1 + 15) & ~15);
   return deep;                     // (> finalize_lds_doubles(NK) for any NK <= 512 at LC >= 11)
 }
@@ -899,13 +909,16 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
       int nlev = cfg.divmax - LC;
       nlev = nlev < 0 ? 0 : (nlev > kDeepWLevels ? kDeepWLevels : nlev);
       copy_doubles(w_all, deepw, nlev * kDeepWStride);
+      romberg_weights_to_lds(w_all + kDeepWLevels * kDeepWStride, cfg.divmax);   // (the rows' weights)
     }
     H.stage(L, E, S, epochs, e, t, profile, hod, sici_g, sm);
     double* red = H.rest;
     double* F0 = red + kDeepScratch;
     double* F1 = F0 + (NC + 1);
     double* W = F1 + (NC + 1);                             // [divmax - LC][kDeepWStride]
-    unsigned char* code = reinterpret_cast<unsigned char*>(W + kDeepWLevels * kDeepWStride);
+    const double* Ctab = W + kDeepWLevels * kDeepWStride;  // [divmax + 1][32]
+    unsigned char* code = reinterpret_cast<unsigned char*>(W + kDeepWLevels * kDeepWStride +
+                                                           (kMaxDivmax + 1) * 32);
     const double a = group_lower(E, group), b = log(E.nu_max);
     HaloCtx c{&E, &S, H.nu_knots, H.lnm_pp, L.NM,
               linspace_at(log(cfg.k_min), log(cfg.k_max), NK, ik), (mask & kMaskExclusion) != 0};
@@ -915,6 +928,7 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
     bool literal = force_literal != 0 || cfg.divmax <= LC;
     int flip = 0;
     RombergRows2 R;
+    R.ctab = Ctab;
     if (!literal) {
       // ---- coarse samples: from the (epoch, group) node table when it reaches level LC (what
       // does not depend on k is already there -- the lower levels are the very nodes

@@ -928,6 +928,9 @@ __global__ __launch_bounds__(256) void k_wtheta_fast(chomp_config cfg, ProjLayou
                                                      const double* __restrict__ mom, int LT,
                                                      int nseg) {
   __shared__ double level_sum[2][4];
+  __shared__ double ctab[(kWthetaTabLevel + 1) * 32];   // the rows' weights (RombergRows2::ctab)
+  romberg_weights_to_lds(ctab, LT);
+  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const double a = log(k_min), b = log(k_max);
   const double lo = pd->ln_kt_min, hi = pd->ln_kt_max;
@@ -942,6 +945,7 @@ __global__ __launch_bounds__(256) void k_wtheta_fast(chomp_config cfg, ProjLayou
   const double X = lo + dxK * (double)lane;              // knot i (= hi for lane NP, up to rounding)
   const KernelView K{pp, L.NKT, lo, hi};
   RombergRows2 R;
+  R.ctab = ctab;
   R.start(b - a, cfg.global_precision, cfg.corr_precision,
           0.5 * (nodes[0] * K(a + s) + nodes[1] * K(b + s)), 0.0, true, false);
   const WthSeg G(nseg, a, b);

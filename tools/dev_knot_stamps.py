@@ -30,6 +30,9 @@ def build():
     rep("            // ---- self-check: the same machinery one level up.", "            KSTAMP(4);\n            // ---- self-check: the same machinery one level up.")
     rep("      if (!literal) {\n        // ---- deeper levels, kDeepRound at a time",
         "      KSTAMP(5);\n      if (!literal) {\n        if (first_item && tid == 0 && blockIdx.x < %d) g_ks[blockIdx.x * %d + 22] = n_fine_sh;\n        // ---- deeper levels, kDeepRound at a time" % (NB, NS))
+    rep("          // the break-point intervals: level lv0 + g has n0 << g nodes in each\n", "          if (lv0 == LC + 1) KSTAMP(10);\n          // the break-point intervals: level lv0 + g has n0 << g nodes in each\n")
+    rep("          // one exchange for the 2 ng sums\n", "          if (lv0 == LC + 1) KSTAMP(11);\n          // one exchange for the 2 ng sums\n")
+    rep("            flip ^= 1;\n          }\n#pragma unroll\n          for (int g = 0; g < kDeepRound; ++g)\n            if (g < ng && !R.all_done()) R.advance(lv0 + g, s0[g], s1[g]);", "            flip ^= 1;\n          }\n          if (lv0 == LC + 1) KSTAMP(12);\n#pragma unroll\n          for (int g = 0; g < kDeepRound; ++g)\n            if (g < ng && !R.all_done()) R.advance(lv0 + g, s0[g], s1[g]);")
     rep("            if (g < ng && !R.all_done()) R.advance(lv0 + g, s0[g], s1[g]);\n        }\n",
         "            if (g < ng && !R.all_done()) R.advance(lv0 + g, s0[g], s1[g]);\n          KSTAMP(5 + (lv0 - LC - 1) / kDeepRound + 1);\n        }\n")
     rep("    arrive(e, false);\n  }   // next item", "    KSTAMP(16);\n    if (first_item && tid == 0 && blockIdx.x < %d) g_ks[blockIdx.x * %d + 23] = lev[0] > lev[1] ? lev[0] : lev[1];\n    arrive(e, false);\n    KSTAMP(17);\n  }   // next item" % (NB, NS))
@@ -78,6 +81,11 @@ def run():
             if ok.sum():
                 d = (a[ok, 5 + lv] - a[ok, 4 + lv]) / T
                 print("  round %2d         n %4d  mean %6.2f  max %6.2f us   (nf mean %.1f)" % (lv, ok.sum(), d.mean(), d.max(), a[ok, 22].mean()))
+        ok = (a[:, 10] > 0) & (a[:, 12] > 0) & (a[:, 6] > 0)
+        if ok.sum():
+            print("  inside round 1: stencil pass %.2f  node-by-node %.2f  exchange %.2f  rows %.2f us (mean)" % (
+                ((a[ok, 10] - a[ok, 5]) / T).mean(), ((a[ok, 11] - a[ok, 10]) / T).mean(),
+                ((a[ok, 12] - a[ok, 11]) / T).mean(), ((a[ok, 6] - a[ok, 12]) / T).mean()))
         ok = a[:, 16] > 0
         tot = (a[ok, 16] - a[ok, 0]) / T
         print("  whole knot       n %4d  mean %6.2f  max %6.2f us;  arrive %5.2f us" % (ok.sum(), tot.mean(), tot.max(), ((a[ok, 17] - a[ok, 16]) / T).mean()))
