@@ -330,15 +330,23 @@ __global__ __launch_bounds__(256) void k_sigma_nodes(chomp_config cfg,
     double Tl = lane == 0 ? result : 0.0;
     int conv = 0;
     const int top = cfg.divmax < kSigmaLevel ? cfg.divmax : kSigmaLevel;
-    for (int i = 1; tab8 && i <= top && !conv; ++i) {
-      nn *= 2.0;
-      ordsum += S[i];
-      const double Ti = range * ordsum / nn;
-      if (lane == i) Tl = Ti;
-      result = wave_sum(lane < 32 ? CHOMP_ROMBERG_C[i][lane & 31] * Tl : 0.0);
-      const double err = fabs(result - prev);
-      prev = result;
-      if (err < cfg.global_precision || err < cfg.cosmo_precision * fabs(result)) conv = 1;
+    // (the rows' weights first, all reads in flight: one dependent read of the constant table
+    //  per row costs this tail ~1 us each)
+    double crow[kSigmaLevel + 1];
+#pragma unroll
+    for (int i = 1; i <= kSigmaLevel; ++i) crow[i] = CHOMP_ROMBERG_C[i][lane & 31];
+#pragma unroll
+    for (int i = 1; i <= kSigmaLevel; ++i) {
+      if (tab8 && i <= top && !conv) {
+        nn *= 2.0;
+        ordsum += S[i];
+        const double Ti = range * ordsum / nn;
+        if (lane == i) Tl = Ti;
+        result = wave_sum(lane < 32 ? crow[i] * Tl : 0.0);
+        const double err = fabs(result - prev);
+        prev = result;
+        if (err < cfg.global_precision || err < cfg.cosmo_precision * fabs(result)) conv = 1;
+      }
     }
     // (divmax below the table's level: scipy returns the last row, unconverged)
     if (tab8 && !conv && cfg.divmax <= kSigmaLevel) conv = 1;

@@ -1545,6 +1545,7 @@ __global__ __launch_bounds__(kCellDeepThreads) void k_cell_deep(
     R.load(state + (size_t)il * kRombergDump, split, b - a, cfg.global_precision,
            cfg.corr_precision);
     for (int lv = split + 1; lv <= cfg.divmax && !R.done; ++lv) {
+      const double c_il = CHOMP_ROMBERG_C[lv][threadIdx.x & 31];   // (in flight behind the nodes)
       const long numtosum = 1L << (lv - 1);
       const double h = (b - a) / (double)numtosum, lox = a + 0.5 * h;
       double part = 0.0;
@@ -1569,7 +1570,7 @@ __global__ __launch_bounds__(kCellDeepThreads) void k_cell_deep(
           v[0] = cell_node_general<HF, BAO>(f, lox + h * (double)j, lv, j);
         part += v[0];
       }
-      R.advance(lv, group_sum<NW>(part, red, flip));
+      R.advance(lv, group_sum<NW>(part, red, flip), c_il);
     }
     if (threadIdx.x == 0) out[il] = R.value;
   }

@@ -166,9 +166,10 @@ struct RombergResume {
     n = (double)(1L << level_);
     done = false;
   }
-  __device__ __forceinline__ void advance(int i, double S) {
+  // c_il: CHOMP_ROMBERG_C[i][lane & 31], read by the caller BEFORE the level's nodes (a
+  // dependent read here would add its latency to every level)
+  __device__ __forceinline__ void advance(int i, double S, double c_il) {
     const int lane = threadIdx.x & 63;
-    const double c_il = CHOMP_ROMBERG_C[i][lane & 31];
     n *= 2.0;
     ordsum += S;
     const double Ti = range * ordsum / n;
