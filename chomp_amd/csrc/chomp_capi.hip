@@ -684,12 +684,16 @@ static int halo_prepare(chomp_ctx* ctx, const chomp_halo_par* profile, const cho
 static int launch_nu_mass(chomp_ctx* ctx, int mf_kind, const HaloPlan* plan) {
   const size_t n = ctx->n_epoch;
   const TabLayout& L = ctx->L;
-  if (ctx->with_bao)
-    hipLaunchKernelGGL(k_nu_table<true>, dim3(L.NM, (unsigned)n), dim3(64), 0, ctx->stream, ctx->cfg,
-                       L, ctx->d_epochs, ctx->d_search, ctx->d_snodes, ctx->d_tab, ctx->d_status);
-  else
-    hipLaunchKernelGGL(k_nu_table<false>, dim3(L.NM, (unsigned)n), dim3(64), 0, ctx->stream, ctx->cfg,
-                       L, ctx->d_epochs, ctx->d_search, ctx->d_snodes, ctx->d_tab, ctx->d_status);
+#define CHOMP_NU_TABLE(BAO, NW)                                                                 \
+  hipLaunchKernelGGL((k_nu_table<BAO, NW>), dim3(L.NM, (unsigned)n), dim3(64 * NW), 0, ctx->stream, \
+                     ctx->cfg, L, ctx->d_epochs, ctx->d_search, ctx->d_snodes, ctx->d_tab,       \
+                     ctx->d_status)
+  if ((size_t)L.NM * n <= 512) {      // (fewer integrals than SIMDs to put them on)
+    if (ctx->with_bao) CHOMP_NU_TABLE(true, 4); else CHOMP_NU_TABLE(false, 4);
+  } else {
+    if (ctx->with_bao) CHOMP_NU_TABLE(true, 1); else CHOMP_NU_TABLE(false, 1);
+  }
+#undef CHOMP_NU_TABLE
   const size_t sh = (size_t)mass_lds_doubles(L.NM) * sizeof(double);
   const int ng = plan && plan->ng > 0 ? plan->ng : 1;
   // (node-table chunks: as many blocks per (epoch, group) as keep the launch under ~2 blocks

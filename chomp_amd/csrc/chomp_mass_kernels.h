@@ -983,17 +983,20 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_probe(
 }
 
 // ---------------------------------------------------------------------------
-// k_nu_table: grid (NM, n_epoch), block 64: one wavefront per sigma(R) Romberg of the nu
-// table, nu_i = nu_m(exp(ln_mass_i)) (mass_function.py:205-210).
+// k_nu_table: grid (NM, n_epoch), block 64 NW: one sigma(R) Romberg of the nu table per block,
+// nu_i = nu_m(exp(ln_mass_i)) (mass_function.py:205-210).  NW = 1 (one wavefront per integral:
+// most integrals in flight) for a batch of epochs; NW = 4 when the whole launch is a few dozen
+// integrals (one epoch) and lasts as long as one of them.
 // ---------------------------------------------------------------------------
-template <bool BAO>
-__global__ __launch_bounds__(64) void k_nu_table(chomp_config cfg, TabLayout L,
-                                                 const Epoch* __restrict__ epochs,
-                                                 const double* __restrict__ search,
-                                                 const double* __restrict__ snodes,
-                                                 double* __restrict__ tab,
-                                                 unsigned* __restrict__ status) {
+template <bool BAO, int NW>
+__global__ __launch_bounds__(64 * NW) void k_nu_table(chomp_config cfg, TabLayout L,
+                                                      const Epoch* __restrict__ epochs,
+                                                      const double* __restrict__ search,
+                                                      const double* __restrict__ snodes,
+                                                      double* __restrict__ tab,
+                                                      unsigned* __restrict__ status) {
   __shared__ Epoch E;
+  __shared__ double red[romberg_scratch<NW, 1>()];
   const int i = blockIdx.x, e = blockIdx.y;
   copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
                kEpochDoubles);
@@ -1002,8 +1005,8 @@ __global__ __launch_bounds__(64) void k_nu_table(chomp_config cfg, TabLayout L,
   const double ln_lo = search[(e * 2 + 0) * 2], ln_hi = search[(e * 2 + 1) * 2];
   const double lnm = linspace_at(ln_lo, ln_hi, L.NM, i);
   bool conv = true;
-  const double nu = nu_of_mass_block<1, 1, BAO>(E, snode, exp(lnm), cfg, cfg.cosmo_precision,
-                                                nullptr, &conv);
+  const double nu = nu_of_mass_block<NW, 1, BAO>(E, snode, exp(lnm), cfg, cfg.cosmo_precision,
+                                                 red, &conv);
   if (threadIdx.x == 0) {
     double* t = tab + (size_t)e * L.stride;
     t[L.off_ln_mass + i] = lnm;
