@@ -483,7 +483,11 @@ __device__ __forceinline__ int group_fb(int group) {
 // Si/Ci tables: everything else it needs is in the (epoch, group) node table.
 // With want_nbar the extra x-block of z == 0 does the epoch's n_bar integral
 // (halo.py:674-700) beside the knots.
+// KNW = 4 (a whole block per knot pair, grid x = NK [+ 1]): for a set-up of one or a few epochs,
+// whose launch lasts as long as its slowest knot -- 1, 1, 2, 4, 8 NFW transforms per lane at
+// levels 6..10 on one wavefront, 1, 1, 1, 1, 2 on four.
 // ---------------------------------------------------------------------------
+template <int KNW>
 __global__ __launch_bounds__(256) void k_halo_knots(
     chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs, double* __restrict__ tab,
     const chomp_halo_par* __restrict__ profile, const HodDev* __restrict__ hod,
@@ -495,7 +499,7 @@ __global__ __launch_bounds__(256) void k_halo_knots(
   __shared__ Epoch E;              // (the n_bar block only)
   const int NK = L.NK;
   const int e = blockIdx.y;
-  const int kb = (NK + 3) / 4;     // knot blocks
+  const int kb = KNW == 1 ? (NK + 3) / 4 : NK;     // knot blocks
   if ((int)blockIdx.x >= kb) {     // ---- n_bar
     if (!want_nbar || blockIdx.z != 0) return;
     HaloLds H;
@@ -512,8 +516,8 @@ __global__ __launch_bounds__(256) void k_halo_knots(
   copy_doubles(reinterpret_cast<double*>(&S), reinterpret_cast<const double*>(sici_g),
                (int)(sizeof(SiCiTab) / sizeof(double)));
   __syncthreads();
-  const int ik = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
-  if (ik >= NK) return;            // (no barrier below: the wavefronts are independent)
+  const int ik = KNW == 1 ? (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6) : (int)blockIdx.x;
+  if (ik >= NK) return;            // (KNW = 1: no barrier below, the wavefronts are independent)
   const double* node = nodes + ((size_t)e * 3 + group) * kNodeStride;
   const double a = node[kNodeFields * kNodeCount], b = node[kNodeFields * kNodeCount + 1];
   const double* ep = endp + ((size_t)e * 3 + group) * 2 * NK + 2 * ik;
@@ -523,11 +527,16 @@ __global__ __launch_bounds__(256) void k_halo_knots(
   NodeIntegrand f{&S, node, ln_k, (mask & kMaskExclusion) != 0};
   const int dmax = cfg.divmax < kNodeLevel ? cfg.divmax : kNodeLevel;
   RombergOut<2> r;
-  if (dmax >= 6)
-    r = romberg_wave6<2>(f, a, b, fb, cfg.global_precision, cfg.halo_precision, dmax);
-  else
-    r = romberg_group<1, 2>(f, a, b, cfg.global_precision, cfg.halo_precision, dmax, nullptr);
-  if ((threadIdx.x & 63) == 0) {
+  if constexpr (KNW == 1) {
+    if (dmax >= 6)
+      r = romberg_wave6<2>(f, a, b, fb, cfg.global_precision, cfg.halo_precision, dmax);
+    else
+      r = romberg_group<1, 2>(f, a, b, cfg.global_precision, cfg.halo_precision, dmax, nullptr);
+  } else {
+    (void)fb;
+    r = romberg_group<KNW, 2>(f, a, b, cfg.global_precision, cfg.halo_precision, dmax, sm);
+  }
+  if ((KNW == 1 ? (threadIdx.x & 63) : threadIdx.x) == 0) {
     double* lev = t + L.off_levels;
     const int fa = group_fa(group), fb_ = group_fb(group);
     const bool more = cfg.divmax > kNodeLevel;
