@@ -173,8 +173,13 @@ struct PowerEval {
       const double d = lk - (x0 + dx * (double)i);
       return pmm * pp_poly(ca, i, d) * pp_poly(cb, i, d) + pp_poly(cp, i, d);
     }
-    if (w == CHOMP_P_LIN || !in || (extrap && !(kv < k_max)))
-      return eval_t<BAO>(kv);                             // the rarely taken branches
+    if (w == CHOMP_P_LIN || !in || (extrap && !(kv < k_max))) {
+      // the rarely taken branches (eval_t's, without the HaloFit formula this instance never uses)
+      if (w == CHOMP_P_LIN) return linear_power_t<BAO>(*E, kv);
+      if (kv < k_min) return linear_power_t<BAO>(*E, kv) * c_lo;
+      if (extrap && kv >= k_max) return power_tail<BAO>(*E, tail, w, kv, k_max);
+      return 0.0;                                         // k > k_max (or NaN)
+    }
     int i = (int)floor((lk - x0) * inv_dx);
     i = i < 0 ? 0 : (i > NK - 2 ? NK - 2 : i);
     const double d = lk - (x0 + dx * (double)i);

@@ -1377,7 +1377,9 @@ __global__ __launch_bounds__(256) void k_cell_ptab(chomp_config cfg, TabLayout H
 }
 
 // correlation.py:387-392 from the node table (levels <= LT), directly beyond
-template <bool HF, bool BAO>
+// DIRECT = false: the caller never asks for a level beyond the node table (k_cell below its
+// hand-over level): the node-by-node route -- windows, growth, ~100 registers -- is not compiled.
+template <bool HF, bool BAO, bool DIRECT = true>
 struct CellTabIntegrand {
   const PowerEval* P;
   const double* nodes;
@@ -1420,8 +1422,10 @@ struct CellTabIntegrand {
       if (ptab != nullptr) p = from_table(lk, &ok);
       if (!ok) p = P->template at_ln<HF, BAO>(lk, ell / nodes[2 * N + idx]);
       out[0] = p * nodes[idx];
-    } else {
+    } else if constexpr (DIRECT) {
       out[0] = direct(chi);
+    } else {
+      out[0] = 0.0;
     }
   }
   // The same value for a node of the table that from_table answers, as straight-line code
@@ -1444,8 +1448,9 @@ struct CellTabIntegrand {
 //  reads of tables another kernel wrote -- a microsecond a piece on a CU whose L2 has not seen
 //  them -- and set the launch's duration: 65 us measured against 9 us for a level-8 block.)
 constexpr int kCellSplitLevel = 11;
-template <bool HF, bool BAO>
-__global__ __launch_bounds__(256) void k_cell(chomp_config cfg, TabLayout HL, ProjLayout L,
+template <bool HF, bool BAO, bool DIRECT>
+// (three blocks per CU for the lean instance: 168 registers, one fewer than it would take)
+__global__ __launch_bounds__(256, DIRECT ? 2 : 3) void k_cell(chomp_config cfg, TabLayout HL, ProjLayout L,
                                               const Epoch* __restrict__ epochs, int e,
                                               const double* __restrict__ htab, int which,
                                               const ProjDev* __restrict__ pdg,
@@ -1472,10 +1477,10 @@ __global__ __launch_bounds__(256) void k_cell(chomp_config cfg, TabLayout HL, Pr
   P.template finish_t<BAO>();
   const double l = ell[blockIdx.x];
   const double px0 = log(cfg.k_min), pdx = (log(cfg.k_max) - px0) / (double)kPTabN;
-  CellTabIntegrand<HF, BAO> f{&P, nodes, (1L << LT) + 1, LT, l, log(l), pk_tab, px0, pdx, 1.0 / pdx,
-                              {&P, &G, l, 1.0 / (D_z * D_z)}};
+  CellTabIntegrand<HF, BAO, DIRECT> f{&P, nodes, (1L << LT) + 1, LT, l, log(l), pk_tab, px0, pdx,
+                                      1.0 / pdx, {&P, &G, l, 1.0 / (D_z * D_z)}};
   const bool hand_over = split < cfg.divmax;
-  const RombergOut<1> r = romberg_group<4, 1, CellTabIntegrand<HF, BAO>, 4>(
+  const RombergOut<1> r = romberg_group<4, 1, CellTabIntegrand<HF, BAO, DIRECT>, 4>(
       f, pd.chi_min, pd.chi_max, cfg.global_precision, cfg.corr_precision, split, red,
       hand_over ? state + (size_t)blockIdx.x * kRombergDump : nullptr);
   if (threadIdx.x == 0) {
