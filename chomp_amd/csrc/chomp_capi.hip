@@ -718,15 +718,19 @@ static int launch_halo_knots(chomp_ctx* ctx, const HaloPlan& P) {
   const int ng = P.ng > 0 ? P.ng : 1;
   // (a block per knot pair when the whole launch is a few hundred knots: one or a few epochs)
   const bool wide = (size_t)L.NK * n * ng <= 512;
-  const unsigned kb = wide ? (unsigned)L.NK : (unsigned)((L.NK + 3) / 4);
+  // (... single-wavefront blocks when the knots outnumber the chip's wavefront slots about twice:
+  //  a finished knot then frees its slot at once -- C3 89 -> 78 us; below that, four knots to a
+  //  256-thread block, whose n_bar block also keeps its four wavefronts -- C2 37 vs 39 us)
+  const bool lone = !wide && (size_t)L.NK * n * ng > 4096;
+  const unsigned kb = (wide || lone) ? (unsigned)L.NK : (unsigned)((L.NK + 3) / 4);
   const size_t shk = (size_t)(L.NM + 8 * (L.NM - 1) + kKnotScratch) * sizeof(double);
 #define CHOMP_KNOTS(KNW)                                                                          \
   hipLaunchKernelGGL((k_halo_knots<KNW>), dim3(kb + (P.want_nbar ? 1u : 0u), (unsigned)n, (unsigned)ng), \
-                     dim3(256), shk, ctx->stream, ctx->cfg, L, ctx->d_epochs, ctx->d_tab,        \
+                     dim3(KNW == 0 ? 64 : 256), shk, ctx->stream, ctx->cfg, L, ctx->d_epochs, ctx->d_tab,        \
                      ctx->d_profile, ctx->d_hod, ctx->d_sici, ctx->d_nodes, ctx->d_endp,          \
                      P.groups[0], P.groups[1], P.groups[2], P.kmask, P.want_nbar, ctx->d_pending, \
                      ctx->d_npend, ctx->d_status)
-  if (wide) CHOMP_KNOTS(4); else CHOMP_KNOTS(1);
+  if (wide) CHOMP_KNOTS(4); else if (lone) CHOMP_KNOTS(0); else CHOMP_KNOTS(1);
 #undef CHOMP_KNOTS
   // blocks 0..n-1 take the epochs' tokens; with integrands that can run beyond the node
   // tables (the HOD ones) enough further blocks to fill the chip draw from the list

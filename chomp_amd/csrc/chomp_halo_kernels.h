@@ -487,8 +487,10 @@ __device__ __forceinline__ int group_fb(int group) {
 // whose launch lasts as long as its slowest knot -- 1, 1, 2, 4, 8 NFW transforms per lane at
 // levels 6..10 on one wavefront, 1, 1, 1, 1, 2 on four.
 // ---------------------------------------------------------------------------
+// KNW = 0: one wavefront per knot pair AND per block (64 threads): a finished knot frees its
+// slot for the next block at once, instead of idling beside the one slow knot of its four.
 template <int KNW>
-__global__ __launch_bounds__(256) void k_halo_knots(
+__global__ __launch_bounds__(KNW == 0 ? 64 : 256) void k_halo_knots(
     chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs, double* __restrict__ tab,
     const chomp_halo_par* __restrict__ profile, const HodDev* __restrict__ hod,
     const SiCiTab* __restrict__ sici_g, const double* __restrict__ nodes,
@@ -506,8 +508,9 @@ __global__ __launch_bounds__(256) void k_halo_knots(
     H.stage(L, E, S, epochs, e, tab + (size_t)e * L.stride, profile, hod, sici_g, sm);
     HaloCtx c{&E, &S, H.nu_knots, H.lnm_pp, L.NM, 0.0, false};
     IntegrandNbar f{c};
-    const double v = romberg1<4>(f, E.ln_nu_lo_first, log(E.nu_max), cfg.global_precision,
-                                 cfg.halo_precision, cfg.divmax, H.rest);
+    const double v = romberg1<(KNW == 0 ? 1 : 4)>(f, E.ln_nu_lo_first, log(E.nu_max),
+                                                  cfg.global_precision, cfg.halo_precision,
+                                                  cfg.divmax, H.rest);
     if (threadIdx.x == 0) tab[(size_t)e * L.stride + L.off_misc] = v;
     return;
   }
@@ -527,7 +530,7 @@ __global__ __launch_bounds__(256) void k_halo_knots(
   NodeIntegrand f{&S, node, ln_k, (mask & kMaskExclusion) != 0};
   const int dmax = cfg.divmax < kNodeLevel ? cfg.divmax : kNodeLevel;
   RombergOut<2> r;
-  if constexpr (KNW == 1) {
+  if constexpr (KNW <= 1) {
     if (dmax >= 6)
       r = romberg_wave6<2>(f, a, b, fb, cfg.global_precision, cfg.halo_precision, dmax);
     else
@@ -536,7 +539,7 @@ __global__ __launch_bounds__(256) void k_halo_knots(
     (void)fb;
     r = romberg_group<KNW, 2>(f, a, b, cfg.global_precision, cfg.halo_precision, dmax, sm);
   }
-  if ((KNW == 1 ? (threadIdx.x & 63) : threadIdx.x) == 0) {
+  if ((KNW <= 1 ? (threadIdx.x & 63) : threadIdx.x) == 0) {
     double* lev = t + L.off_levels;
     const int fa = group_fa(group), fb_ = group_fb(group);
     const bool more = cfg.divmax > kNodeLevel;
