@@ -621,3 +621,29 @@ def test_roctx_ranges_switch_on_and_off():
     hg.ctx.set_tuning(_lib.TUNE_ROCTX, 0)
     hg.setup("power_mm")
     assert numpy.array_equal(hg.power("power_mm", k), ref)
+
+
+def test_launch_shapes_by_batch_size_agree():
+    """The set-up kernels pick their block shapes by the size of the batch -- four wavefronts per
+    sigma(R) integral and a block per knot pair for one epoch, one wavefront each for a batch,
+    single-wavefront knot blocks once the knots outnumber the chip's slots (48 epochs x 50 knots
+    x 2 groups) -- and the tables of an epoch do not depend on which batch it came in (to the
+    order of the additions)."""
+    from chomp_amd import grid
+    k = numpy.logspace(-2.5, 1.5, 37)
+    z = numpy.linspace(0.05, 1.2, 48)
+    big = grid.HaloGrid(z)
+    p_big = big.power("power_gm", k)
+    for i in (0, 17, 47):
+        one = grid.HaloGrid(z[i:i + 1])
+        p_one = one.power("power_gm", k)[0]
+        assert numpy.max(numpy.abs(p_one / p_big[i] - 1)) < 1e-12, i
+        for name in ("nu", "pp_gm", "h_g"):
+            a, b = one.ctx.table(name, 0), big.ctx.table(name, i)
+            assert numpy.max(numpy.abs(a - b)) <= 1e-12 * numpy.max(numpy.abs(b)), (i, name)
+        la = one.ctx.table("levels", 0).reshape(5, -1)[[0, 2, 3]]      # h_m, h_g, pp_gm: the built ones
+        lb = big.ctx.table("levels", i).reshape(5, -1)[[0, 2, 3]]
+        assert numpy.array_equal(la, lb), i
+    mid = grid.HaloGrid(z[:8])                   # 8 x 50 x 2 = 800 knots: four-knot blocks
+    p_mid = mid.power("power_gm", k)
+    assert numpy.max(numpy.abs(p_mid / p_big[:8] - 1)) < 1e-12
