@@ -149,6 +149,31 @@ class Dist(object):
         return float(t.item())
 
 
+def rehearsal_gathers():
+    """--rehearse only (every rank on ONE GPU, gloo): device tensors cannot go through gloo, so
+    the two gathers of chomp_amd.grid are replaced by versions staged through host memory.  Same
+    shapes, same re-ordering; a functional check of the N > 1 path, never a measurement."""
+    import torch
+    import torch.distributed as dist
+    from chomp_amd import grid
+
+    def gather_rows_async(local, n_all, world, out=None):
+        rpr = grid.rows_per_rank(n_all, world)
+        assert local.shape[0] == rpr
+        host = torch.empty((world * rpr, local.shape[1]), dtype=local.dtype)
+        dist.all_gather_into_tensor(host, local.cpu().contiguous())
+        return grid.PendingRows(host.to(local.device), None, n_all, world)
+
+    def gather_samples(local, n_all, world):
+        per = local.shape[0]
+        host = torch.empty(world * per, dtype=local.dtype)
+        dist.all_gather_into_tensor(host, local.cpu().contiguous())
+        return host.to(local.device).view(world, per).t().reshape(-1)[:n_all]
+
+    grid.gather_rows_async = gather_rows_async
+    grid.gather_samples = gather_samples
+
+
 def grid_leg(D, which, mf, nz, steps, warmup, stream):
     """`steps` timed steps of the (k, z) grid workload with nz redshift rows in all, dealt
     over the ranks (interleaved).  Steps are software-pipelined for N > 1: the all-gather of
@@ -229,8 +254,8 @@ def projection_leg(D, ggl, steps, warmup):
         w = ctx.wtheta(code, 0, corr._k_lim[0], corr._k_lim[1], corr.D_z, my_theta)
         c = ctx.cell(code, 0, corr.D_z, my_ell)
         if D.world > 1:                      # one all-gather per output array
-            w = grid.gather_samples(w, N_THETA, D.world, via_host=D.args.rehearse)
-            c = grid.gather_samples(c, N_ELL, D.world, via_host=D.args.rehearse)
+            w = grid.gather_samples(w, N_THETA, D.world)
+            c = grid.gather_samples(c, N_ELL, D.world)
         return w, c
 
     import warnings as _w
@@ -269,6 +294,37 @@ def stage_k_roofline(stage_k_seconds, workload):
                     "profiles/round2_stage_k_counters.json" % len(cnt.get("kernels", []))}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU)
+    with torch.distributed.run as CHILDREN of this process -- which never initialises the GPU
+    and is never replaced by another program -- relay rank 0's JSON line and return the
+    launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                      # a free rendezvous port on the loop-back
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get(
+        "HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for text in proc.stdout:
+        if text.startswith("{") and '"metric"' in text:
+            line = text.rstrip("\n")
+        else:
+            sys.stderr.write(text)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks exited cleanly but rank 0 printed no result\n")
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -289,10 +345,17 @@ def main():
                          "gloo all-gather through host memory); the numbers mean nothing")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher.  It has not
+        # imported torch.cuda or touched HIP in any way and never will.
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node N"
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (run `python bench.py --gpus N` or "
+                 "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`)"
+                 % (args.gpus, world))
     proj = args.workload in ("c4", "c5")
     which = "power_mm" if args.workload == "c2" else "power_gm"
     mf = "st" if args.workload == "c2" else "tinker"
@@ -329,7 +392,13 @@ def main():
     # image serialises against the whole device (+0.1 ms per step, measured).
     stream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)
-    job = {"rccl_world_size": dist.get_world_size() if world > 1 else 1, "backend": backend or "none"}
+    # rccl_world_size: ranks that talk RCCL (1 without a process group; None when the group is
+    # the gloo rehearsal, which proves nothing about RCCL)
+    job = {"rccl_world_size": (1 if world == 1 else dist.get_world_size() if backend == "nccl"
+                               else None),
+           "world_size": world, "backend": backend or "none"}
+    if args.rehearse and world > 1:
+        rehearsal_gathers()
 
     def finish(res):
         if rank == 0:

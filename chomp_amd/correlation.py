@@ -220,7 +220,7 @@ class Correlation3d(Correlation):
     def _prepare(self):
         code, need = _POWER[self._power_name]
         if isinstance(self.halo, halo_mod.HaloFit) and code != _lib.P_LIN:
-            self.halo._ensure_halofit(defer_status=defer_status)
+            self.halo._ensure_halofit()     # (xi(r) returns to the host: nothing to defer)
             code |= _lib.P_HALOFIT
             if (code & 15) == _lib.P_MM:
                 need = 0

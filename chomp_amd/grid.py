@@ -165,20 +165,13 @@ class PendingRows(object):
 def gather_rows_async(local, n_all, world, out=None):
     """Launch the all-gather of the per-rank row blocks ([rows_per_rank, nk], zero
     padded) into `out` (allocated if None).  RCCL on GPUs ("nccl" backend), gloo on CPU
-    tensors (multi-process CPU tests); CUDA tensors under gloo are staged through host
-    memory (rehearsal only)."""
+    tensors (the multi-process CPU tests)."""
     import torch
     import torch.distributed as dist
     if world == 1:
         return PendingRows(local, None, n_all, world)
     rpr = rows_per_rank(n_all, world)
     assert local.shape[0] == rpr
-    if local.is_cuda and dist.get_backend() == "gloo":
-        # rehearsal of the N > 1 path on a box with fewer GPUs than ranks
-        # (bench.py --rehearse): the same gather, staged through host memory
-        host = torch.empty((world * rpr, local.shape[1]), dtype=local.dtype)
-        dist.all_gather_into_tensor(host, local.cpu().contiguous())
-        return PendingRows(host.to(local.device), None, n_all, world)
     full = out if out is not None else torch.empty((world * rpr, local.shape[1]),
                                                    dtype=local.dtype, device=local.device)
     work = dist.all_gather_into_tensor(full, local.contiguous(), async_op=True)
@@ -204,20 +197,14 @@ def shard_samples(x, rank, world):
     return mine.contiguous()
 
 
-def gather_samples(local, n_all, world, via_host=False):
+def gather_samples(local, n_all, world):
     """All-gather the per-rank results of shard_samples and undo the interleaving: the n_all
-    values in the caller's sample order on every rank.  via_host: stage through host memory
-    (gloo with device tensors: the one-GPU rehearsal)."""
+    values in the caller's sample order on every rank."""
     import torch
     import torch.distributed as dist
     if world == 1:
         return local[:n_all]
     per = local.shape[0]
-    if via_host:
-        host = torch.empty(world * per, dtype=local.dtype)
-        dist.all_gather_into_tensor(host, local.cpu().contiguous())
-        full = host.to(local.device)
-    else:
-        full = torch.empty(world * per, dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(full, local.contiguous())
+    full = torch.empty(world * per, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(full, local.contiguous())
     return full.view(world, per).t().reshape(-1)[:n_all]

@@ -320,6 +320,7 @@ class Kernel(object):
         self._own = None
         self._done = {}
         self._info = None
+        self._info_sig = None
         self._info_ctx = None
         self._z_bar_override = None
 
@@ -350,10 +351,17 @@ class Kernel(object):
         return self._setup_on(self._own)
 
     def _get(self, name):
-        if self._info is None and self._info_ctx is None:
-            self._dev()
+        """Host scalars of the projection set-up (z_bar, chi limits, D(z_bar), ...), read back
+        once per set-up.  A read-back made for other windows / another cosmology is dropped:
+        set_cosmology re-runs _find_z_bar and the growth factor in the reference
+        (kernel.py:657-676), so must every scalar served from here."""
+        sig = self._signature()
+        if self._info is not None and self._info_sig != sig:
+            self._info = None
         if self._info is None:
-            self._info = self._setup_on(self._info_ctx).kernel_info()
+            ctx = self._info_ctx if self._info_ctx is not None else self._dev()
+            self._info = self._setup_on(ctx).kernel_info()
+            self._info_sig = sig
         return float(self._info[name])
 
     chi_min = property(lambda self: self._get("chi_min"))
@@ -376,9 +384,12 @@ class Kernel(object):
         return self.cosmo.get_cosmology()
 
     def set_cosmology(self, cosmo_dict):
+        """kernel.py:657-676: new MultiEpoch tables, windows, chi limits, and _find_z_bar again
+        (which also replaces a z_bar assigned through Correlation.set_redshift)."""
         self.cosmo.set_cosmology(cosmo_dict)
         self.window_function_a.set_cosmology_object(self.cosmo)
         self.window_function_b.set_cosmology_object(self.cosmo)
+        self._z_bar_override = None
 
     def write(self, output_file_name):
         """kernel.py:765-781."""

@@ -176,3 +176,26 @@ def test_halo_grid_power_all_end_to_end(world, n_all):
         p.join(120)
         assert p.exitcode == 0
     assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` in the driver's command form (no launcher): the parent starts N
+    rank processes itself and passes their exit code on.  Without a GPU the ranks stop at their
+    "needs MI355X" assertion -- which proves that N ranks started, each with its own RANK, and
+    that the launcher neither died on a world-size assertion nor reported success."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU rehearsal of the launcher (on a GPU box bench.py itself is run)")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
+                        "--warmup", "0"], capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert p.stderr.count("bench.py needs MI355X GPUs") >= 2, p.stderr[-2000:]
+    assert "launch with torch.distributed.run" not in p.stderr
+    assert p.stdout.strip() == ""
+    # a WORLD_SIZE that contradicts --gpus is refused with a message, not an assertion
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"],
+                       capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"))
+    assert p.returncode != 0 and "--gpus 2 but WORLD_SIZE=4" in p.stderr

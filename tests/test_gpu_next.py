@@ -75,6 +75,27 @@ def test_correlation3d():
         assert got[g["r_test"] <= 0.1].tolist() == [0.0] * int(numpy.sum(g["r_test"] <= 0.1))
 
 
+def test_correlation3d_with_halofit():
+    """Correlation3d over a HaloFit spectrum (correlation.py:408-510 with halo.py:1236-1412 as
+    input_halo): raw_correlation / compute_correlation / correlation against the oracle."""
+    from chomp_amd import correlation, halo
+    from oracle import chomp_oracle as o
+    e = o.epoch(None, 0.0)
+    t = o.halo_table(e, o.mass_table(e), o.zheng(), families=("mm", "gm"))
+    o.halofit_table(t)
+    r = numpy.logspace(-1, numpy.log10(50.0), 7)
+    for ps, fam in (("power_mm", "mm"), ("power_gm", "gm")):
+        c3 = correlation.Correlation3d(0.1, 50.0, redshift=0.0, input_halo=halo.HaloFit(0.0),
+                                       powSpec=ps)
+        got = c3.raw_correlation(r)
+        ref = o.xi3d_raw(lambda k: o.halofit_power(t, fam, k), r, t.k_min, t.k_max)
+        scale = numpy.max(numpy.abs(ref))
+        assert numpy.max(numpy.abs(got - ref)) < RTOL * scale, ps
+        c3.compute_correlation()
+        assert numpy.all(numpy.isfinite(c3.xi_array)) and c3.xi_array.size == 50
+        assert numpy.shape(c3.correlation(numpy.array([1.0, 10.0]))) == (2,)
+
+
 def test_spline_eval_matches_fitpack():
     from chomp_amd import cosmology
     ctx = cosmology._context()

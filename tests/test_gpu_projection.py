@@ -249,3 +249,42 @@ def test_shortened_routes_at_other_depths(mods, over):
     finally:
         defaults.default_precision.clear()
         defaults.default_precision.update(saved)
+
+
+def test_correlation_set_cosmology_equals_fresh_object(mods):
+    """correlation.py:160-171 -> kernel.py:657-676: set_cosmology rebuilds the MultiEpoch tables
+    and the windows, re-runs _find_z_bar and re-reads the growth factor; the halo moves to the
+    new z_bar.  Every host scalar and w(theta) must equal a freshly constructed object's (an MCMC /
+    SimulationDesign loop over cosmologies goes through exactly this)."""
+    cosmology, kernel, correlation, halo = mods
+    from chomp_amd import defaults
+    c2 = dict(defaults.default_cosmo_dict, omega_m0=0.35 - 8.469e-5, omega_l0=0.65, sigma_8=0.75,
+              h=0.68)
+    theta = numpy.logspace(-2.5, -0.2, 9) * D2R
+
+    def fresh(cd):
+        cm = cosmology.MultiEpoch(0.0, 5.0, cd)
+        wa = kernel.WindowFunctionGalaxy(kernel.dNdzMagLim(0.0, 2.0, 2.0, 0.3, 2.0), cm)
+        wb = kernel.WindowFunctionGalaxy(kernel.dNdzGaussian(0.0, 2.0, 0.8, 0.1), cm)
+        kern = kernel.Kernel(1e-6 * D2R, 100.0 * D2R, wa, wb, cm)
+        h = halo.Halo(0.0, cosmo_single_epoch=cosmology.SingleEpoch(0.0, cd))
+        return correlation.Correlation(0.001, 1.0, kern, input_halo=h, power_spec="power_mm")
+
+    a = fresh(defaults.default_cosmo_dict)
+    w0 = a.correlation(theta)              # (tables and host scalars of the first cosmology read)
+    z0, D0 = a.kernel.z_bar, a.D_z
+    a.set_cosmology(c2)
+    b = fresh(c2)
+    assert (b.kernel.z_bar, b.D_z) != (z0, D0)
+    assert a.kernel.z_bar == b.kernel.z_bar
+    assert a.D_z == b.D_z
+    assert a.kernel.chi_max == b.kernel.chi_max and a.kernel.chi_min == b.kernel.chi_min
+    assert a.halo._redshift == b.halo._redshift == b.kernel.z_bar
+    wa_, wb_ = a.correlation(theta), b.correlation(theta)
+    assert numpy.array_equal(wa_, wb_)
+    assert rel_err(wa_, w0) > 1e-3
+    # a z_bar forced through set_redshift is replaced by _find_z_bar again (kernel.py:676)
+    a.set_redshift(0.5)
+    assert a.kernel.z_bar == 0.5
+    a.set_cosmology(c2)
+    assert a.kernel.z_bar == b.kernel.z_bar
