@@ -42,6 +42,8 @@ NK, NZ, Z_MAX = 4096, 64, 1.5
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 measured copy)
 FP64_VALU_PEAK_TFLOPS = 78.6   # vector fp64: half the 157.3 TFLOP/s fp32 vector peak
 N_THETA, N_ELL = 1024, 2048
+# SQ counter summaries of Stage K (tools/prof.sh sq -> tools/collect_profiles.py), newest first
+STAGE_K_COUNTER_FILES = ("round3_stage_k_counters.json", "round2_stage_k_counters.json")
 
 
 # ---------------------------------------------------------------------------
@@ -208,6 +210,90 @@ def grid_leg(D, which, mf, nz, steps, warmup, stream):
     return elapsed, hg, k, out
 
 
+BATCH_SIZES = (64, 256, 1024)
+COSMO_FIELDS = ("omega_m0", "omega_b0", "omega_l0", "omega_r0", "cmb_temp", "h", "sigma_8",
+                "n_scalar", "w0", "wa")
+
+
+def batch_cosmologies(n, draws, seed):
+    """`draws` parameter sets for n epochs, each a float64 [n, 10] block in chomp_cosmo's field
+    order: WMAP7 with Omega_m and sigma_8 jittered by +-2 % per epoch, flat (Omega_L follows)."""
+    from chomp_amd import defaults
+    base = numpy.array([float(defaults.default_cosmo_dict[f]) for f in COSMO_FIELDS])
+    rng = numpy.random.default_rng(seed)
+    out = []
+    for _ in range(draws):
+        a = numpy.tile(base, (n, 1))
+        om = (base[0] + base[3]) * (1.0 + 0.02 * rng.uniform(-1.0, 1.0, n))
+        a[:, 0] = om - base[3]
+        a[:, 2] = 1.0 - om
+        a[:, 6] = base[6] * (1.0 + 0.02 * rng.uniform(-1.0, 1.0, n))
+        out.append(a)
+    return out
+
+
+def batch_leg(D, n, distinct, steps, warmup, stream, which="power_mm", mf="st"):
+    """SURVEY 8(f) rank 1, the batch-over-parameters axis (simulation_design.py:116-155, the MCMC
+    loop of examples/example_script.py:141-143): n epochs (z = linspace(0, 1.5, n)) x 4096 k per
+    step.  distinct=False: one cosmology for all (configs[1] made longer; the cosmology-only work
+    is shared and no parameter changes between steps).  distinct=True: every epoch its own
+    cosmology AND a fresh draw every step (a pool of 4 pre-packed draws taken in turn, so that
+    every step's block differs from what the device holds: no upload is skipped, the host packs
+    nothing inside the step).  Returns the result dict of one batch_scaling entry."""
+    import torch
+    from chomp_amd import grid
+    z = numpy.linspace(0.0, Z_MAX, n)
+    hg = grid.HaloGrid(z, mass_function=mf, device=D.local, stream=stream.cuda_stream)
+    pool = None
+    if distinct:
+        pool = [hg.ctx.pack_cosmo(a, n) for a in batch_cosmologies(n, 4, 1000 + n)]
+    k = torch.logspace(-3, 2, NK, dtype=torch.float64, device=D.dev)
+    out = torch.empty((n, NK), dtype=torch.float64, device=D.dev)
+    turn = [0]
+
+    def setup():
+        if pool is not None:
+            hg.set_parameters(cosmo=pool[turn[0] % len(pool)])
+            turn[0] += 1
+        hg.setup(which)
+
+    def step():
+        setup()
+        hg.power(which, k, out=out)
+
+    for _ in range(warmup):
+        step()
+    D.fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    D.fence()
+    elapsed = time.perf_counter() - t0
+    assert bool(torch.isfinite(out).all())
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = max(3, steps // 2)
+    ev0.record(stream)
+    for _ in range(reps):
+        setup()
+    ev1.record(stream)
+    torch.cuda.synchronize(D.dev)
+    t_k = ev0.elapsed_time(ev1) / reps * 1e-3
+    status = hg.status()
+    res = {"n_epoch": n, "distinct_cosmologies": bool(distinct),
+           "parameters_change_every_step": bool(distinct),
+           "ms_per_step": 1e3 * elapsed / steps, "samples_per_s": n * NK * steps / elapsed,
+           "us_per_epoch": 1e6 * elapsed / steps / n, "stage_k_ms": t_k * 1e3, "steps": steps,
+           "epochs_flagged": int(numpy.count_nonzero(status))}
+    rk = stage_k_roofline(t_k, "batch_%d_%s" % (n, "distinct" if distinct else "one"))
+    if rk is not None:
+        res["stage_k_frac"] = rk["frac"]
+        res["stage_k_tflops"] = rk["achieved"]
+        res["flop_per_step"] = rk["flop_per_step"]
+    else:
+        res["stage_k_frac"] = None
+    return res
+
+
 def projection_leg(D, ggl, steps, warmup):
     """configs[3] (c4: gal-gal clustering, J0, P_gg) and configs[4] (c5: galaxy-galaxy
     lensing, J2, HaloFit P_gm): a step = the whole projection path -- MultiEpoch chi(z),
@@ -278,10 +364,16 @@ def stage_k_roofline(stage_k_seconds, workload):
     """Stage K against the vector-fp64 peak: FLOP per step from the SQ counters committed
     under profiles/ (rocprofv3 --pmc SQ_INSTS_VALU_*_F64 of the same kernels on the same
     workload; 64 lanes x (2 FMA + ADD + MUL + TRANS) per wavefront instruction)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "round2_stage_k_counters.json")) as fh:
-            cnt = json.load(fh)[workload]
-    except (OSError, ValueError, KeyError):
+    cnt = None
+    for name in STAGE_K_COUNTER_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                cnt = json.load(fh)[workload]
+            counters_file = name
+            break
+        except (OSError, ValueError, KeyError):
+            continue
+    if cnt is None:
         return None
     flop = float(cnt["fp64_flop_per_step"])
     return {"bound": "fp64_valu", "achieved": flop / stage_k_seconds / 1e12,
@@ -290,8 +382,8 @@ def stage_k_roofline(stage_k_seconds, workload):
             "flop_per_step": flop, "stage_k_ms": stage_k_seconds * 1e3,
             "valu_insts_per_step": cnt.get("valu_insts_per_step"),
             "kernels": cnt.get("kernels"),
-            "note": "latency chain of %d dependent launches on 64 epochs; counters: "
-                    "profiles/round2_stage_k_counters.json" % len(cnt.get("kernels", []))}
+            "note": "chain of %d dependent launches; counters: profiles/%s"
+                    % (len(cnt.get("kernels", [])), counters_file)}
 
 
 def launch_ranks(n):
@@ -330,7 +422,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5", "batch"])
+    ap.add_argument("--batch-n", type=int, default=1024,
+                    help="--workload batch: epochs per step")
+    ap.add_argument("--batch-distinct", type=int, default=1,
+                    help="--workload batch: 1 = a cosmology per epoch, redrawn every step; "
+                         "0 = one cosmology")
+    ap.add_argument("--no-batch-scaling", action="store_true")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1, c2 / c3: which split is the headline (the other one is timed "
                          "too and reported beside it)")
@@ -360,7 +458,7 @@ def main():
     which = "power_mm" if args.workload == "c2" else "power_gm"
     mf = "st" if args.workload == "c2" else "tinker"
     baseline = None
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and args.workload != "batch":
         # before the GPU is initialised: the pool forks
         if proj:
             baseline = projection_baseline(args.workload == "c5")
@@ -406,6 +504,20 @@ def main():
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
+
+    # ---- the batch-over-parameters axis as the headline (profiling runs: tools/prof.sh sq)
+    if args.workload == "batch":
+        assert world == 1, "--workload batch is a one-GPU measurement"
+        b = batch_leg(D, args.batch_n, bool(args.batch_distinct), args.steps, args.warmup, stream)
+        return finish({"metric": "halo-model P(k,z) samples/sec (batch over parameters)",
+                       "value": b["samples_per_s"], "unit": "samples/s", "n_gpus": 1,
+                       "steps": args.steps, "warmup": args.warmup, "ms_per_step": b["ms_per_step"],
+                       "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                       "dtype": "f64", "data": "synthetic",
+                       "config": {"workload": "power_mm, %d epochs x %d k, %s" % (
+                           args.batch_n, NK, "a cosmology per epoch, redrawn every step"
+                           if args.batch_distinct else "one cosmology")},
+                       "job": job, "batch": b})
 
     # ---- projection workloads as the headline
     if proj:
@@ -622,6 +734,14 @@ def main():
                            "frac": None,
                            "profile": "profiles/round2_kernel_stats_%s.csv" % name}
         res["other_configs"] = other
+    # ---- the batch-over-parameters axis: where Stage K fills the chip
+    if world == 1 and not args.no_batch_scaling and args.workload == "c2":
+        try:
+            del hg
+        except NameError:
+            pass
+        res["batch_scaling"] = [batch_leg(D, n, distinct, 10 if n < 1024 else 6, 2, stream)
+                                for distinct in (False, True) for n in BATCH_SIZES]
     finish(res)
 
 

@@ -447,6 +447,15 @@ class Context(object):
     # dictionaries per step costs more host time than the kernels take).
     @staticmethod
     def pack_cosmo(cosmo_dicts, n):
+        """One dict (for all n epochs), a list of n dicts, or a float64 array [n, 10] in the
+        field order of chomp_cosmo (omega_m0, omega_b0, omega_l0, omega_r0, cmb_temp, h,
+        sigma_8, n_scalar, w0, wa) -- what a sampler that draws thousands of points per step
+        hands over without building dictionaries."""
+        if isinstance(cosmo_dicts, numpy.ndarray):
+            a = numpy.ascontiguousarray(cosmo_dicts, dtype=numpy.float64)
+            if a.shape != (n, 10):
+                raise ValueError("cosmology array must be [%d, 10], got %r" % (n, a.shape))
+            return (Cosmo * n).from_buffer_copy(a.tobytes())
         if isinstance(cosmo_dicts, dict):
             cosmo_dicts = [cosmo_dicts] * n
         return (Cosmo * n)(*[cosmo_struct(c) for c in cosmo_dicts])

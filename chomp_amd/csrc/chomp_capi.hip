@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/chomp_mi355x.h"
@@ -596,13 +597,29 @@ int chomp_epochs_set(chomp_ctx* ctx, size_t n_epoch, const chomp_cosmo* cosmo,
   if (rc) return rc;
   // cosmology-only work (sigma node table, sigma_8 integral) is shared by the epochs of
   // one cosmology: slot = index of the first epoch with identical parameters
+  // (hashed: a design of a thousand distinct cosmologies must not cost n^2 comparisons per step)
   std::vector<int> slot(n_epoch), first;
-  for (size_t i = 0; i < n_epoch; ++i) {
-    int s_found = -1;
-    for (size_t s = 0; s < first.size(); ++s)
-      if (std::memcmp(&cosmo[first[s]], &cosmo[i], sizeof(chomp_cosmo)) == 0) { s_found = (int)s; break; }
-    if (s_found < 0) { s_found = (int)first.size(); first.push_back((int)i); }
-    slot[i] = s_found;
+  {
+    std::unordered_multimap<uint64_t, int> seen;     // hash of the parameter bytes -> slot
+    seen.reserve(n_epoch * 2);
+    for (size_t i = 0; i < n_epoch; ++i) {
+      uint64_t h = 1469598103934665603ull;           // FNV-1a over the 10 doubles
+      const unsigned char* b = reinterpret_cast<const unsigned char*>(&cosmo[i]);
+      for (size_t j = 0; j < sizeof(chomp_cosmo); ++j) { h ^= b[j]; h *= 1099511628211ull; }
+      int s_found = -1;
+      auto range = seen.equal_range(h);
+      for (auto it = range.first; it != range.second; ++it)
+        if (std::memcmp(&cosmo[first[it->second]], &cosmo[i], sizeof(chomp_cosmo)) == 0) {
+          s_found = it->second;
+          break;
+        }
+      if (s_found < 0) {
+        s_found = (int)first.size();
+        first.push_back((int)i);
+        seen.emplace(h, s_found);
+      }
+      slot[i] = s_found;
+    }
   }
   const size_t n_slots = first.size();
   ctx->slot = slot;

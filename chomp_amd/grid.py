@@ -73,6 +73,27 @@ class HaloGrid(object):
         self._c_hod = self.ctx.pack_hod(self.hod, n) if n else None
         self._z = numpy.ascontiguousarray(self.z, dtype=numpy.float64)
 
+    def set_parameters(self, cosmo=None, halo=None, hod=None):
+        """New parameters for this rank's epochs, taking effect at the next setup(): the step of
+        an MCMC / design loop.  Each argument: None (keep), one dict, a list with one dict per
+        local epoch, or the packed ctypes array (Context.pack_*; cosmo also as a float64 array
+        [n_local, 10]) -- packing once outside the loop keeps the host out of the step."""
+        import ctypes
+        n = len(self.idx)
+        if n == 0:
+            return
+        if cosmo is not None:
+            self._c_cosmo = cosmo if isinstance(cosmo, ctypes.Array) else self.ctx.pack_cosmo(cosmo, n)
+        if halo is not None:
+            self._c_halo = halo if isinstance(halo, ctypes.Array) else self.ctx.pack_halo(halo, n)
+        if hod is not None:
+            if not isinstance(hod, ctypes.Array):
+                hod = self.ctx.pack_hod([hod_mod.HODZheng(h) for h in hod]
+                                        if isinstance(hod, (list, tuple)) else hod_mod.HODZheng(hod), n)
+            self._c_hod = hod
+        assert len(self._c_cosmo) == n and len(self._c_halo) == n and len(self._c_hod) == n
+        self._tables = 0
+
     def setup(self, which="power_mm"):
         """Stage K for this rank's epochs (asynchronous on the context's stream)."""
         _, need = _WHICH[which]

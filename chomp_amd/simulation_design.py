@@ -10,10 +10,12 @@ point becomes one epoch of a HaloGrid and all of them are built and evaluated by
 kernel launches.
 """
 import copy
+import warnings
 
 import numpy
 import pandas
 
+from . import _lib
 from . import defaults
 from . import grid
 from . import halo as halo_mod
@@ -23,6 +25,15 @@ default_parameter_dict = {"cosmo_dict": defaults.default_cosmo_dict,
                           "hod_dict": defaults.default_hod_dict}
 
 _BATCHED_METHODS = ("linear_power", "power_mm", "power_gm", "power_mg", "power_gg")
+
+
+def _hod_dict_of(h):
+    """The parameter dictionary of an HODZheng; one built without a dictionary keeps None
+    (hod.py:157-165) and answers from its attributes."""
+    d = h.get_hod()
+    if d is None:
+        d = {key: getattr(h, key) for key in ("log_M_min", "sigma", "log_M_0", "log_M_1p", "alpha")}
+    return dict(d)
 
 
 def random_lhs(n, k):
@@ -132,7 +143,7 @@ class SimulationDesign(object):
                 self._apply_point(point)
                 cosmos.append(rec.cosmo if rec.cosmo is not None else dict(obj.cosmo.cosmo_dict))
                 halos.append(dict(obj.mass.halo_dict))
-                hods.append(rec.hod if rec.hod is not None else dict(obj.local_hod.get_hod()))
+                hods.append(rec.hod if rec.hod is not None else _hod_dict_of(obj.local_hod))
         finally:
             self._input_object = real
         kind = "tinker" if getattr(obj.mass, "_kind", 0) else "st"
@@ -140,21 +151,44 @@ class SimulationDesign(object):
                            halo_dict=halos, hod_dict=hods, mass_function=kind)
         k = numpy.asarray(self._ind_var, dtype=numpy.float64)
         out = hg.power(self._method, k.ravel())
+        # The result is on the host: read the status words now and say which design points they
+        # concern.  What the point-by-point loop reports through Halo._sync (an exhausted divmax =
+        # scipy's AccuracyWarning; a saturated mass-limit search, where the reference's own answer
+        # is decided by rounding noise and may differ by percents) must not get lost in a batch.
+        words = hg.status()
+        self.design_status = pandas.Series([int(w) for w in words], index=self.points.index,
+                                           name="status", dtype="int64")
+        for label, w in self.design_status.items():
+            if w:
+                kind = (_lib.ChompParityWarning
+                        if w & (_lib.ST_SATURATED | _lib.ST_MASS_SEARCH_EXHAUSTED)
+                        else _lib.ChompAccuracyWarning)
+                warnings.warn("design point %s: %s" % (label, "; ".join(_lib.describe_status(w))),
+                              kind, stacklevel=3)
         return pandas.DataFrame(numpy.asarray(out).T, columns=self.points.index)
 
-    def run_design(self, batched=None):
+    def run_design(self, batched=None, with_status=False):
         """simulation_design.py:140-155.  Returns a DataFrame with one column per design
         point holding the flattened output of the method.  batched=None picks the
-        one-launch path when the object / method allow it."""
+        one-launch path when the object / method allow it.
+
+        The batched path keeps the status word of every design point (chomp_get_status bits) in
+        `self.design_status` and raises them as warnings naming the point; with_status=True
+        also appends them to the returned frame as a last row labelled 'status' (the frame the
+        reference returns has no such row, so this is opt-in)."""
         if not self._initialized_design:
             self._init_design_points()
         if batched is None:
             batched = self._batched()
+        self.design_status = None
         if batched:
             self.design_values = self._run_batched()
         else:
             self.design_values = self.points.transpose().apply(self._run_des_point)
         self.values_frame = self.design_values
+        if with_status and self.design_status is not None:
+            return pandas.concat([self.design_values,
+                                  self.design_status.to_frame().transpose()])
         return self.design_values
 
     def set_cosmology(self, cosmo_dict=None, values=None):

@@ -185,6 +185,50 @@ def test_simulation_design_batched_equals_loop():
     des.write("/dev/null")
 
 
+def test_simulation_design_reports_status_of_its_points():
+    """The batch path of SimulationDesign must not swallow what the point-by-point loop says
+    through Halo._sync: a design point whose mass-limit search saturates (the reference's own
+    answer is decided by rounding noise there; P(k) may differ by percents) raises a
+    ChompParityWarning naming the point, its word is kept in design_status, and with_status=True
+    appends the words to the frame."""
+    import warnings
+    from chomp_amd import halo, simulation_design as sd, _lib
+    numpy.random.seed(5)
+    k = numpy.logspace(-3, 2, 16)
+    params = {"omega_m0": [0.27, 0.21, 0.33], "omega_b0": [0.045, 0.04, 0.05],
+              "h": [0.7, 0.65, 0.75], "sigma_8": [0.8, 0.69, 0.9], "n_scalar": [0.96, 0.92, 1.0]}
+    z = 1.3923165344405541
+    des = sd.SimulationDesignFlatUniverse(halo.Halo(z), "power_mm", params, n_design=5,
+                                          independent_var=k)
+    des._init_design_points()
+    # point 3 := one of the cases the randomised soak found 5 % from the oracle (flagged there)
+    des.points.loc[3, ["omega_m0", "omega_b0", "h", "sigma_8", "n_scalar"]] = [
+        0.22563, 0.04499, 0.7203, 0.70574, 0.93183]
+    # ... and point 1 := a benign one
+    des.points.loc[1, ["omega_m0", "omega_b0", "h", "sigma_8", "n_scalar"]] = [
+        0.30, 0.045, 0.7, 0.85, 0.96]
+    with pytest.warns(_lib.ChompParityWarning, match="design point 3: .*saturated"):
+        frame = des.run_design(with_status=True)
+    assert des._batched() and frame.shape == (17, 5)
+    assert list(frame.index)[-1] == "status"
+    st = des.design_status
+    assert int(st[3]) & _lib.ST_MASS_MIN_SATURATED and int(st[1]) == 0
+    assert numpy.array_equal(frame.loc["status"].values, st.values)
+    assert des.design_values.shape == (16, 5)           # the reference's frame, without the row
+    # the loop path says the same about the same point
+    loop = sd.SimulationDesignFlatUniverse(halo.Halo(z), "power_mm", params, n_design=5,
+                                           independent_var=k)
+    loop._init_design_points()
+    loop.points = des.points.copy()
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        looped = loop.run_design(batched=False)
+    assert any(issubclass(w.category, _lib.ChompParityWarning) for w in rec)
+    assert loop.design_status is None
+    ok = [c for c in range(5) if int(st[c]) == 0]
+    assert rel_err(des.design_values.values[:, ok], looped.values[:, ok]) < 1e-12
+
+
 def test_convenience_methods_vs_oracle(tmp_path):
     """Methods of the reference's classes that sit beside the hot path: MassFunction.dndm /
     write (mass_function.py:268-302), MultiEpoch's redshift-argument scalars
