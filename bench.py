@@ -593,21 +593,28 @@ def main():
     nk_big = args.roofline_nk
     k_big = torch.logspace(-3, 2, nk_big, dtype=torch.float64, device=dev)
     buf_big = torch.empty((n_local, nk_big), dtype=torch.float64, device=dev)
-    # (the first ~100 launches after the compute-bound Stage K phase run at a varying,
-    #  lower rate while the device's clocks settle -- rocprof trace in DESIGN.md section 6 --
-    #  so the streaming stage gets a warm-up train of its own)
-    for _ in range(200):
-        hg.power(which, k_big, out=buf_big)
-    t_e_big = timed(lambda: hg.power(which, k_big, out=buf_big), 100)
-    # per-kernel durations of the same call (HIP events recorded by the library around its
-    # launches, on the stream they run on): the last call of 5 back-to-back trains
+    # Per-kernel durations of the call: HIP events recorded by the library around its launches,
+    # on the stream they run on; the last call of each back-to-back train of 40.  NO private
+    # warm-up: the trains start right behind the compute-bound Stage K phase, where the first
+    # ~100 launches run at a varying, lower rate while the device's clocks settle, and
+    # `avg_launch_us` (hence roofline.frac) is the mean over ALL trains -- what a rocprofv3
+    # --stats average of the same command sees.  The settled rate (last 5 trains) is reported
+    # beside it as frac_steady.
     hg.ctx.set_timing(True)
     per_kernel = []
-    for _ in range(5):
+    t_calls = []
+    for _ in range(12):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(stream)
         for _ in range(40):
             hg.power(which, k_big, out=buf_big)
+        ev1.record(stream)
         per_kernel.append(hg.ctx.get_timing())
+        ev1.synchronize()
+        t_calls.append(ev0.elapsed_time(ev1) / 40 * 1e-3)
     t_prep, t_stream, t_lanes = (float(x) * 1e-6 for x in numpy.mean(per_kernel, axis=0))
+    t_stream_steady = float(numpy.mean([p[1] for p in per_kernel[-5:]])) * 1e-6
+    t_e_big = float(numpy.mean(t_calls))
     # the same grid registered once (chomp_power_plan: the k-only table is kept, a grid
     # without k groups for the per-lane pass skips that launch): what a caller who evaluates
     # many (cosmology-preserving) set-ups on one k grid sees per call
@@ -645,12 +652,18 @@ def main():
                       "the context's stream)",
             "workload": "%d k x %d z (enlarged grid, SURVEY 8(d))" % (nk_big, n_local),
             "achieved": bytes_big / t_stream / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": bytes_big / t_stream / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+            "frac": bytes_big / t_stream / 1e9 / HBM_PEAK_GBS,
+            "frac_steady": bytes_big / t_stream_steady / 1e9 / HBM_PEAK_GBS,
+            "steady_launch_us": t_stream_steady * 1e6,
+            "averaging": "avg_launch_us / frac: mean over 12 trains of 40 calls starting right "
+                         "behind Stage K (no private warm-up; comparable with a rocprofv3 --stats "
+                         "average); steady: the last 5 trains",
+            "traffic": traffic,
             "traffic_source": "profiles/stage_e_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                               "passes of this command, FETCH doubled per MI355X_MICROARCH.md); "
                               "not re-measured by this run",
             "bytes_per_launch": bytes_big, "avg_launch_us": t_stream * 1e6,
-            # the whole chomp_power call as a caller sees it (HIP events around 100 calls)
+            # the whole chomp_power call as a caller sees it (HIP events around the trains)
             "whole_call": {"kernels_us": {"k_power_prep": t_prep * 1e6,
                                           "k_power_stream": t_stream * 1e6,
                                           "k_power_grid_lanes": t_lanes * 1e6},

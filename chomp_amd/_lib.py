@@ -114,6 +114,7 @@ ST_NONFINITE = 0x10000
 ST_SATURATED = ST_MASS_MIN_SATURATED | ST_MASS_MAX_SATURATED
 TUNE_E_STREAM_MIN, TUNE_E_ROWS, TUNE_DEEP_LITERAL, TUNE_ROCTX, TUNE_WTHETA_DIRECT = 0, 1, 2, 3, 4
 TUNE_CELL_ONE_KERNEL = 5
+TUNE_DEEP_TOL, TUNE_DEEP_MAX_BREAKS, TUNE_DEEP_MAX_FINE = 6, 7, 8
 
 
 class ChompAccuracyWarning(UserWarning):
@@ -156,11 +157,24 @@ def sources():
 HASH_PATH = LIB_PATH + ".srchash"
 
 
+# Compiler flags of the device code.  -disable-machine-licm: LLVM's machine-level loop-invariant
+# code motion hoists the materialisation of every double constant of the inlined libm / special-
+# function polynomials (a v_mov pair each) out of the kernels' outer loops, where they stay live
+# across everything and -- the scalar registers being exhausted -- end up in VGPRs or even
+# spilled to scratch and re-loaded INSIDE the dependent FMA chains (k_halo_knots_fast: 256 VGPRs +
+# 652 B of scratch per lane).  Without it: k_halo_knots 231 -> 168 VGPRs, k_epoch_probe 215 -> 152,
+# k_nu_table 128 -> 98, k_power_grid 166 -> 106, no spills left in k_cell / k_cell_deep / k_wtheta
+# (tools/kernel_regs.py); same arithmetic, bit-identical results.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-mllvm", "-disable-machine-licm"]
+
+
 def source_hash():
     """Content hash of everything the library is compiled from (mtimes do not survive a
-    copy of the tree to another box; contents do)."""
+    copy of the tree to another box; contents do), compiler flags included."""
     import hashlib
     h = hashlib.sha256()
+    h.update(" ".join(HIPCC_FLAGS).encode())
     for path in sources():
         h.update(os.path.basename(path).encode())
         with open(path, "rb") as f:
@@ -182,8 +196,7 @@ def build(force=False, verbose=False):
             pass
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     tmp = LIB_PATH + ".tmp%d" % os.getpid()
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-o", tmp, os.path.join(CSRC, "chomp_capi.hip")]
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", tmp, os.path.join(CSRC, "chomp_capi.hip")]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
@@ -240,8 +253,7 @@ def lib():
             warnings.warn("chomp_amd: sources are newer than libchomp_mi355x.so and the "
                           "rebuild failed (%s); using the existing library" % exc)
         _preload_hip_runtime()
-        # (development aid: an experimental build of the same library, e.g. for A/B timing)
-        L = ctypes.CDLL(os.environ.get("CHOMP_LIB_OVERRIDE", LIB_PATH))
+        L = ctypes.CDLL(LIB_PATH)
         for name in EXPORTS:
             if not hasattr(L, name):
                 raise ImportError("chomp_amd: %s lacks symbol %s" % (LIB_PATH, name))
@@ -400,6 +412,7 @@ class Context(object):
         self._L.chomp_get_stream(self._h, ctypes.byref(sp))
         self.stream_ptr = sp.value or 0
         self.n_epoch = 0
+        self._plan_k = None
 
     # -- ordering against the caller's torch stream ------------------------------------
     def _torch_enter(self):
@@ -424,6 +437,7 @@ class Context(object):
         if getattr(self, "_h", None) is not None and self._h:
             self._L.chomp_ctx_destroy(self._h)
             self._h = ctypes.c_void_p()
+            self._plan_k = None
 
     def __del__(self):
         try:
@@ -539,6 +553,10 @@ class Context(object):
         assert _is_torch(k) and k.is_cuda and k.is_contiguous()
         self._check(self._L.chomp_power_plan(self._h, epoch0, ctypes.c_void_p(k.data_ptr()),
                                              k.numel()))
+        # The library recognises the registered grid by (address, length, cosmology).  Keeping
+        # the tensor alive for as long as the context may hold that registration means the
+        # caching allocator can never hand the same address to a different k grid.
+        self._plan_k = k
 
     def sigma_r(self, epoch, scale):
         s = numpy.ascontiguousarray(numpy.atleast_1d(scale), dtype=numpy.float64)

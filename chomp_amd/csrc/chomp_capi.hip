@@ -103,7 +103,7 @@ struct chomp_ctx {
   unsigned* d_status = nullptr;    // per-epoch status word (chomp_get_status)
   double* d_endp = nullptr;        // integrand pairs of the knots at the upper end point
   int* d_npend = nullptr;          // per epoch: listed knots + 1 token (k_halo_knots_fast)
-  long long tune[CHOMP_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1};   // chomp_set_tuning
+  long long tune[CHOMP_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};   // chomp_set_tuning
   bool have_epochs = false, have_mass = false, have_halo = false;
   unsigned fam_mask = 0;          // families (F_* bits) with valid splines
   std::vector<char> have_halofit;
@@ -143,6 +143,10 @@ struct chomp_ctx {
     int bao = 0, parity = 0, n_slow = -1;
   } plan;
   int slow_parity = 0;
+  // opt-ins for more than 64 KiB of dynamic LDS, done once per context (hipFuncSetAttribute
+  // applies to the current device: a process-wide flag would skip a second device)
+  bool lds_knots_set = false;
+  unsigned lds_cell_mask = 0;      // k_cell_deep<HF, BAO>: bit 2 HF + BAO
   bool slow_by_memset = false;     // set once a Stage E call has been captured into a HIP graph
   int precision = CHOMP_PREC_F64;  // chomp_set_precision
   int with_bao = 0;                // chomp_set_transfer
@@ -352,7 +356,7 @@ int alloc_epochs(chomp_ctx* ctx, size_t n) {
   HIPCHK(hipMalloc(&ctx->d_probe, n * kProbeStride * sizeof(double)));
   HIPCHK(hipMalloc(&ctx->d_count, n * sizeof(int)));
   HIPCHK(hipMemsetAsync(ctx->d_count, 0, n * sizeof(int), ctx->stream));
-  HIPCHK(hipMalloc(&ctx->d_pending, (kPendingHead + 3 * n * (size_t)ctx->L.NK) * sizeof(int)));
+  HIPCHK(hipMalloc(&ctx->d_pending, pending_ints(n, ctx->L.NK) * sizeof(int)));
   HIPCHK(hipMemsetAsync(ctx->d_pending, 0, kPendingHead * sizeof(int), ctx->stream));
   HIPCHK(hipMalloc(&ctx->d_endp, n * 3 * 2 * (size_t)ctx->L.NK * sizeof(double)));
   HIPCHK(hipMalloc(&ctx->d_npend, n * sizeof(int)));
@@ -761,28 +765,60 @@ static int launch_halo_knots(chomp_ctx* ctx, const HaloPlan& P) {
   size_t shf = deep_fast_lds<kDeepCoarse>(L.NM);
   if (shf < (size_t)finalize_lds_doubles(L.NK) * sizeof(double))
     shf = (size_t)finalize_lds_doubles(L.NK) * sizeof(double);
-#define CHOMP_KNOTS_FAST(NT)                                                                     \
-  hipLaunchKernelGGL((k_halo_knots_fast<kDeepCoarse, NT>), dim3(gd), dim3(NT), shf, ctx->stream,    \
-                     ctx->cfg, L, ctx->d_epochs, ctx->d_tab, ctx->d_profile, ctx->d_hod,            \
-                     ctx->d_sici, P.groups[0], P.groups[1], P.groups[2], P.kmask, (int)n,           \
-                     ctx->d_pending, ctx->d_npend, ctx->d_epochs, P.fam, ctx->d_status,             \
-                     ctx->d_deepw, ctx->tune[CHOMP_TUNE_DEEP_LITERAL] > 0 ? 1 : 0, ctx->d_deepstat,     \
-                     ctx->d_nodes)
-  if (shf > 64 * 1024) {            // (more than 64 KiB of dynamic LDS: opt in, once)
-    static bool lds_set = false;
-    if (!lds_set) {
+  // chomp_set_tuning: the checker (every listed knot by literal evaluation) and the two
+  // thresholds at which a knot leaves the fast path by itself
+  const int all_literal = ctx->tune[CHOMP_TUNE_DEEP_LITERAL] > 0 ? 1 : 0;
+  const double deep_tol = ctx->tune[CHOMP_TUNE_DEEP_TOL] >= 0
+                              ? (double)ctx->tune[CHOMP_TUNE_DEEP_TOL] * 1e-15 : kDeepTol;
+  int max_rough = ctx->tune[CHOMP_TUNE_DEEP_MAX_BREAKS] >= 0 ? (int)ctx->tune[CHOMP_TUNE_DEEP_MAX_BREAKS]
+                                                             : kDeepMaxRough;
+  if (max_rough > kDeepMaxRough) max_rough = kDeepMaxRough;
+  int max_fine = ctx->tune[CHOMP_TUNE_DEEP_MAX_FINE] >= 0 ? (int)ctx->tune[CHOMP_TUNE_DEEP_MAX_FINE]
+                                                          : kDeepMaxFine;
+  if (max_fine > kDeepMaxFine) max_fine = kDeepMaxFine;
+#define CHOMP_KNOTS_FAST(NT, SELF)                                                               \
+  hipLaunchKernelGGL((k_halo_knots_fast<kDeepCoarse, NT, SELF>), dim3(gd), dim3(NT), shf, ctx->stream, \
+                     ctx->cfg, L, ctx->d_epochs, ctx->d_tab, ctx->d_sici, P.groups[0], P.groups[1], \
+                     P.groups[2], P.kmask, (int)n, ctx->d_pending, ctx->d_npend, ctx->d_epochs,     \
+                     P.fam, ctx->d_status, ctx->d_deepw, all_literal, deep_tol, max_rough, max_fine, \
+                     ctx->d_deepstat, ctx->d_nodes)
+#define CHOMP_KNOTS_LITERAL(NT, GRID)                                                            \
+  hipLaunchKernelGGL((k_halo_knots_literal<NT>), dim3(GRID), dim3(NT), shl, ctx->stream, ctx->cfg,  \
+                     L, ctx->d_epochs, ctx->d_tab, ctx->d_profile, ctx->d_hod, ctx->d_sici,         \
+                     P.groups[0], P.groups[1], P.groups[2], P.kmask, (int)n, ctx->d_pending,        \
+                     ctx->d_npend, ctx->d_epochs, P.fam, ctx->d_status, ctx->d_deepstat)
+  if (shf > 64 * 1024) {            // (more than 64 KiB of dynamic LDS: opt in, once per context)
+    if (!ctx->lds_knots_set) {       // (per context: the attribute belongs to the current device)
       HIPCHK(hipFuncSetAttribute(
-          reinterpret_cast<const void*>(&k_halo_knots_fast<kDeepCoarse, kDeepThreadsFew>),
+          reinterpret_cast<const void*>(&k_halo_knots_fast<kDeepCoarse, kDeepThreadsFew, false>),
           hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
       HIPCHK(hipFuncSetAttribute(
-          reinterpret_cast<const void*>(&k_halo_knots_fast<kDeepCoarse, kDeepThreads>),
+          reinterpret_cast<const void*>(&k_halo_knots_fast<kDeepCoarse, kDeepThreads, false>),
           hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-      lds_set = true;
+      HIPCHK(hipFuncSetAttribute(
+          reinterpret_cast<const void*>(&k_halo_knots_fast<kDeepCoarse, kDeepThreadsFew, true>),
+          hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+      HIPCHK(hipFuncSetAttribute(
+          reinterpret_cast<const void*>(&k_halo_knots_fast<kDeepCoarse, kDeepThreads, true>),
+          hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+      ctx->lds_knots_set = true;
     }
   }
-  if ((size_t)L.NK * n * ng <= 768) CHOMP_KNOTS_FAST(kDeepThreadsFew);
-  else CHOMP_KNOTS_FAST(kDeepThreads);
+  const bool few = (size_t)L.NK * n * ng <= 768;
+  if (!hod_groups) {                // (group 0 alone: listed knots are done in the same launch)
+    if (few) CHOMP_KNOTS_FAST(kDeepThreadsFew, true); else CHOMP_KNOTS_FAST(kDeepThreads, true);
+  } else {
+    if (few) CHOMP_KNOTS_FAST(kDeepThreadsFew, false); else CHOMP_KNOTS_FAST(kDeepThreads, false);
+  }
+  // knots can only be handed on when some HOD Romberg may run beyond the node tables
+  if (hod_groups && ctx->cfg.divmax > kNodeLevel) {
+    const size_t shl = deep_literal_lds(L.NM, L.NK);
+    // (an empty list is the rule: few blocks, each returns after one read)
+    const unsigned gl = all_literal ? gd : (gd < 256u ? gd : 256u);
+    if (few) CHOMP_KNOTS_LITERAL(kDeepThreadsFew, gl); else CHOMP_KNOTS_LITERAL(kDeepThreads, gl);
+  }
 #undef CHOMP_KNOTS_FAST
+#undef CHOMP_KNOTS_LITERAL
   HIPCHK(hipGetLastError());
   ctx->have_halo = true;
   ctx->fam_mask |= P.fam;

@@ -23,7 +23,17 @@ namespace chomp {
 // omitted.
 // ---------------------------------------------------------------------------
 constexpr double kPendingLevel = -1.0;   // levels-table marker: needs the deep pass
-constexpr int kPendingHead = 4;          // ints in front of the items of the work list
+// The work lists of the knots that run beyond the node tables (ints; one buffer per context):
+//   [0] listed items, [1] next item to hand out, [2] unused          (k_halo_knots_fast)
+//   [4] items handed on to the literal evaluation, [5] next of those (k_halo_knots_literal)
+//   [kPendingHead ...] the items; the second list follows at pending_literal_base().
+constexpr int kPendingHead = 8;
+__host__ __device__ inline size_t pending_literal_base(size_t n_epoch, int NK) {
+  return (size_t)kPendingHead + 3 * n_epoch * (size_t)NK;
+}
+__host__ __device__ inline size_t pending_ints(size_t n_epoch, int NK) {
+  return (size_t)kPendingHead + 2 * 3 * n_epoch * (size_t)NK;
+}
 constexpr unsigned kMaskExclusion = 1u << 8;   // bit of the kernels' family mask: HaloExclusion
 constexpr unsigned kMaskDeepNodes = 1u << 9;   // ... the node tables hold level kNodeTabLevel too
 
@@ -338,7 +348,7 @@ __device__ __forceinline__ void halo_epoch_begin(Epoch& E, const chomp_halo_par&
   *npend_e = 1;
   // the work list of the knots: emptied once per set-up, before any knot is integrated
   // (every block of the previous set-up's k_halo_knots_fast has finished by now)
-  if (first_epoch) { pending[0] = 0; pending[1] = 0; pending[2] = 0; }
+  if (first_epoch) { pending[0] = 0; pending[1] = 0; pending[2] = 0; pending[4] = 0; pending[5] = 0; }
 }
 
 // ---------------------------------------------------------------------------
@@ -838,31 +848,67 @@ inline size_t deep_fast_lds(int NM) {
                           sizeof(double) + (size_t)((NC + 1 + 15) & ~15);
   return deep;                     // (> finalize_lds_doubles(NK) for any NK <= 512 at LC >= 11)
 }
+// ... of k_halo_knots_literal.
+inline size_t deep_literal_lds(int NM, int NK) {
+  size_t d = (size_t)(NM + 8 * (NM - 1) + kDeepScratch);
+  if (d < (size_t)finalize_lds_doubles(NK)) d = (size_t)finalize_lds_doubles(NK);
+  return d * sizeof(double);
+}
 
-// grid >= n_epoch (blocks draw knots from the list k_halo_knots left), block kDeepThreads.  An epoch's
+// One more arrival at epoch e (its token, or one of its listed knots done) by a whole block:
+// whoever brings npend[e] to zero finalises the epoch.  fences: knots were written by other
+// blocks of this or the previous launch's kernels since the counter was armed.
+__device__ __forceinline__ void deep_arrive(const chomp_config& cfg, const TabLayout& L,
+                                            Epoch* __restrict__ epochs_rw, double* __restrict__ tab,
+                                            int e, unsigned fam_mask, unsigned* __restrict__ status,
+                                            int* __restrict__ npend, bool fences, int* last_sh,
+                                            double* sm) {
+  __syncthreads();                 // (the block's results are written)
+  if (threadIdx.x == 0) {
+    if (fences) {
+      __threadfence();             // ... and visible before the count moves
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    *last_sh = atomicSub(&npend[e], 1) == 1 ? 1 : 0;
+  }
+  __syncthreads();
+  if (*last_sh) {                  // block-uniform
+    if (fences) __threadfence();
+    halo_finalize_block(cfg, L, epochs_rw, tab, e, fam_mask, status, sm);
+  }
+}
+
+// grid >= n_epoch (blocks draw knots from the list k_halo_knots left), block NT.  An epoch's
 // set-up ends with halo_finalize_block once all its knots are final: npend[e] counts its
 // listed knots plus one token, which block e takes first -- an epoch with nothing listed
 // (every P_mm epoch at the default precision) is finalised right there, otherwise by the
-// block that completes its last knot.  (The list is cleared by the next set-up's node-table
-// stage, halo_epoch_begin: blocks of this launch may still be polling its head.)
-// deepw: deep_weights_host(LC, divmax).  force_literal: evaluate
-// every node (chomp_set_tuning CHOMP_TUNE_DEEP_LITERAL: the checker).  stats (optional):
-// [0] knots done by the fast path, [1] by the literal one; why literal: [2] too many break
-// points, [3] too many node-by-node intervals, [4] self-check; [5] largest self-check
-// estimate seen (float bits).
+// block that completes its last knot, here or in k_halo_knots_literal.  (The lists are cleared
+// by the next set-up's node-table stage, halo_epoch_begin: blocks of this launch may still be
+// polling their heads.)
+// deepw: deep_weights_host(LC, divmax).  A knot the scheme cannot do -- more break points than
+// max_rough, more node-by-node intervals than max_fine, a self-check estimate above tol,
+// coarse samples missing from the node table, or all_literal (chomp_set_tuning
+// CHOMP_TUNE_DEEP_LITERAL: the checker) -- is NOT evaluated here: it is handed on, still
+// counted in npend[e], to the second list, which k_halo_knots_literal works off behind this
+// launch.  (The literal evaluation inlined here cost every knot of the fast path its
+// registers: 256 VGPRs + 652 bytes of scratch per lane.)
+// stats (optional): [0] knots done by the fast path, [1] by the literal one; why literal:
+// [2] too many break points, [3] too many node-by-node intervals, [4] self-check; [5] largest
+// self-check estimate seen (float bits).
 // NT: kDeepThreads, or kDeepThreadsFew when there are at most about two knots per CU to do (one
 // epoch): the launch then lasts as long as one knot, and a knot's phases are spread wider.
-template <int LC, int NT>
-// (eight wavefronts per CU: the phases of one knot are latency chains -- a few nodes per level in
-//  the break-point intervals -- and a second block fills them; measured 349 vs 417 us on C3
-//  although the register cap spills)
+// SELF: the set-up has no HOD integrands (P_mm, linear): nothing is ever listed at the default
+// precision, the launch is the epochs' finalisation -- and a listed knot (tightened
+// halo_precision) can only be of the smooth group 0, which this instance evaluates literally
+// right here, so that the headline chain does not carry an always-empty hand-over launch.
+template <int LC, int NT, bool SELF>
 __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
     chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs, double* __restrict__ tab,
-    const chomp_halo_par* __restrict__ profile, const HodDev* __restrict__ hod,
     const SiCiTab* __restrict__ sici_g, int g0, int g1, int g2, unsigned mask, int n_epoch,
     int* __restrict__ pending, int* __restrict__ npend, Epoch* __restrict__ epochs_rw,
     unsigned fam_mask, unsigned* __restrict__ status, const double* __restrict__ deepw,
-    int force_literal, int* __restrict__ stats, const double* __restrict__ nodes) {
+    int all_literal, double tol, int max_rough, int max_fine, int* __restrict__ stats,
+    const double* __restrict__ nodes) {
   static_assert(LC == kNodeTabLevel, "the coarse samples are the node table's grid");
   constexpr int NC = 1 << LC;
   constexpr int NWV = NT / 64;
@@ -872,59 +918,94 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
   __shared__ int item_sh, n_rough_sh, n_fine_sh, n_seg_sh, last_sh;
   __shared__ int rough_sh[kDeepMaxRough], fine_sh[kDeepMaxFine];
   __shared__ int seg_lo[kDeepMaxRough + 1], seg_hi[kDeepMaxRough + 1];
+  __shared__ double lsum_w[NWV][2][LC + 1];        // per-wavefront sums of the coarse levels
   const int NK = L.NK;
   const int tid = threadIdx.x;
+  const int wv = tid >> 6, ln = tid & 63;
   const int count = pending[0];
-  // One more arrival at epoch e (its token, or one of its listed knots done): whoever brings
-  // the count to zero finalises the epoch; the last of ALL arrivals clears the list.
   // (with an empty list no block of this launch writes a knot: every value the finalisation
   //  reads comes from the previous launch, and no fence is needed)
   const bool fences = count != 0;
-  auto arrive = [&](int e, bool token) {
-    (void)token;
-    __syncthreads();               // (the block's results are written)
-    if (tid == 0) {
-      if (fences) {
-        __threadfence();           // ... and visible before the count moves
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      last_sh = atomicSub(&npend[e], 1) == 1 ? 1 : 0;
-    }
-    __syncthreads();
-    if (last_sh) {                 // block-uniform
-      if (fences) __threadfence();
-      halo_finalize_block(cfg, L, epochs_rw, tab, e, fam_mask, status, sm);
-    }
-  };
-  if ((int)blockIdx.x < n_epoch) arrive((int)blockIdx.x, true);
+  if ((int)blockIdx.x < n_epoch)
+    deep_arrive(cfg, L, epochs_rw, tab, (int)blockIdx.x, fam_mask, status, npend, fences, &last_sh, sm);
   if (count == 0) return;          // nothing listed: no traffic on the queue head
+  int* lit_items = pending + pending_literal_base((size_t)n_epoch, NK);
+  // what does not depend on the knot, once per block: Si/Ci tables; the deep levels' weights
+  // and the Romberg rows' weights where the finalisation of an epoch cannot reach them
+  double* const w_all = sm + L.NM + 8 * (L.NM - 1) + kDeepScratch + 2 * (NC + 1);
+  const bool w_safe = finalize_lds_doubles(NK) <= L.NM + 8 * (L.NM - 1) + kDeepScratch + 2 * (NC + 1);
+  auto stage_weights = [&]() {
+    int nlev = cfg.divmax - LC;
+    nlev = nlev < 0 ? 0 : (nlev > kDeepWLevels ? kDeepWLevels : nlev);
+    copy_doubles(w_all, deepw, nlev * kDeepWStride);
+    romberg_weights_to_lds(w_all + kDeepWLevels * kDeepWStride, cfg.divmax);   // (the rows' weights)
+  };
+  copy_doubles(reinterpret_cast<double*>(&S), reinterpret_cast<const double*>(sici_g),
+               (int)(sizeof(SiCiTab) / sizeof(double)));
+  stage_weights();
   for (;;) {
-    __syncthreads();               // (previous item done with E, S, sm)
+    __syncthreads();               // (previous item done with E, sm)
     if (tid == 0) item_sh = atomicAdd(&pending[1], 1);
     __syncthreads();
     if (item_sh >= count) return;  // block-uniform
     const int item = pending[kPendingHead + item_sh];
     const int ik = item % NK, e = (item / NK) % n_epoch, zg = item / (NK * n_epoch);
     const int group = zg == 0 ? g0 : (zg == 1 ? g1 : g2);
-    if (group < 0 || group > 2) { arrive(e, false); continue; }   // (never listed; keep the count right)
     double* t = tab + (size_t)e * L.stride;
     double* levs = t + L.off_levels;
-    const int fa = group_fa(group), fb = group_fb(group);
-    const bool pa = group != 2 && (mask & (1u << fa)) && levs[fa * NK + ik] == kPendingLevel;
-    const bool pb = (mask & (1u << fb)) && levs[fb * NK + ik] == kPendingLevel;
-    if (!pa && !pb) { arrive(e, false); continue; }
-    HaloLds H;
-    // (the weights of every deep level, behind the same barrier as the epoch's tables: the
-    //  finalisation of an epoch may have used the space since the previous knot)
-    {
-      double* w_all = sm + L.NM + 8 * (L.NM - 1) + kDeepScratch + 2 * (NC + 1);
-      int nlev = cfg.divmax - LC;
-      nlev = nlev < 0 ? 0 : (nlev > kDeepWLevels ? kDeepWLevels : nlev);
-      copy_doubles(w_all, deepw, nlev * kDeepWStride);
-      romberg_weights_to_lds(w_all + kDeepWLevels * kDeepWStride, cfg.divmax);   // (the rows' weights)
+    const int fa = group_fa(group < 0 ? 0 : group), fb = group_fb(group < 0 ? 0 : group);
+    const bool pa = group >= 0 && group <= 2 && group != 2 && (mask & (1u << fa)) &&
+                    levs[fa * NK + ik] == kPendingLevel;
+    const bool pb = group >= 0 && group <= 2 && (mask & (1u << fb)) && levs[fb * NK + ik] == kPendingLevel;
+    if (!pa && !pb) {              // (never listed; keep the count right)
+      deep_arrive(cfg, L, epochs_rw, tab, e, fam_mask, status, npend, fences, &last_sh, sm);
+      if (!w_safe) { __syncthreads(); stage_weights(); }
+      continue;
     }
-    H.stage(L, E, S, epochs, e, t, profile, hod, sici_g, sm);
-    double* red = H.rest;
+    if constexpr (SELF) {
+      // (group 0 only; the block-wide literal Romberg on the smooth h_m / pp_mm pair)
+      double* nu_knots = sm;
+      double* lnm_pp = nu_knots + L.NM;
+      copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
+                   kEpochDoubles);
+      copy_doubles(nu_knots, t + L.off_nu, L.NM);
+      copy_doubles(lnm_pp, t + L.off_lnm_pp, 4 * (L.NM - 1));
+      __syncthreads();
+      HaloCtx c{&E, &S, nu_knots, lnm_pp, L.NM,
+                linspace_at(log(cfg.k_min), log(cfg.k_max), NK, ik), (mask & kMaskExclusion) != 0};
+      IntegrandMM f{c};
+      const RombergOut<2> r = romberg_group<NWV, 2>(f, group_lower(E, 0), log(E.nu_max),
+                                                   cfg.global_precision, cfg.halo_precision,
+                                                   cfg.divmax, sm + L.NM + 8 * (L.NM - 1));
+      if (tid == 0) {
+        if (pa) { t[L.off_knot[fa] + ik] = r.value[0]; levs[fa * NK + ik] = (double)r.level[0]; }
+        if (pb) { t[L.off_knot[fb] + ik] = r.value[1]; levs[fb * NK + ik] = (double)r.level[1]; }
+        unsigned st = 0u;
+        if (pa && !r.converged[0]) st |= kStHaloDivmax0 << fa;
+        if (pb && !r.converged[1]) st |= kStHaloDivmax0 << fb;
+        if (st) atomicOr(&status[e], st);
+        if (stats) atomicAdd(&stats[1], 1);
+      }
+      deep_arrive(cfg, L, epochs_rw, tab, e, fam_mask, status, npend, fences, &last_sh, sm);
+      if (!w_safe) { __syncthreads(); stage_weights(); }
+      continue;
+    }
+    // hand the knot on where this scheme does not apply at all
+    if (all_literal || cfg.divmax <= LC || !(mask & kMaskDeepNodes)) {
+      if (tid == 0) lit_items[atomicAdd(&pending[4], 1)] = item;
+      continue;
+    }
+    // ---- the epoch's tables
+    double* nu_knots = sm;
+    double* lnm_pp = nu_knots + L.NM;
+    copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
+                 kEpochDoubles);
+    copy_doubles(nu_knots, t + L.off_nu, L.NM);
+    copy_doubles(lnm_pp, t + L.off_lnm_pp, 4 * (L.NM - 1));
+    if (tid == 0) { n_rough_sh = 0; n_fine_sh = 0; n_seg_sh = 0; }
+    if (ln <= LC) { lsum_w[wv][0][ln] = 0.0; lsum_w[wv][1][ln] = 0.0; }
+    __syncthreads();
+    double* red = sm + L.NM + 8 * (L.NM - 1);
     double* F0 = red + kDeepScratch;
     double* F1 = F0 + (NC + 1);
     double* W = F1 + (NC + 1);                             // [divmax - LC][kDeepWStride]
@@ -932,31 +1013,34 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
     unsigned char* code = reinterpret_cast<unsigned char*>(W + kDeepWLevels * kDeepWStride +
                                                            (kMaxDivmax + 1) * 32);
     const double a = group_lower(E, group), b = log(E.nu_max);
-    HaloCtx c{&E, &S, H.nu_knots, H.lnm_pp, L.NM,
+    HaloCtx c{&E, &S, nu_knots, lnm_pp, L.NM,
               linspace_at(log(cfg.k_min), log(cfg.k_max), NK, ik), (mask & kMaskExclusion) != 0};
-    double val[2] = {0.0, 0.0};
-    int lev[2] = {0, 0};
-    bool conv[2] = {true, true};
-    bool literal = force_literal != 0 || cfg.divmax <= LC;
+    bool literal = false;
     int flip = 0;
     RombergRows2 R;
     R.ctab = Ctab;
-    if (!literal) {
-      // ---- coarse samples: from the (epoch, group) node table when it reaches level LC (what
-      // does not depend on k is already there -- the lower levels are the very nodes
-      // k_halo_knots summed), else one evaluation each
-      if (mask & kMaskDeepNodes) {
-        const double* nd = nodes + ((size_t)e * 3 + group) * kNodeStride;
-        for (int idx = tid; idx <= NC; idx += NT) {
+    {
+      // ---- coarse samples from the (epoch, group) node table (what does not depend on k is
+      // already there -- the lower levels are the very nodes k_halo_knots summed); the table
+      // is level-major, so a wavefront's 64 samples of one pass belong to one or two levels
+      // (the first pass: levels 0..6): their sums are taken here, from the registers, one
+      // butterfly per level present -- a separate pass over the samples in position order
+      // would read LDS at power-of-two strides (2.8 M bank conflicts per C3 launch)
+      const double* nd = nodes + ((size_t)e * 3 + group) * kNodeStride;
+      for (int base = 0; base <= NC; base += NT) {
+        const int idx = base + tid;
+        const bool live = idx <= NC;
+        double o[2] = {0.0, 0.0};
+        int lv = 0;
+        if (live) {
           int q;
           if (idx < 2) {
             q = idx == 0 ? 0 : NC;
           } else {                                             // level-major -> position
             const int m = idx - 1;
-            const int lv = 32 - __builtin_clz((unsigned)m);
+            lv = 32 - __builtin_clz((unsigned)m);
             q = (2 * (m - (1 << (lv - 1))) + 1) << (LC - lv);
           }
-          double o[2];
           const double state = nd[6 * kNodeCount + idx];
           node_pair(S, c.ln_k, c.exclusion, nd[idx], nd[kNodeCount + idx], nd[2 * kNodeCount + idx],
                     nd[3 * kNodeCount + idx], nd[4 * kNodeCount + idx], nd[5 * kNodeCount + idx],
@@ -965,34 +1049,29 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
           F1[q] = o[1];
           code[q] = (unsigned char)(int)state;
         }
-      } else {
-        for (int q = tid; q <= NC; q += NT) {
-          double o[2];
-          int st;
-          halo_eval_coded(group, c, deep_coarse_x<LC>(a, b, q), o, &st);
-          F0[q] = o[0];
-          F1[q] = o[1];
-          code[q] = (unsigned char)st;
+        const int i0 = base + 64 * wv;                         // this wavefront's first sample
+        if (i0 <= NC) {                                        // wave-uniform
+          const int i1 = i0 + 63 < NC ? i0 + 63 : NC;
+          int l0 = i0 < 2 ? 1 : 32 - __builtin_clz((unsigned)(i0 - 1));
+          const int l1 = i1 < 2 ? 0 : 32 - __builtin_clz((unsigned)(i1 - 1));
+          if (l0 < 1) l0 = 1;
+          for (int l = l0; l <= l1; ++l) {
+            const bool mine = live && idx >= 2 && lv == l;
+            const double x0 = wave_sum(mine ? o[0] : 0.0), x1 = wave_sum(mine ? o[1] : 0.0);
+            if (ln == 0) { lsum_w[wv][0][l] += x0; lsum_w[wv][1][l] += x1; }
+          }
         }
       }
-      if (tid == 0) { n_rough_sh = 0; n_fine_sh = 0; n_seg_sh = 0; }
       __syncthreads();
-      // ---- levels 0..LC from the samples: wavefront w sums the levels w + 1, w + 5, ...
-      // (lane-strided, then one butterfly: no block barrier per level), the rows follow
+      // ---- levels 0..LC: the wavefronts' sums in a fixed order, then scipy's rows
       {
         double* lsum = red + 2 * NWV;                          // [2][LC + 1] (behind group_sum's slots)
-        const int wv = tid >> 6, ln = tid & 63;
-        for (int l = 1 + wv; l <= LC; l += NWV) {
-          const int stride = NC >> l, cnt = 1 << (l - 1);
-          double s0 = 0.0, s1 = 0.0;
-          for (int j = ln; j < cnt; j += 64) {
-            const int q = stride * (2 * j + 1);
-            s0 += F0[q];
-            s1 += F1[q];
-          }
-          s0 = wave_sum(s0);
-          s1 = wave_sum(s1);
-          if (ln == 0) { lsum[l] = s0; lsum[LC + 1 + l] = s1; }
+        if (tid < 2 * (LC + 1)) {
+          const int f = tid / (LC + 1), l = tid % (LC + 1);
+          double v = 0.0;
+#pragma unroll
+          for (int w = 0; w < NWV; ++w) v += lsum_w[w][f][l];
+          lsum[f * (LC + 1) + l] = v;
         }
         __syncthreads();
         R.start(b - a, cfg.global_precision, cfg.halo_precision, 0.5 * (F0[0] + F0[NC]),
@@ -1008,7 +1087,7 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
           }
         __syncthreads();
         const int nr = n_rough_sh;
-        if (nr > kDeepMaxRough) {
+        if (nr > max_rough) {
           literal = true;                                      // block-uniform
           if (stats && tid == 0) atomicAdd(&stats[2], 1);
         } else {
@@ -1053,7 +1132,7 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
               }
               lo = hi + 1;
             }
-            n_fine_sh = over ? kDeepMaxFine + 1 : extra;
+            n_fine_sh = (over || extra > max_fine) ? kDeepMaxFine + 1 : extra;
             n_seg_sh = ns;
           }
           __syncthreads();
@@ -1097,8 +1176,8 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
             e1 = group_sum<NWV>(e1, red, flip);
             m0 = group_sum<NWV>(m0, red, flip);
             m1 = group_sum<NWV>(m1, red, flip);
-            const bool bad0 = !R.done[0] && !(e0 * (1.0 / 256.0) <= kDeepTol * fabs(m0));
-            const bool bad1 = !R.done[1] && !(e1 * (1.0 / 256.0) <= kDeepTol * fabs(m1));
+            const bool bad0 = !R.done[0] && !(e0 * (1.0 / 256.0) <= tol * fabs(m0));
+            const bool bad1 = !R.done[1] && !(e1 * (1.0 / 256.0) <= tol * fabs(m1));
             if (bad0 || bad1) literal = true;
             if (stats && tid == 0) {
               if (literal) atomicAdd(&stats[4], 1);
@@ -1109,7 +1188,11 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
           }
         }
       }
-      if (!literal) {
+      if (literal) {               // block-uniform: on to k_halo_knots_literal, still counted
+        if (tid == 0) lit_items[atomicAdd(&pending[4], 1)] = item;
+        continue;
+      }
+      {
         // ---- deeper levels, kDeepRound at a time (their sums are independent; what a level
         // costs here is latency -- a handful of node-by-node evaluations and two reductions --
         // so a pass over three levels takes little longer than one; a knot that stops at the
@@ -1176,9 +1259,9 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
             for (int g = 0; g < kDeepRound; ++g) {
               double t0 = 0.0, t1 = 0.0;
 #pragma unroll
-              for (int wv = 0; wv < NWV; ++wv) {
-                t0 += slot[(2 * g) * NWV + wv];
-                t1 += slot[(2 * g + 1) * NWV + wv];
+              for (int w2 = 0; w2 < NWV; ++w2) {
+                t0 += slot[(2 * g) * NWV + w2];
+                t1 += slot[(2 * g + 1) * NWV + w2];
               }
               s0[g] = t0; s1[g] = t1;
             }
@@ -1188,15 +1271,65 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
           for (int g = 0; g < kDeepRound; ++g)
             if (g < ng && !R.all_done()) R.advance(lv0 + g, s0[g], s1[g]);
         }
-        val[0] = R.value[0]; val[1] = R.value[1];
-        lev[0] = R.level[0]; lev[1] = R.level[1];
-        conv[0] = R.done[0]; conv[1] = R.done[1];
       }
     }
-    if (literal) {
-      __syncthreads();
-      deep_literal<NWV>(cfg, c, E, group, pa, red, val, lev, conv);
+    if (tid == 0) {
+      if (pa) { t[L.off_knot[fa] + ik] = R.value[0]; levs[fa * NK + ik] = (double)R.level[0]; }
+      if (pb) { t[L.off_knot[fb] + ik] = R.value[1]; levs[fb * NK + ik] = (double)R.level[1]; }
+      unsigned st = 0u;              // divmax exhausted (halo.py:1065-1071 and alike)
+      if (pa && !R.done[0]) st |= kStHaloDivmax0 << fa;
+      if (pb && !R.done[1]) st |= kStHaloDivmax0 << fb;
+      if (st) atomicOr(&status[e], st);
+      if (stats) atomicAdd(&stats[0], 1);
     }
+    deep_arrive(cfg, L, epochs_rw, tab, e, fam_mask, status, npend, fences, &last_sh, sm);
+    if (!w_safe) { __syncthreads(); stage_weights(); }
+  }   // next item
+}
+
+// The knots k_halo_knots_fast handed on (pending[4] of them, behind pending_literal_base):
+// every node of scipy's Romberg evaluated (deep_literal) -- the checker of the fast path and
+// its fallback.  grid: any (blocks draw from the list), block NT.  Launched behind
+// k_halo_knots_fast whenever knots can be listed at all; with an empty list (the rule) every
+// block returns after one read.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_halo_knots_literal(
+    chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs, double* __restrict__ tab,
+    const chomp_halo_par* __restrict__ profile, const HodDev* __restrict__ hod,
+    const SiCiTab* __restrict__ sici_g, int g0, int g1, int g2, unsigned mask, int n_epoch,
+    int* __restrict__ pending, int* __restrict__ npend, Epoch* __restrict__ epochs_rw,
+    unsigned fam_mask, unsigned* __restrict__ status, int* __restrict__ stats) {
+  constexpr int NWV = NT / 64;
+  extern __shared__ __align__(16) double sm[];
+  __shared__ Epoch E;
+  __shared__ SiCiTab S;
+  __shared__ int item_sh, last_sh;
+  const int count = pending[4];
+  if (count == 0) return;
+  const int NK = L.NK;
+  const int tid = threadIdx.x;
+  const int* items = pending + pending_literal_base((size_t)n_epoch, NK);
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) item_sh = atomicAdd(&pending[5], 1);
+    __syncthreads();
+    if (item_sh >= count) return;  // block-uniform
+    const int item = items[item_sh];
+    const int ik = item % NK, e = (item / NK) % n_epoch, zg = item / (NK * n_epoch);
+    const int group = zg == 0 ? g0 : (zg == 1 ? g1 : g2);
+    double* t = tab + (size_t)e * L.stride;
+    double* levs = t + L.off_levels;
+    const int fa = group_fa(group), fb = group_fb(group);
+    const bool pa = group != 2 && (mask & (1u << fa)) && levs[fa * NK + ik] == kPendingLevel;
+    const bool pb = (mask & (1u << fb)) && levs[fb * NK + ik] == kPendingLevel;
+    HaloLds H;
+    H.stage(L, E, S, epochs, e, t, profile, hod, sici_g, sm);
+    HaloCtx c{&E, &S, H.nu_knots, H.lnm_pp, L.NM,
+              linspace_at(log(cfg.k_min), log(cfg.k_max), NK, ik), (mask & kMaskExclusion) != 0};
+    double val[2];
+    int lev[2];
+    bool conv[2];
+    deep_literal<NWV>(cfg, c, E, group, pa, H.rest, val, lev, conv);
     if (tid == 0) {
       if (pa) { t[L.off_knot[fa] + ik] = val[0]; levs[fa * NK + ik] = (double)lev[0]; }
       if (pb) { t[L.off_knot[fb] + ik] = val[1]; levs[fb * NK + ik] = (double)lev[1]; }
@@ -1204,10 +1337,10 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
       if (pa && !conv[0]) st |= kStHaloDivmax0 << fa;
       if (pb && !conv[1]) st |= kStHaloDivmax0 << fb;
       if (st) atomicOr(&status[e], st);
-      if (stats) atomicAdd(&stats[literal ? 1 : 0], 1);
+      if (stats) atomicAdd(&stats[1], 1);
     }
-    arrive(e, false);
-  }   // next item
+    deep_arrive(cfg, L, epochs_rw, tab, e, fam_mask, status, npend, true, &last_sh, sm);
+  }
 }
 
 }  // namespace chomp

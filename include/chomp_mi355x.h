@@ -299,6 +299,17 @@ int chomp_status_wait(chomp_ctx* ctx, size_t epoch0, size_t n, unsigned* out);
  *   CHOMP_TUNE_E_ROWS        rows per block of the streaming kernel (1, 2 or 4)
  *   CHOMP_TUNE_DEEP_LITERAL  1: knots beyond the node tables by literal evaluation of every
  *                            Romberg node (the checker of the fast deep-level sums)
+ *   CHOMP_TUNE_DEEP_TOL      self-check threshold of the fast deep-level sums, in units of 1e-15
+ *                            relative (default 1 000 000 = 1e-9): a knot whose estimate is above
+ *                            it is handed to the literal evaluation.  0 sends every knot that
+ *                            reaches the self-check there
+ *   CHOMP_TUNE_DEEP_MAX_BREAKS  break points of the integrand (changes of its discrete state
+ *                            along ln nu) a knot may have and still take the fast sums (default
+ *                            and maximum 8); a knot with more goes to the literal evaluation
+ *   CHOMP_TUNE_DEEP_MAX_FINE coarse intervals a knot may evaluate node by node (break points,
+ *                            the margin above a singular satellite onset, segments shorter
+ *                            than a stencil) and still take the fast sums (default and
+ *                            maximum 64)
  *   CHOMP_TUNE_WTHETA_DIRECT 1: w(theta) by evaluating the kernel spline at every Romberg node
  *                            (the checker of the moment route of chomp_wtheta)
  *   CHOMP_TUNE_CELL_ONE_KERNEL 1: C_l with every Romberg level in the per-multipole kernel (the
@@ -314,7 +325,10 @@ int chomp_status_wait(chomp_ctx* ctx, size_t epoch0, size_t n, unsigned* out);
 #define CHOMP_TUNE_ROCTX 3
 #define CHOMP_TUNE_WTHETA_DIRECT 4
 #define CHOMP_TUNE_CELL_ONE_KERNEL 5
-#define CHOMP_TUNE_COUNT 6
+#define CHOMP_TUNE_DEEP_TOL 6
+#define CHOMP_TUNE_DEEP_MAX_BREAKS 7
+#define CHOMP_TUNE_DEEP_MAX_FINE 8
+#define CHOMP_TUNE_COUNT 9
 int chomp_set_tuning(chomp_ctx* ctx, int what, long long value);
 /* Measurement aid: out[6] <- knots beyond the node tables done so far (since the context was
  * created) by [0] the fast deep-level sums, [1] literal evaluation of every node; why literal:

@@ -266,6 +266,73 @@ def g7(ns):
     save("g7_ggl_halofit", **out)
 
 
+def g5b(ns):
+    """configs[2] at its full size: Tinker10 + Zheng07 P_gm on all 64 redshifts
+    z = linspace(0, 1.5, 64) x the 257-point subsample of k = logspace(-3, 2, 4096) that G4
+    uses.  One fresh SingleEpoch / TinkerMassFunction / Halo per redshift, as G5 builds them
+    (about 5 s each: the discontinuous pp_gm integrand runs to divmax at the high-k knots)."""
+    k_full = numpy.logspace(-3, 2, 4096)
+    idx = numpy.unique(numpy.concatenate([numpy.arange(0, 4096, 16), [4095]]))
+    z = numpy.linspace(0.0, 1.5, 64)
+    out = numpy.empty((z.size, idx.size))
+    n_bar = numpy.empty(z.size)
+    times = numpy.empty(z.size)
+    for i, zz in enumerate(z):
+        t0 = time.time()
+        cosmo = ns.cosmology.SingleEpoch(zz)
+        mass = ns.mass_function.TinkerMassFunction(zz, cosmo)
+        h = ns.halo.Halo(zz, ns.hod.HODZheng(ns.defaults.default_hod_dict), cosmo, mass)
+        out[i] = h.power_gm(k_full)[idx]
+        n_bar[i] = h.n_bar
+        times[i] = time.time() - t0
+        print("   g5b z=%.4f %.1f s" % (zz, times[i]), flush=True)
+    save("g5b_pgm_grid", z=z, k_idx=idx, k=k_full[idx], gm=out, n_bar=n_bar, t_rows=times)
+
+
+def g6b(ns):
+    """configs[3] at its full size: w(theta) at all 1024 theta = logspace(-3, 0) deg and C_l at
+    all 2048 l = logspace(1, 4), gal x gal windows, power_gg (and power_mm), built as G6."""
+    cm, kern = _projection(ns, ggl=False)
+    theta = numpy.logspace(-3, 0, 1024) * deg_to_rad
+    ell = numpy.logspace(1, 4, 2048)
+    out = dict(theta=theta, ell=ell, z_bar=kern.z_bar)
+    for ps in ("power_gg", "power_mm"):
+        h = ns.halo.Halo(0.0)
+        t0 = time.time()
+        corr = ns.correlation.Correlation(0.001, 1.0, kern, input_halo=h, power_spec=ps)
+        out["w_" + ps] = corr.correlation(theta)
+        out["t_w_" + ps] = time.time() - t0
+        out["D_z"] = corr.D_z
+        t0 = time.time()
+        cf = ns.correlation.CorrelationFourier(10, 1e4, kern, input_halo=h, powSpec=ps)
+        out["cl_" + ps] = cf.correlation(ell)
+        out["t_cl_" + ps] = time.time() - t0
+    save("g6b_limber_galgal_full", **out)
+
+
+def g7b(ns):
+    """configs[4] at its full size: w_GGL(theta) at 1024 theta and C_l at 2048 l, J2 kernel
+    (galaxy x convergence) with HaloFit power_gm -- in G7's call order: the HaloFit object is
+    built and first evaluated at z = 0 (its sigma spline is built there and, as in the
+    reference, never refreshed), then handed to the correlation objects."""
+    cm, kern = _projection(ns, ggl=True)
+    theta = numpy.logspace(-3, 0, 1024) * deg_to_rad
+    ell = numpy.logspace(1, 4, 2048)
+    hf = ns.halo.HaloFit(0.0)
+    hf.power_mm(numpy.logspace(-3, 2, 8))
+    out = dict(theta=theta, ell=ell, z_bar=kern.z_bar)
+    corr = ns.correlation.Correlation(0.001, 1.0, kern, input_halo=hf, power_spec="power_gm")
+    t0 = time.time()
+    out["w_ggl"] = corr.correlation(theta)
+    out["t_w_ggl"] = time.time() - t0
+    out["D_z"] = corr.D_z
+    cf = ns.correlation.CorrelationFourier(10, 1e4, kern, input_halo=hf, powSpec="power_gm")
+    t0 = time.time()
+    out["cl_ggl"] = cf.correlation(ell)
+    out["t_cl_ggl"] = time.time() - t0
+    save("g7b_ggl_halofit_full", **out)
+
+
 def g8(ns):
     """Halo(extrapolate=True) beyond k_max (halo.py:300-312, 341-367,
     405-431) and HaloExclusion (halo.py:1201-1233)."""
@@ -557,7 +624,7 @@ def pins():
 
 
 def main():
-    names = sys.argv[1:] or ["pins", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
+    names = sys.argv[1:] or ["pins", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g5b", "g6b", "g7b"]
     ns = ref_loader.load()
     cwd = os.getcwd()
     with tempfile.TemporaryDirectory() as tmp:

@@ -10,6 +10,7 @@ from conftest import load_golden, rel_err
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-4
+PROJ_RTOL = 1e-9     # w(theta), C_l against the reference's vectors (measured 4e-11 / 7e-12)
 
 
 @pytest.fixture(scope="module")
@@ -392,39 +393,57 @@ def test_batch_of_cosmologies_vs_oracle():
         assert rel_err(got[i], o.halo_power(t, "gm", k)) < RTOL, i
 
 
-def test_c4_full_size_properties():
-    """configs[3] at full size: 2048 l and 1024 theta.  Values at the golden sample
-    points must match the reference; evaluating in chunks must give identical values
-    (every theta / l is an independent integral: the sharding unit)."""
-    from chomp_amd import cosmology, kernel, correlation, halo
-    g = load_golden("g6_limber_galgal")
+def _full_size_projection(ggl):
+    from chomp_amd import cosmology, kernel
     d2r = numpy.pi / 180.0
     cm = cosmology.MultiEpoch(0.0, 5.0)
     wa = kernel.WindowFunctionGalaxy(kernel.dNdzMagLim(0.0, 2.0, 2.0, 0.3, 2.0), cm)
+    if ggl:
+        wb = kernel.WindowFunctionConvergence(kernel.dNdzGaussian(0.0, 2.0, 1.0, 0.2), cm)
+        return kernel.GalaxyGalaxyLensingKernel(1e-6 * d2r, 100.0 * d2r, wa, wb, cm)
     wb = kernel.WindowFunctionGalaxy(kernel.dNdzMagLim(0.0, 2.0, 2.0, 0.3, 2.0), cm)
-    kern = kernel.Kernel(1e-6 * d2r, 100.0 * d2r, wa, wb, cm)
-    h = halo.Halo(0.0)
-    corr = correlation.Correlation(0.001, 1.0, kern, input_halo=h, power_spec="power_gg")
-    theta = numpy.logspace(-3, 0, 1024) * d2r
-    w = corr.correlation(theta)
-    assert w.shape == (1024,) and numpy.all(numpy.isfinite(w))
-    assert rel_err(corr.correlation(g["theta"]), g["w_power_gg"]) < RTOL
-    # w(theta) is smooth: the full-size run interpolates onto the golden angles
-    interp = numpy.exp(numpy.interp(numpy.log(g["theta"]), numpy.log(theta), numpy.log(w)))
-    assert rel_err(interp, g["w_power_gg"]) < 5e-4
-    halves = numpy.concatenate([corr.correlation(theta[:500]), corr.correlation(theta[500:])])
-    assert numpy.array_equal(halves, w)
-    cf = correlation.CorrelationFourier(10, 1e4, kern, input_halo=h, powSpec="power_gg")
-    ell = numpy.logspace(1, 4, 2048)
-    cl = cf.correlation(ell)
-    assert cl.shape == (2048,) and numpy.all(cl > 0)
-    ref_ell = g["ell"]
-    near = numpy.array([numpy.argmin(numpy.abs(numpy.log(ell / x))) for x in ref_ell])
-    # C_l is smooth: compare through log-log interpolation at the golden multipoles
-    interp = numpy.exp(numpy.interp(numpy.log(ref_ell), numpy.log(ell), numpy.log(cl)))
-    assert rel_err(interp, g["cl_power_gg"]) < 5e-4
-    assert rel_err(cf.correlation(ref_ell), g["cl_power_gg"]) < RTOL
-    assert numpy.array_equal(cf.correlation(ell[near]), cl[near])
+    return kernel.Kernel(1e-6 * d2r, 100.0 * d2r, wa, wb, cm)
+
+
+def test_c4_full_size_vs_reference():
+    """G6b / configs[3] at full size: all 1024 theta and 2048 l, power_gg and power_mm, against
+    the reference's own vectors (1e-9: the same Romberg rows on the same integrand values).
+    Evaluating in chunks must give identical values (every theta / l is an independent
+    integral: the sharding unit)."""
+    from chomp_amd import correlation, halo
+    g = load_golden("g6b_limber_galgal_full")
+    kern = _full_size_projection(False)
+    for ps in ("power_gg", "power_mm"):
+        h = halo.Halo(0.0)
+        corr = correlation.Correlation(0.001, 1.0, kern, input_halo=h, power_spec=ps)
+        w = corr.correlation(g["theta"])
+        assert w.shape == (1024,)
+        assert rel_err(w, g["w_" + ps]) < PROJ_RTOL, ps
+        cf = correlation.CorrelationFourier(10, 1e4, kern, input_halo=h, powSpec=ps)
+        cl = cf.correlation(g["ell"])
+        assert cl.shape == (2048,) and numpy.all(cl > 0)
+        assert rel_err(cl, g["cl_" + ps]) < PROJ_RTOL, ps
+        if ps == "power_gg":
+            halves = numpy.concatenate([corr.correlation(g["theta"][:500]),
+                                        corr.correlation(g["theta"][500:])])
+            assert numpy.array_equal(halves, w)
+            pick = numpy.arange(3, 2048, 97)
+            assert numpy.array_equal(cf.correlation(g["ell"][pick]), cl[pick])
+
+
+def test_c5_full_size_vs_reference():
+    """G7b / configs[4] at full size: w_GGL at 1024 theta and C_l at 2048 l, J2 kernel +
+    HaloFit power_gm, in the fixture's call order (HaloFit built and first evaluated at z = 0)."""
+    from chomp_amd import correlation, halo
+    g = load_golden("g7b_ggl_halofit_full")
+    kern = _full_size_projection(True)
+    hf = halo.HaloFit(0.0)
+    hf.power_mm(numpy.logspace(-3, 2, 8))
+    corr = correlation.Correlation(0.001, 1.0, kern, input_halo=hf, power_spec="power_gm")
+    assert abs(corr.D_z / float(g["D_z"]) - 1) < 1e-9
+    assert rel_err(corr.correlation(g["theta"]), g["w_ggl"]) < PROJ_RTOL
+    cf = correlation.CorrelationFourier(10, 1e4, kern, input_halo=hf, powSpec="power_gm")
+    assert rel_err(cf.correlation(g["ell"]), g["cl_ggl"]) < PROJ_RTOL
 
 
 def test_stage_e_timing_facility():
@@ -486,6 +505,81 @@ def test_deep_knot_paths_agree():
             f, l = lit.ctx.deep_stats()
             assert f == 0 and l > 0
     assert n_fast > 500
+
+
+def test_deep_knots_leave_the_fast_route_by_themselves():
+    """The three exits of k_halo_knots_fast -- a self-check estimate above the threshold, more
+    break points than allowed, more node-by-node intervals than allowed -- hand a knot to
+    k_halo_knots_literal behind the launch.  With the default thresholds no knot of any tested
+    model takes them, so the thresholds are moved (CHOMP_TUNE_DEEP_TOL / _MAX_BREAKS /
+    _MAX_FINE) until SOME BUT NOT ALL knots of a 5-epoch Tinker batch leave: knots of one
+    launch then finish on both routes, in both kernels, epochs are finalised by either -- and
+    tables, stopping levels and spectra must equal the all-literal run."""
+    from chomp_amd import grid, _lib
+    z = numpy.array([0.0, 0.3, 0.7, 1.1, 1.5])
+    k = numpy.logspace(-3, 2, 120)
+    hd = dict(log_M_min=12.0, sigma=0.25, log_M_0=12.2, log_M_1p=13.2, alpha=0.9)
+
+    def run(tune):
+        hg = grid.HaloGrid(z, mass_function="tinker", hod_dict=hd)
+        hg.ctx = hg.ctx.__class__(hg.ctx.config, device=hg.ctx.device)      # (a context of its own)
+        for what, v in tune:
+            hg.ctx.set_tuning(what, v)
+        out, tabs, status = {}, {}, []
+        for w, names in (("power_gm", ("h_m", "h_g", "pp_gm")), ("power_gg", ("h_g", "pp_gg"))):
+            out[w] = hg.power(w, k)                    # (a set-up builds the requested families only)
+            for i in range(z.size):
+                for n in names + ("levels",):
+                    tabs[(w, n, i)] = hg.ctx.table(n, i)
+            status.append(hg.status())
+        f, l = hg.ctx.deep_stats()
+        return out, tabs, f, l, dict(hg.ctx.deep_detail), numpy.concatenate(status)
+
+    ref = run([(_lib.TUNE_DEEP_LITERAL, 1)])
+    assert ref[2] == 0 and ref[3] > 50
+    base = run([])
+    assert base[3] == 0 and base[2] == ref[3]
+    worst = base[4]["worst_estimate"]
+    assert 0.0 < worst < 1e-9
+
+    def same_as_literal(r, why):
+        for w in ref[0]:
+            assert numpy.max(numpy.abs(r[0][w] / ref[0][w] - 1)) < 1e-9, (why, w)
+        for key, t in ref[1].items():
+            if key[1] == "levels":             # (rows of the families this set-up built)
+                rows = [0, 2, 3] if key[0] == "power_gm" else [2, 4]
+                assert numpy.array_equal(r[1][key].reshape(5, -1)[rows], t.reshape(5, -1)[rows]), (why, key)
+            else:
+                assert numpy.max(numpy.abs(r[1][key] / t - 1)) < 1e-9, (why, key)
+        assert numpy.array_equal(r[5], ref[5]), why                  # status words
+        assert r[2] + r[3] == ref[3], why                            # every listed knot done once
+
+    # (1) the self-check: a threshold inside the range of the knots' estimates
+    mixed = None
+    for div in (3.0, 10.0, 30.0, 100.0, 1000.0, 1e4):
+        r = run([(_lib.TUNE_DEEP_TOL, max(1, int(worst / div / 1e-15)))])
+        if r[2] > 0 and r[3] > 0:
+            mixed = r
+            break
+    assert mixed is not None, "no threshold splits the knots"
+    assert mixed[4]["self_check"] == mixed[3] and mixed[4]["too_many_breaks"] == 0
+    same_as_literal(mixed, "self-check")
+    # ... and at 0 every knot that reaches the check leaves
+    r = run([(_lib.TUNE_DEEP_TOL, 0)])
+    assert r[3] > 0 and r[4]["self_check"] == r[3]
+    same_as_literal(r, "tol 0")
+    # (2) break points: pp_gm has two (<N> = 1, the satellite onset at M_0), pp_gg one
+    r = run([(_lib.TUNE_DEEP_MAX_BREAKS, 1)])
+    assert r[2] > 0 and r[3] > 0 and r[4]["too_many_breaks"] == r[3], (r[2], r[3], r[4])
+    same_as_literal(r, "max breaks 1")
+    r = run([(_lib.TUNE_DEEP_MAX_BREAKS, 0)])
+    assert r[3] > 0 and r[4]["too_many_breaks"] == r[3]
+    same_as_literal(r, "max breaks 0")
+    # (3) node-by-node intervals: alpha != 1 makes the satellite onset singular, 17 intervals
+    # above it are evaluated node by node
+    r = run([(_lib.TUNE_DEEP_MAX_FINE, 4)])
+    assert r[3] > 0 and r[4]["too_many_fine"] == r[3], (r[2], r[3], r[4])
+    same_as_literal(r, "max fine 4")
 
 
 def test_step_replays_from_a_hip_graph():

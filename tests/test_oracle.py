@@ -199,6 +199,42 @@ def test_g7_ggl_halofit():
     assert rel_err(c, g["cl_ggl"][::8]) < 1e-9
 
 
+def test_full_size_vectors_of_configs_2_3_4():
+    """G5b / G6b / G7b: the reference run at the FULL sizes of configs[2..4] (64 z x 4096 k P_gm
+    with Tinker10 + Zheng07; 1024 theta + 2048 l for the gal-gal and the GGL + HaloFit set-ups).
+    The oracle is held to them on a subsample it finishes in seconds (the full vectors are what
+    the GPU tests compare against)."""
+    g = load_golden("g5b_pgm_grid")
+    assert g["gm"].shape == (64, 257) and numpy.array_equal(g["z"], numpy.linspace(0.0, 1.5, 64))
+    for i in (0, 37, 63):
+        t = _halo(None, z=float(g["z"][i]), kind="tinker", fam=("gm",))
+        assert rel_err(o.halo_power(t, "gm", g["k"]), g["gm"][i]) < 1e-10, i
+        assert abs(t.n_bar / float(g["n_bar"][i]) - 1) < 1e-12
+    g = load_golden("g6b_limber_galgal_full")
+    assert g["w_power_gg"].shape == (1024,) and g["cl_power_gg"].shape == (2048,)
+    me, kt = _projection(False)
+    D_z = float(o.me_growth(me, kt.z_bar))
+    assert kt.z_bar == g["z_bar"] and abs(D_z / float(g["D_z"]) - 1) < 1e-13
+    t = _halo(None, z=float(kt.z_bar), fam=("mm", "gg"))
+    for ps in ("gg", "mm"):
+        power = lambda k, ps=ps: o.halo_power(t, ps, k)
+        w = o.wtheta(kt, power, g["theta"][5::128], t.k_min, t.k_max, D_z)
+        assert rel_err(w, g["w_power_" + ps][5::128]) < 1e-9
+        c = o.cell(kt, power, g["ell"][7::128], D_z)
+        assert rel_err(c, g["cl_power_" + ps][7::128]) < 1e-9
+    g = load_golden("g7b_ggl_halofit_full")
+    me, kt = _projection(True)
+    D_z = float(o.me_growth(me, kt.z_bar))
+    t0 = _halo(None, z=0.0, fam=("mm",))
+    t = _halo(None, z=float(kt.z_bar), fam=("gm",))
+    t.hf = o.halofit_table(t0)            # (the fixture's call order: sigma spline built at z = 0)
+    power = lambda k: o.halofit_power(t, "gm", k)
+    w = o.wtheta(kt, power, g["theta"][5::128], t.k_min, t.k_max, D_z)
+    assert rel_err(w, g["w_ggl"][5::128]) < 1e-9
+    c = o.cell(kt, power, g["ell"][7::128], D_z)
+    assert rel_err(c, g["cl_ggl"][7::128]) < 1e-9
+
+
 def test_g8_extrapolation_and_exclusion():
     """SURVEY 8(f) rank 2 against the reference: Halo(extrapolate=True) above k_max
     (halo.py:300-312, 341-367, 405-431) and HaloExclusion (halo.py:1201-1233)."""

@@ -40,7 +40,9 @@ def build():
 
 
 def run():
-    os.environ["CHOMP_LIB_OVERRIDE"] = SO
+    sys.path.insert(0, R)
+    from chomp_amd import _lib as _l
+    _l.LIB_PATH = SO          # (the instrumented build instead of the product library)
     sys.path.insert(0, R)
     import contextlib, warnings
     import numpy, torch

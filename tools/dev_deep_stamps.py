@@ -41,7 +41,9 @@ def build():
 
 
 def run():
-    os.environ["CHOMP_LIB_OVERRIDE"] = SO
+    sys.path.insert(0, R)
+    from chomp_amd import _lib as _l
+    _l.LIB_PATH = SO          # (the instrumented build instead of the product library)
     sys.argv = [sys.argv[0]]
     sys.path.insert(0, os.path.join(R, "tools"))
     import cell_one      # 20 calls on the deepest multipole
