@@ -507,6 +507,17 @@ int chomp_sync(chomp_ctx* ctx) {
   return CHOMP_OK;
 }
 
+#ifdef CHOMP_STAMPS
+// (development builds only: read / clear the stamps of k_halo_knots_fast)
+int chomp_debug_ks(long long* out, int n, int clear) {
+  if (clear) {
+    static long long z[kStampBlocks * kStampSlots];
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(chomp::g_ks), z, sizeof(z));
+  }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(chomp::g_ks), (size_t)n * sizeof(long long));
+}
+#endif
+
 int chomp_set_tuning(chomp_ctx* ctx, int what, long long value) {
   if (!ctx) return CHOMP_ERR_ARG;
   if (what < 0 || what >= CHOMP_TUNE_COUNT) return fail(ctx, CHOMP_ERR_ARG, "set_tuning: unknown knob");
@@ -758,8 +769,12 @@ static int launch_halo_knots(chomp_ctx* ctx, const HaloPlan& P) {
   unsigned gd = (unsigned)n;
   const bool hod_groups = P.groups[0] > 0 || P.groups[1] > 0 || P.groups[2] > 0;
   if (hod_groups && ctx->cfg.divmax > kNodeLevel) {
+    // (as many blocks as are resident at once -- two of 256 threads or one of 512 per CU, 256
+    //  CUs: a block loops over the list until it is empty, and one that starts after that only
+    //  stages its tables to find nothing left)
     unsigned want = (unsigned)(L.NK * n * ng);
-    if (want > 2048) want = 2048;
+    const unsigned resident = (size_t)L.NK * n * ng <= 768 ? 256u : 512u;
+    if (want > resident) want = resident;
     if (want > gd) gd = want;
   }
   size_t shf = deep_fast_lds<kDeepCoarse>(L.NM);

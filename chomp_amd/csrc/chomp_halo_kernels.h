@@ -24,7 +24,10 @@ namespace chomp {
 // ---------------------------------------------------------------------------
 constexpr double kPendingLevel = -1.0;   // levels-table marker: needs the deep pass
 // The work lists of the knots that run beyond the node tables (ints; one buffer per context):
-//   [0] listed items, [1] next item to hand out, [2] unused          (k_halo_knots_fast)
+//   [0] items listed at the front, [1] next item to hand out, [2] items listed at the back
+//       (the list is drawn front first: k_halo_knots puts the knots of the highest k, whose
+//       Romberg runs deepest, at the front, so that a launch ends with short knots)
+//                                                                      (k_halo_knots_fast)
 //   [4] items handed on to the literal evaluation, [5] next of those (k_halo_knots_literal)
 //   [kPendingHead ...] the items; the second list follows at pending_literal_base().
 constexpr int kPendingHead = 8;
@@ -571,11 +574,14 @@ __global__ __launch_bounds__(KNW == 0 ? 64 : 256) void k_halo_knots(
       if ((mask & (1u << fb_)) && !r.converged[1]) st |= kStHaloDivmax0 << fb_;
       if (st) atomicOr(&status[e], st);
     }
-    // work list of k_halo_knots_fast: [0] items, [1] next item to hand out, [2] epochs
-    // finalised, [kPendingHead...] items
+    // work list of k_halo_knots_fast (layout at kPendingHead): the deepest-running knots --
+    // the highest k -- at the front, the rest from the back of the buffer downwards
     if (any) {
       atomicAdd(&npend[e], 1);
-      pending[kPendingHead + atomicAdd(&pending[0], 1)] = (int)((blockIdx.z * gridDim.y + e) * NK + ik);
+      const int item = (int)((blockIdx.z * gridDim.y + e) * NK + ik);
+      const int cap = 3 * (int)gridDim.y * NK;
+      if (4 * ik >= 3 * NK) pending[kPendingHead + atomicAdd(&pending[0], 1)] = item;
+      else pending[kPendingHead + cap - 1 - atomicAdd(&pending[2], 1)] = item;
     }
   }
 }
@@ -739,6 +745,48 @@ __device__ __forceinline__ void halo_eval_coded(int group, const HaloCtx& c, dou
   *code = st;
 }
 
+// The discrete state alone (halo_eval_coded's code) at a node: everything of the integrand
+// that does not depend on k and decides its branch -- no NFW transform, no mass function.
+__device__ __forceinline__ int halo_state_at(int group, const HaloCtx& c, double ln_nu) {
+  const Epoch& E = *c.e;
+  const double nu = exp(ln_nu);
+  const double lnm = spline_eval(c.nu_knots, c.lnm_pp, c.NM, nu);
+  const double mass = exp(lnm);
+  double n1, n2;
+  zheng_node(E, mass, lnm, &n1, &n2);
+  int st = (mass - E.hod_M0 > 0.0) ? 2 : 0;
+  if (E.hod_sigma <= 0.0 && lnm * 0.43429448190325182765 > E.hod_log_M_min) st |= 4;
+  st |= ((group == 1 ? n1 : n2) < 1.0) ? 1 : 0;
+  return st;
+}
+
+// The degree-7 Lagrange interpolant through f[0..7] (nodes 0..7) at t, for a pair of arrays.
+// t outside [0, 7] extrapolates: one-sided continuation of a smooth branch up to a break point.
+__device__ __forceinline__ void lagrange8_pair(double t, const double* f0, const double* f1,
+                                               double* o0, double* o1) {
+  double d[kDeepStencil], pre[kDeepStencil], suf[kDeepStencil];
+#pragma unroll
+  for (int j = 0; j < kDeepStencil; ++j) d[j] = t - (double)j;
+  pre[0] = 1.0;
+#pragma unroll
+  for (int m = 1; m < kDeepStencil; ++m) pre[m] = pre[m - 1] * d[m - 1];
+  suf[kDeepStencil - 1] = 1.0;
+#pragma unroll
+  for (int m = kDeepStencil - 2; m >= 0; --m) suf[m] = suf[m + 1] * d[m + 1];
+  // 1 / prod_(j != m) (m - j) = (-1)^(7 - m) / (m! (7 - m)!)
+  const double cm[kDeepStencil] = {-1.0 / 5040.0, 1.0 / 720.0, -1.0 / 240.0, 1.0 / 144.0,
+                                   -1.0 / 144.0, 1.0 / 240.0, -1.0 / 720.0, 1.0 / 5040.0};
+  double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+  for (int m = 0; m < kDeepStencil; ++m) {
+    const double l = cm[m] * (pre[m] * suf[m]);
+    a0 = fma(l, f0[m], a0);
+    a1 = fma(l, f1[m], a1);
+  }
+  *o0 = a0;
+  *o1 = a1;
+}
+
 // Rows 0..top of CHOMP_ROMBERG_C into LDS ((top + 1) * 32 doubles; all threads; a barrier must
 // follow before RombergRows2::ctab is used).
 __device__ __forceinline__ void romberg_weights_to_lds(double* dst, int top) {
@@ -855,6 +903,32 @@ inline size_t deep_literal_lds(int NM, int NK) {
   return d * sizeof(double);
 }
 
+// Development stamps (tools/dev_knot_stamps.py builds with -DCHOMP_STAMPS; absent from the
+// product build): s_memtime at the phase boundaries of the first knot each block draws.
+#ifdef CHOMP_STAMPS
+constexpr int kStampBlocks = 2048, kStampSlots = 24;
+__device__ long long g_ks[kStampBlocks * kStampSlots];
+#define KSTAMP(k)                                                                     \
+  do {                                                                                \
+    if (first_item && threadIdx.x == 0 && blockIdx.x < kStampBlocks)                  \
+      g_ks[blockIdx.x * kStampSlots + (k)] = (long long)__builtin_amdgcn_s_memtime(); \
+  } while (0)
+#define KSTAMP_VALUE(k, v)                                                            \
+  do {                                                                                \
+    if (first_item && threadIdx.x == 0 && blockIdx.x < kStampBlocks)                  \
+      g_ks[blockIdx.x * kStampSlots + (k)] = (long long)(v);                          \
+  } while (0)
+#define KSTAMP_BLOCK(k, v)                                                            \
+  do {                                                                                \
+    if (threadIdx.x == 0 && blockIdx.x < kStampBlocks)                                \
+      g_ks[blockIdx.x * kStampSlots + (k)] = (long long)(v);                          \
+  } while (0)
+#else
+#define KSTAMP_BLOCK(k, v) do { } while (0)
+#define KSTAMP(k) do { } while (0)
+#define KSTAMP_VALUE(k, v) do { } while (0)
+#endif
+
 // One more arrival at epoch e (its token, or one of its listed knots done) by a whole block:
 // whoever brings npend[e] to zero finalises the epoch.  fences: knots were written by other
 // blocks of this or the previous launch's kernels since the counter was armed.
@@ -919,10 +993,16 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
   __shared__ int rough_sh[kDeepMaxRough], fine_sh[kDeepMaxFine];
   __shared__ int seg_lo[kDeepMaxRough + 1], seg_hi[kDeepMaxRough + 1];
   __shared__ double lsum_w[NWV][2][LC + 1];        // per-wavefront sums of the coarse levels
+  // per node-by-node interval: the states of its two end nodes (low / high nibble), and whether
+  // its nodes may be read off the one-sided continuations of the neighbouring smooth segments
+  __shared__ unsigned char fine_states[kDeepMaxFine], fine_poly[kDeepMaxFine];
+  // per smooth segment [lo, hi]: the sum of the samples lo .. hi - 7 (see the deep rounds)
+  __shared__ double seg_sum[2][kDeepMaxRough + 1], seg_slot[NWV][2][kDeepMaxRough + 1];
   const int NK = L.NK;
   const int tid = threadIdx.x;
   const int wv = tid >> 6, ln = tid & 63;
-  const int count = pending[0];
+  KSTAMP_BLOCK(18, __builtin_amdgcn_s_memtime());
+  const int count_front = pending[0], count = count_front + pending[2];
   // (with an empty list no block of this launch writes a knot: every value the finalisation
   //  reads comes from the previous launch, and no fence is needed)
   const bool fences = count != 0;
@@ -943,12 +1023,27 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
   copy_doubles(reinterpret_cast<double*>(&S), reinterpret_cast<const double*>(sici_g),
                (int)(sizeof(SiCiTab) / sizeof(double)));
   stage_weights();
+#ifdef CHOMP_STAMPS
+  bool first_item = true;
+  int n_items = 0;
+#endif
   for (;;) {
+#ifdef CHOMP_STAMPS
+    first_item = (n_items++ == 0);
+#endif
     __syncthreads();               // (previous item done with E, sm)
     if (tid == 0) item_sh = atomicAdd(&pending[1], 1);
     __syncthreads();
-    if (item_sh >= count) return;  // block-uniform
-    const int item = pending[kPendingHead + item_sh];
+    if (item_sh >= count) {        // block-uniform
+      KSTAMP_BLOCK(19, __builtin_amdgcn_s_memtime());
+#ifdef CHOMP_STAMPS
+      KSTAMP_BLOCK(20, n_items - 1);
+#endif
+      return;
+    }
+    const int item = item_sh < count_front
+                         ? pending[kPendingHead + item_sh]
+                         : pending[kPendingHead + 3 * n_epoch * NK - 1 - (item_sh - count_front)];
     const int ik = item % NK, e = (item / NK) % n_epoch, zg = item / (NK * n_epoch);
     const int group = zg == 0 ? g0 : (zg == 1 ? g1 : g2);
     double* t = tab + (size_t)e * L.stride;
@@ -995,6 +1090,7 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
       if (tid == 0) lit_items[atomicAdd(&pending[4], 1)] = item;
       continue;
     }
+    KSTAMP(0);
     // ---- the epoch's tables
     double* nu_knots = sm;
     double* lnm_pp = nu_knots + L.NM;
@@ -1005,6 +1101,7 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
     if (tid == 0) { n_rough_sh = 0; n_fine_sh = 0; n_seg_sh = 0; }
     if (ln <= LC) { lsum_w[wv][0][ln] = 0.0; lsum_w[wv][1][ln] = 0.0; }
     __syncthreads();
+    KSTAMP(1);
     double* red = sm + L.NM + 8 * (L.NM - 1);
     double* F0 = red + kDeepScratch;
     double* F1 = F0 + (NC + 1);
@@ -1063,6 +1160,7 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
         }
       }
       __syncthreads();
+      KSTAMP(2);
       // ---- levels 0..LC: the wavefronts' sums in a fixed order, then scipy's rows
       {
         double* lsum = red + 2 * NWV;                          // [2][LC + 1] (behind group_sum's slots)
@@ -1078,6 +1176,7 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
                 0.5 * (F1[0] + F1[NC]), pa, pb);
         for (int l = 1; l <= LC && !R.all_done(); ++l) R.advance(l, lsum[l], lsum[LC + 1 + l]);
       }
+      KSTAMP(3);
       if (!R.all_done()) {
         // ---- break points: coarse intervals whose ends are in different states
         for (int i = tid; i < NC; i += NT)
@@ -1141,6 +1240,12 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
             literal = true;
             if (stats && tid == 0) atomicAdd(&stats[3], 1);
           } else {
+            const int nf_all = n_fine_sh;
+            if (tid < nf_all) {
+              const int i = fine_sh[tid];
+              fine_states[tid] = (unsigned char)((code[i] & 15) | ((code[i + 1] & 15) << 4));
+            }
+            __syncthreads();
             // interval -> 1 + its segment (0: node by node); the states are no longer needed
             for (int i = tid; i < NC; i += NT) {
               int sg = 0;
@@ -1149,6 +1254,71 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
               code[i] = (unsigned char)sg;
             }
             __syncthreads();
+            // ---- a break-point interval between two smooth segments: on either side of the
+            // break the integrand is the smooth continuation of its neighbour's branch (each
+            // `if` of halo.py:1038-1041, 1084-1086, hod.py:189-230 switches between analytic
+            // expressions), so a node inside it need not be EVALUATED: its branch is decided by
+            // the exact discrete state at the node (halo_state_at: what does not depend on k,
+            // no NFW transform), its value read off the degree-7 polynomial through the last /
+            // first 8 samples of that neighbour, continued by less than one coarse spacing.
+            // The eighth difference at the segment's end bounds that continuation's error
+            // (0.2 of it at mid-interval); a singular satellite onset (alpha != 1) is not
+            // continued across: those intervals have no smooth neighbour on that side.
+            if (tid < nf_all) {
+              const int i = fine_sh[tid];
+              bool ok = i > 0 && i < NC - 1 && code[i - 1] != 0 && code[i + 1] != 0 &&
+                        (fine_states[tid] & 15) != (fine_states[tid] >> 4);
+              if (ok) {
+                const int sl = code[i - 1] - 1, sr = code[i + 1] - 1;
+                ok = seg_hi[sl] == i && seg_lo[sr] == i + 1 && i - seg_lo[sl] >= 8 &&
+                     seg_hi[sr] - (i + 1) >= 8;
+              }
+              if (ok) {
+                // |Delta^8 F| at the two ends against the size of the samples there
+                const double w8[9] = {1.0, -8.0, 28.0, -56.0, 70.0, -56.0, 28.0, -8.0, 1.0};
+                double dl0 = 0.0, dl1 = 0.0, dr0 = 0.0, dr1 = 0.0, sc0 = 0.0, sc1 = 0.0;
+#pragma unroll
+                for (int m = 0; m < 9; ++m) {
+                  dl0 = fma(w8[m], F0[i - 8 + m], dl0);
+                  dl1 = fma(w8[m], F1[i - 8 + m], dl1);
+                  dr0 = fma(w8[m], F0[i + 1 + m], dr0);
+                  dr1 = fma(w8[m], F1[i + 1 + m], dr1);
+                  sc0 += fabs(F0[i - 8 + m]) + fabs(F0[i + 1 + m]);
+                  sc1 += fabs(F1[i - 8 + m]) + fabs(F1[i + 1 + m]);
+                }
+                const double lim = 1e-7 / 18.0;
+                ok = fabs(dl0) <= lim * sc0 && fabs(dr0) <= lim * sc0 &&
+                     fabs(dl1) <= lim * sc1 && fabs(dr1) <= lim * sc1;
+              }
+              fine_poly[tid] = ok ? 1 : 0;
+            }
+            // ---- per smooth segment the sum of its samples lo .. hi - 7: all a deep level
+            // needs of the segment's interior (below); every segment in one pass, one exchange
+            {
+#pragma unroll
+              for (int sgi = 0; sgi <= kDeepMaxRough; ++sgi) {
+                double a0 = 0.0, a1 = 0.0;
+                if (sgi < ns) {                                  // block-uniform
+                  const int hi7 = seg_hi[sgi] - 7;
+                  for (int q = seg_lo[sgi] + tid; q <= hi7; q += NT) { a0 += F0[q]; a1 += F1[q]; }
+                  a0 = wave_sum(a0);
+                  a1 = wave_sum(a1);
+                  if (ln == 0) { seg_slot[wv][0][sgi] = a0; seg_slot[wv][1][sgi] = a1; }
+                }
+              }
+            }
+            __syncthreads();
+            if (tid < 2 * (kDeepMaxRough + 1)) {
+              const int f = tid / (kDeepMaxRough + 1), sgi = tid % (kDeepMaxRough + 1);
+              double v = 0.0;
+              if (sgi < ns) {
+#pragma unroll
+                for (int w2 = 0; w2 < NWV; ++w2) v += seg_slot[w2][f][sgi];
+              }
+              seg_sum[f][sgi] = v;
+            }
+            // (visible to the rounds below: the self-check's exchanges carry barriers)
+            KSTAMP(4);
             // ---- self-check: the same machinery one level up.  Every odd sample is predicted
             // from the even ones (stencils of twice the spacing, shifted at segment ends
             // exactly as below) and compared with its true value; at the spacing actually
@@ -1192,6 +1362,8 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
         if (tid == 0) lit_items[atomicAdd(&pending[4], 1)] = item;
         continue;
       }
+      KSTAMP(5);
+      KSTAMP_VALUE(22, n_fine_sh);
       {
         // ---- deeper levels, kDeepRound at a time (their sums are independent; what a level
         // costs here is latency -- a handful of node-by-node evaluations and two reductions --
@@ -1205,27 +1377,46 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
 #pragma unroll
           for (int g = 0; g < kDeepRound; ++g) { s0[g] = 0.0; s1[g] = 0.0; }
           const double* Wl = W + (size_t)(lv0 - LC - 1) * kDeepWStride;
-          for (int i = tid; i < NC; i += NT) {
-            const int sg = code[i];
-            if (!sg) continue;                                 // node by node below
-            const int lo = seg_lo[sg - 1], hi = seg_hi[sg - 1];
-            int st = i - 3;
-            st = st < lo ? lo : (st > hi - 7 ? hi - 7 : st);
-            double f0[kDeepStencil], f1[kDeepStencil];
-#pragma unroll
-            for (int m = 0; m < kDeepStencil; ++m) { f0[m] = F0[st + m]; f1[m] = F1[st + m]; }
-#pragma unroll
-            for (int g = 0; g < kDeepRound; ++g) {
-              if (g < ng) {
-                const double* w = Wl + g * kDeepWStride + (i - st) * kDeepStencil;
+          // The smooth segments.  Interval i of a segment [lo, hi] takes the stencil starting
+          // at st = clamp(i - 3, lo, hi - 7), offset o = i - st: o = 0, 1, 2 for the first three
+          // intervals, 4, 5, 6 for the last three, 3 for all those between -- whose total is
+          // sum_m W[3][m] D_m with D_m = sum of the samples lo + m .. hi - 7 + m: range sums that
+          // do not depend on the level (D_0 is seg_sum; D_(m+1) = D_m - F[lo + m] + F[hi - 6 + m]).
+          // One task per (segment, level of the round, {three left, interior, three right}):
+          // <= 9 x 3 x 7 threads with 8 multiply-adds each, where a pass over all 2048 intervals
+          // cost 40 LDS reads per interval and level round (6.7 us of a ~11 us round).
+          {
+            const int nseg = n_seg_sh;
+            if (tid < nseg * ng * 7) {
+              const int part = tid % 7, g = (tid / 7) % ng, sgi = tid / (7 * ng);
+              const int lo = seg_lo[sgi], hi = seg_hi[sgi];
+              const double* w = Wl + g * kDeepWStride + part * kDeepStencil;
+              double v0 = 0.0, v1 = 0.0;
+              if (part != 3) {
+                const int st = part < 3 ? lo : hi - 7;
 #pragma unroll
                 for (int m = 0; m < kDeepStencil; ++m) {
-                  s0[g] = fma(w[m], f0[m], s0[g]);
-                  s1[g] = fma(w[m], f1[m], s1[g]);
+                  v0 = fma(w[m], F0[st + m], v0);
+                  v1 = fma(w[m], F1[st + m], v1);
+                }
+              } else {
+                double d0 = seg_sum[0][sgi], d1 = seg_sum[1][sgi];
+#pragma unroll
+                for (int m = 0; m < kDeepStencil; ++m) {
+                  v0 = fma(w[m], d0, v0);
+                  v1 = fma(w[m], d1, v1);
+                  if (m < kDeepStencil - 1) {
+                    d0 += F0[hi - 6 + m] - F0[lo + m];
+                    d1 += F1[hi - 6 + m] - F1[lo + m];
+                  }
                 }
               }
+#pragma unroll
+              for (int gg = 0; gg < kDeepRound; ++gg)
+                if (gg == g) { s0[gg] += v0; s1[gg] += v1; }
             }
           }
+          if (lv0 == LC + 1) KSTAMP(10);
           // the break-point intervals: level lv0 + g has n0 << g nodes in each
           const int n0 = 1 << (lv0 - 1 - LC);
           const int per0 = nf * n0;                            // nodes of the round's first level
@@ -1234,15 +1425,32 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
             int g = 0, r = idx;
             while (r >= (per0 << g)) { r -= per0 << g; ++g; }
             const int n = n0 << g;
-            const long j = (long)fine_sh[r / n] * n + (r % n);
+            const int xi = r / n, rr = r % n, iv = fine_sh[xi];
+            const long j = (long)iv * n + rr;
             const double h = (b - a) / (double)(1L << (lv0 + g - 1));
+            const double x = (a + 0.5 * h) + h * (double)j;
             double o[2];
-            int st;
-            halo_eval_coded(group, c, (a + 0.5 * h) + h * (double)j, o, &st);
+            bool done = false;
+            if (fine_poly[xi]) {
+              const int st = halo_state_at(group, c, x);
+              const int sl = fine_states[xi] & 15, sr = fine_states[xi] >> 4;
+              if (st == sl || st == sr) {
+                const bool left = st == sl;
+                const int s0i = left ? iv - 7 : iv + 1;
+                const double t = (left ? 7.0 : -1.0) + ((double)rr + 0.5) / (double)n;
+                lagrange8_pair(t, F0 + s0i, F1 + s0i, &o[0], &o[1]);
+                done = true;
+              }
+            }
+            if (!done) {
+              int st;
+              halo_eval_coded(group, c, x, o, &st);
+            }
 #pragma unroll
             for (int gg = 0; gg < kDeepRound; ++gg)
               if (gg == g) { s0[gg] += o[0]; s1[gg] += o[1]; }
           }
+          if (lv0 == LC + 1) KSTAMP(11);
           // one exchange for the 2 ng sums
           {
             double* slot = red + (flip ? 2 * kDeepRound * NWV : 0);
@@ -1267,12 +1475,16 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
             }
             flip ^= 1;
           }
+          if (lv0 == LC + 1) KSTAMP(12);
 #pragma unroll
           for (int g = 0; g < kDeepRound; ++g)
             if (g < ng && !R.all_done()) R.advance(lv0 + g, s0[g], s1[g]);
+          KSTAMP(5 + (lv0 - LC - 1) / kDeepRound + 1);
         }
       }
     }
+    KSTAMP(16);
+    KSTAMP_VALUE(23, R.level[0] > R.level[1] ? R.level[0] : R.level[1]);
     if (tid == 0) {
       if (pa) { t[L.off_knot[fa] + ik] = R.value[0]; levs[fa * NK + ik] = (double)R.level[0]; }
       if (pb) { t[L.off_knot[fb] + ik] = R.value[1]; levs[fb * NK + ik] = (double)R.level[1]; }
@@ -1283,6 +1495,7 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
       if (stats) atomicAdd(&stats[0], 1);
     }
     deep_arrive(cfg, L, epochs_rw, tab, e, fam_mask, status, npend, fences, &last_sh, sm);
+    KSTAMP(17);
     if (!w_safe) { __syncthreads(); stage_weights(); }
   }   // next item
 }

@@ -1,5 +1,6 @@
-"""Development aid: build build_exp/knot_stamps.so = the library with s_memtime stamps at the
-phase boundaries of k_halo_knots_fast (first knot each block draws); `run` (GPU box) prints the
+"""Development aid: build build_exp/knot_stamps.so = the library compiled with -DCHOMP_STAMPS
+(s_memtime stamps at the phase boundaries of k_halo_knots_fast, first knot each block draws);
+`python tools/dev_knot_stamps.py build` here, then `run` on the GPU box prints the
 mean phase durations on configs[2] (64 epochs, power_gm, Tinker10) and on one epoch.
 Not part of the product."""
 import os, subprocess, sys, ctypes
@@ -9,50 +10,20 @@ NB, NS = 2048, 24
 
 
 def build():
-    H = os.path.join(R, "chomp_amd/csrc/chomp_halo_kernels.h"); C = os.path.join(R, "chomp_amd/csrc/chomp_capi.hip")
-    h0, c0 = open(H).read(), open(C).read()
-    s = h0
-
-    def rep(old, new):
-        nonlocal s
-        assert old in s, old[:70]
-        s = s.replace(old, new, 1)
-    rep("template <int LC, int NT>\n// (eight wavefronts per CU",
-        "__device__ long long g_ks[%d * %d];\n#define KSTAMP(k) do { if (first_item && threadIdx.x == 0 && blockIdx.x < %d) g_ks[blockIdx.x * %d + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)\n"
-        "template <int LC, int NT>\n// (eight wavefronts per CU" % (NB, NS, NB, NS))
-    rep("  if (count == 0) return;          // nothing listed: no traffic on the queue head\n  for (;;) {\n",
-        "  if (count == 0) return;          // nothing listed: no traffic on the queue head\n  bool first_item = true; int n_items = 0;\n  for (;;) {\n    first_item = (n_items++ == 0);\n")
-    rep("    HaloLds H;\n    // (the weights of every deep level", "    KSTAMP(0);\n    HaloLds H;\n    // (the weights of every deep level")
-    rep("      // ---- coarse samples: from the", "      __syncthreads(); KSTAMP(1);\n      // ---- coarse samples: from the")
-    rep("      if (tid == 0) { n_rough_sh = 0; n_fine_sh = 0; n_seg_sh = 0; }\n      __syncthreads();\n",
-        "      if (tid == 0) { n_rough_sh = 0; n_fine_sh = 0; n_seg_sh = 0; }\n      __syncthreads();\n      KSTAMP(2);\n")
-    rep("      if (!R.all_done()) {\n        // ---- break points", "      KSTAMP(3);\n      if (!R.all_done()) {\n        // ---- break points")
-    rep("            // ---- self-check: the same machinery one level up.", "            KSTAMP(4);\n            // ---- self-check: the same machinery one level up.")
-    rep("      if (!literal) {\n        // ---- deeper levels, kDeepRound at a time",
-        "      KSTAMP(5);\n      if (!literal) {\n        if (first_item && tid == 0 && blockIdx.x < %d) g_ks[blockIdx.x * %d + 22] = n_fine_sh;\n        // ---- deeper levels, kDeepRound at a time" % (NB, NS))
-    rep("          // the break-point intervals: level lv0 + g has n0 << g nodes in each\n", "          if (lv0 == LC + 1) KSTAMP(10);\n          // the break-point intervals: level lv0 + g has n0 << g nodes in each\n")
-    rep("          // one exchange for the 2 ng sums\n", "          if (lv0 == LC + 1) KSTAMP(11);\n          // one exchange for the 2 ng sums\n")
-    rep("            flip ^= 1;\n          }\n#pragma unroll\n          for (int g = 0; g < kDeepRound; ++g)\n            if (g < ng && !R.all_done()) R.advance(lv0 + g, s0[g], s1[g]);", "            flip ^= 1;\n          }\n          if (lv0 == LC + 1) KSTAMP(12);\n#pragma unroll\n          for (int g = 0; g < kDeepRound; ++g)\n            if (g < ng && !R.all_done()) R.advance(lv0 + g, s0[g], s1[g]);")
-    rep("            if (g < ng && !R.all_done()) R.advance(lv0 + g, s0[g], s1[g]);\n        }\n",
-        "            if (g < ng && !R.all_done()) R.advance(lv0 + g, s0[g], s1[g]);\n          KSTAMP(5 + (lv0 - LC - 1) / kDeepRound + 1);\n        }\n")
-    rep("    arrive(e, false);\n  }   // next item", "    KSTAMP(16);\n    if (first_item && tid == 0 && blockIdx.x < %d) g_ks[blockIdx.x * %d + 23] = lev[0] > lev[1] ? lev[0] : lev[1];\n    arrive(e, false);\n    KSTAMP(17);\n  }   // next item" % (NB, NS))
-    c = c0.replace('int chomp_set_tuning(chomp_ctx* ctx, int what, long long value) {',
-                   'int chomp_debug_ks(long long* out, int n, int clear) {\n  if (clear) { static long long z[%d]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(chomp::g_ks), z, sizeof(z)); }\n'
-                   '  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(chomp::g_ks), (size_t)n * sizeof(long long));\n}\n\nint chomp_set_tuning(chomp_ctx* ctx, int what, long long value) {' % (NB * NS))
-    try:
-        open(H, "w").write(s); open(C, "w").write(c)
-        os.makedirs(os.path.join(R, "build_exp"), exist_ok=True)
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                               "-o", SO, "chomp_capi.hip"], cwd=os.path.join(R, "chomp_amd/csrc"))
-    finally:
-        open(H, "w").write(h0); open(C, "w").write(c0)
+    """The library with -DCHOMP_STAMPS (the KSTAMP macros of chomp_halo_kernels.h)."""
+    sys.path.insert(0, R)
+    from chomp_amd import _lib
+    os.makedirs(os.path.join(R, "build_exp"), exist_ok=True)
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + _lib.HIPCC_FLAGS + ["-DCHOMP_STAMPS", "-o", SO, "chomp_capi.hip"],
+                          cwd=os.path.join(R, "chomp_amd/csrc"))
     print("built", SO)
 
 
 def run():
     sys.path.insert(0, R)
     from chomp_amd import _lib as _l
-    _l.LIB_PATH = SO          # (the instrumented build instead of the product library)
+    _l.LIB_PATH = SO          # (the instrumented build instead of the product library ...)
+    _l.build = lambda *a, **k: SO      # (... which must not be rebuilt over it)
     sys.path.insert(0, R)
     import numpy, torch
     from chomp_amd import grid, _lib
@@ -92,7 +63,17 @@ def run():
         tot = (a[ok, 16] - a[ok, 0]) / T
         print("  whole knot       n %4d  mean %6.2f  max %6.2f us;  arrive %5.2f us" % (ok.sum(), tot.mean(), tot.max(), ((a[ok, 17] - a[ok, 16]) / T).mean()))
         print("  final level histogram 11..20:", numpy.bincount(a[ok, 23].astype(int), minlength=21)[11:])
-        print("  launch span (first stamp -> last stamp) %.1f us" % ((a[:, 17].max() - a[:, 0].min()) / T))
+        b = numpy.array(out[:], dtype=numpy.int64).reshape(NB, NS)
+        b = b[b[:, 18] > 0]
+        t0 = b[:, 18].min()
+        print("  blocks %d: start %.1f..%.1f us, end mean %.1f max %.1f us; items per block: %s" % (
+            len(b), 0.0, (b[:, 18].max() - t0) / T, ((b[:, 19] - t0) / T).mean(), (b[:, 19].max() - t0) / T,
+            numpy.bincount(b[:, 20].astype(int))))
+        # (s_memtime is per XCD: only differences inside one block mean anything)
+        dur = (b[:, 19] - b[:, 18]) / T
+        print("  block lifetimes (entry -> list empty), percentiles 10/50/90/99/100: %s; by items: %s" % (
+            numpy.percentile(dur, [10, 50, 90, 99, 100]),
+            [round(float(dur[b[:, 20] == k].mean()), 1) for k in range(int(b[:, 20].max()) + 1) if (b[:, 20] == k).any()]))
 
 
 if __name__ == "__main__":
