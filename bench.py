@@ -337,8 +337,8 @@ def projection_leg(D, ggl, steps, warmup):
         if ggl:
             h._initialized_sigma_spline = False
         ctx, code = corr._prepare(defer_status=True)   # (device in, device out: no sync)
-        w = ctx.wtheta(code, 0, corr._k_lim[0], corr._k_lim[1], corr.D_z, my_theta)
-        c = ctx.cell(code, 0, corr.D_z, my_ell)
+        # (one call for both observables: C_l runs beside w(theta) on the context's side stream)
+        w, c = ctx.wtheta_cell(code, 0, corr._k_lim[0], corr._k_lim[1], corr.D_z, my_theta, my_ell)
         if D.world > 1:                      # one all-gather per output array
             w = grid.gather_samples(w, N_THETA, D.world)
             c = grid.gather_samples(c, N_ELL, D.world)

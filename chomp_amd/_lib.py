@@ -105,6 +105,7 @@ EXPORTS = [
     "chomp_set_timing", "chomp_get_timing", "chomp_get_status", "chomp_status_post",
     "chomp_status_wait", "chomp_set_tuning",
     "chomp_get_deep_stats", "chomp_stage_k", "chomp_power_plan", "chomp_get_stream",
+    "chomp_wtheta_cell", "chomp_stage_k_halofit",
 ]
 
 # chomp_get_status bits (include/chomp_mi355x.h)
@@ -275,6 +276,8 @@ def lib():
         L.chomp_stage_k.argtypes = [vp, ctypes.POINTER(HaloPar), i, ctypes.POINTER(HaloPar),
                                     ctypes.POINTER(HodPar), ctypes.c_uint]
         L.chomp_halofit_setup.argtypes = [vp, sz, sz, d, d, d, d, d]
+        L.chomp_stage_k_halofit.argtypes = [vp, ctypes.POINTER(HaloPar), i, ctypes.POINTER(HaloPar),
+                                            ctypes.POINTER(HodPar), ctypes.c_uint, sz, d, d, d, d, d]
         L.chomp_power.argtypes = [vp, i, vp, sz, vp, i]
         L.chomp_power_range.argtypes = [vp, i, sz, sz, vp, sz, vp, i]
         L.chomp_power_plan.argtypes = [vp, sz, vp, sz]
@@ -297,6 +300,7 @@ def lib():
         L.chomp_window_eval.argtypes = [vp, i, vp, sz, vp, i]
         L.chomp_wtheta.argtypes = [vp, i, sz, d, d, d, vp, sz, vp, i]
         L.chomp_cell.argtypes = [vp, i, sz, d, vp, sz, vp, i]
+        L.chomp_wtheta_cell.argtypes = [vp, i, sz, d, d, d, vp, sz, vp, vp, sz, vp, i]
         L.chomp_set_precision.argtypes = [vp, i]
         L.chomp_hod_stats.argtypes = [vp, sz, sz, c_double_p]
         L.chomp_set_transfer.argtypes = [vp, i]
@@ -518,6 +522,17 @@ class Context(object):
         assert len(ma) == n and len(pa) == n and len(ha) == n
         self._check(self._L.chomp_stage_k(self._h, ma, int(mf_kind), pa, ha, int(tables)))
 
+    def stage_k_halofit(self, mass_halo, mf_kind, profile, hods, tables, epoch, f1, f2, f3,
+                        omega_l, w):
+        """stage_k + halofit_setup(epoch, epoch, ...) in one call (chomp_stage_k_halofit)."""
+        n = self.n_epoch
+        ma = mass_halo if isinstance(mass_halo, ctypes.Array) else self.pack_halo(mass_halo, n)
+        pa = profile if isinstance(profile, ctypes.Array) else self.pack_halo(profile, n)
+        ha = hods if isinstance(hods, ctypes.Array) else self.pack_hod(hods, n)
+        assert len(ma) == n and len(pa) == n and len(ha) == n
+        self._check(self._L.chomp_stage_k_halofit(self._h, ma, int(mf_kind), pa, ha, int(tables),
+                                                  epoch, f1, f2, f3, omega_l, w))
+
     def halofit_setup(self, dst, src, f1, f2, f3, omega_l, w):
         self._check(self._L.chomp_halofit_setup(self._h, dst, src, f1, f2, f3,
                                                 omega_l, w))
@@ -734,6 +749,33 @@ class Context(object):
     def wtheta(self, which, epoch, k_min, k_max, D_z, theta):
         return self._map1(self._L.chomp_wtheta, theta, int(which), epoch,
                           float(k_min), float(k_max), float(D_z))
+
+    def wtheta_cell(self, which, epoch, k_min, k_max, D_z, theta, ell):
+        """(w(theta), C_l) of one set-up in one call (chomp_wtheta_cell): with torch cuda
+        tensors C_l is computed beside w(theta) on the context's side stream; same numbers as
+        wtheta() and cell()."""
+        if _is_torch(theta):
+            import torch
+            assert _is_torch(ell)
+            for x in (theta, ell):
+                assert x.is_cuda and x.dtype == torch.float64 and x.is_contiguous()
+            w, c = torch.empty_like(theta), torch.empty_like(ell)
+            pair = self._torch_enter()
+            self._check(self._L.chomp_wtheta_cell(
+                self._h, int(which), epoch, float(k_min), float(k_max), float(D_z),
+                ctypes.c_void_p(theta.data_ptr()), theta.numel(), ctypes.c_void_p(w.data_ptr()),
+                ctypes.c_void_p(ell.data_ptr()), ell.numel(), ctypes.c_void_p(c.data_ptr()), DEVICE))
+            self._torch_leave(pair)
+            return w, c
+        th = numpy.ascontiguousarray(theta, dtype=numpy.float64).ravel()
+        el = numpy.ascontiguousarray(ell, dtype=numpy.float64).ravel()
+        w, c = numpy.empty_like(th), numpy.empty_like(el)
+        if th.size and el.size:
+            self._check(self._L.chomp_wtheta_cell(
+                self._h, int(which), epoch, float(k_min), float(k_max), float(D_z),
+                ctypes.c_void_p(th.ctypes.data), th.size, ctypes.c_void_p(w.ctypes.data),
+                ctypes.c_void_p(el.ctypes.data), el.size, ctypes.c_void_p(c.ctypes.data), HOST))
+        return w, c
 
     def set_timing(self, on=True):
         self._check(self._L.chomp_set_timing(self._h, int(bool(on))))

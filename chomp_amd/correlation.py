@@ -111,13 +111,16 @@ class Correlation(object):
         """Halo tables and projection tables in ONE device context.  defer_status: see
         Halo._sync (the device-resident evaluation path synchronises nowhere)."""
         code, need = _POWER[self._power_name if power_name is None else power_name]
+        # The projection tables first: their set-up runs on the context's side stream, beside
+        # the halo set-up queued next (neither needs anything of the other).
+        self.kernel._setup_on(self.halo._context())
         if isinstance(self.halo, halo_mod.HaloFit) and code != _lib.P_LIN:
-            self.halo._ensure_halofit(defer_status=defer_status)
             code |= _lib.P_HALOFIT
             if (code & 15) == _lib.P_MM:
                 need = 0
-        ctx = self.halo._sync(need, defer_status=defer_status)
-        self.kernel._setup_on(ctx)
+            ctx = self.halo._ensure_halofit(need, defer_status=defer_status)
+        else:
+            ctx = self.halo._sync(need, defer_status=defer_status)
         return ctx, self.halo._power_code(code)
 
     def compute_correlation(self):

@@ -158,6 +158,15 @@ struct chomp_ctx {
 
   // projection
   ProjState proj;
+  // The side stream.  The projection set-up (chomp_kernel_setup / chomp_multi_epoch_setup:
+  // a chain of six small launches) depends on nothing the halo set-up produces, and C_l on
+  // nothing w(theta) produces: they run here, beside the context's stream, ordered against it
+  // by events -- behind everything queued on `stream` when they start, and joined back before
+  // anything reads what they wrote (proj_pending: lazily, at the next call that looks at the
+  // projection tables).  Never while `stream` is being captured.
+  hipStream_t side = nullptr;
+  hipEvent_t ev_side_go = nullptr, ev_proj_ready = nullptr, ev_side_done = nullptr;
+  bool proj_pending = false;
 };
 
 namespace {
@@ -232,6 +241,58 @@ int upload(chomp_ctx* ctx, void* dst, const void* src, size_t bytes, StagedBlock
   b.used[t] = true;
   b.turn = t ^ 1;
   b.shadow.assign(static_cast<const char*>(src), static_cast<const char*>(src) + bytes);
+  return CHOMP_OK;
+}
+
+// -- the side stream ------------------------------------------------------------------
+int side_create(chomp_ctx* ctx) {
+  if (ctx->side) return CHOMP_OK;
+  HIPCHK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+  for (hipEvent_t* e : {&ctx->ev_side_go, &ctx->ev_proj_ready, &ctx->ev_side_done})
+    HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  return CHOMP_OK;
+}
+
+// While alive, everything the context queues goes to the side stream, which first waits for
+// what `stream` holds now; on destruction `done` (if any) is recorded there and the context's
+// stream restored.  on() is false (nothing redirected) under stream capture or on failure.
+struct SideScope {
+  chomp_ctx* ctx;
+  hipStream_t saved = nullptr;
+  hipEvent_t* done;                // (a member of *ctx: the events are created by begin())
+  bool active = false;
+  SideScope(chomp_ctx* c, hipEvent_t* done_) : ctx(c), done(done_) {}
+  int begin() {
+    if (capturing(ctx)) return CHOMP_OK;
+    const int rc = side_create(ctx);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(ctx->ev_side_go, ctx->stream));
+    HIPCHK(hipStreamWaitEvent(ctx->side, ctx->ev_side_go, 0));
+    saved = ctx->stream;
+    ctx->stream = ctx->side;
+    active = true;
+    return CHOMP_OK;
+  }
+  bool on() const { return active; }
+  void end() {
+    if (!active) return;
+    (void)hipEventRecord(*done, ctx->side);
+    ctx->stream = saved;
+    active = false;
+  }
+  ~SideScope() { end(); }
+};
+
+// Before anything on the context's stream reads (or rewrites) the projection tables: wait for
+// a projection set-up still in flight on the side stream.
+int proj_join(chomp_ctx* ctx) {
+  if (!ctx->proj_pending) return CHOMP_OK;
+  if (capturing(ctx))
+    return fail(ctx, CHOMP_ERR_STATE,
+                "a projection set-up is still in flight beside the stream being captured: make "
+                "any projection call (or chomp_sync) before the capture begins");
+  HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_proj_ready, 0));
+  ctx->proj_pending = false;
   return CHOMP_OK;
 }
 
@@ -442,6 +503,7 @@ int chomp_ctx_create(const chomp_config* cfg, int device, void* hip_stream,
 void chomp_ctx_destroy(chomp_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  if (ctx->side) (void)hipStreamSynchronize(ctx->side);
   (void)hipStreamSynchronize(ctx->stream);
   void* ptrs[] = {ctx->d_sici, ctx->d_j0, ctx->d_j2, ctx->d_tinker, ctx->d_gl16,
                   ctx->d_cand, ctx->d_cosmo, ctx->d_z, ctx->d_epochs, ctx->d_search, ctx->d_probe, ctx->d_count, ctx->d_pending,
@@ -462,6 +524,9 @@ void chomp_ctx_destroy(chomp_ctx* ctx) {
   proj_free(ctx->proj);
   for (hipEvent_t e : ctx->ev)
     if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {ctx->ev_side_go, ctx->ev_proj_ready, ctx->ev_side_done})
+    if (e) (void)hipEventDestroy(e);
+  if (ctx->side) (void)hipStreamDestroy(ctx->side);
   if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -503,6 +568,7 @@ int chomp_get_stream(chomp_ctx* ctx, void** out) {
 int chomp_sync(chomp_ctx* ctx) {
   if (!ctx) return CHOMP_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
+  { const int rcj = proj_join(ctx); if (rcj) return rcj; }
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return CHOMP_OK;
 }

@@ -100,13 +100,17 @@ class Halo(object):
 
     status = property(lambda self: self._resolve_status())
 
+    def _context(self):
+        """The device context of this object (created on first use)."""
+        if self._ctx is None:
+            self._ctx = cosmology._context()
+        return self._ctx
+
     def _sync(self, need_tables, defer_status=False):
         """Bring the device tables named by the CHOMP_T_* mask up to date.  defer_status: leave
         the status word on the device (no synchronisation here); it is read by whoever next
         looks at .status, brings a result to the host, or rebuilds the tables."""
-        if self._ctx is None:
-            self._ctx = cosmology._context()
-        ctx = self._ctx
+        ctx = self._context()
         bao = bool(getattr(self.cosmo, "_with_bao", False))
         esig = (tuple(sorted(self.cosmo.cosmo_dict.items())), self.cosmo._redshift, bao)
         if esig != self._epoch_sig:
@@ -118,8 +122,8 @@ class Halo(object):
             self._nbar_valid = False
             self._after_epochs_set()
         msig = (tuple(sorted(self.mass.halo_dict.items())), self.mass._kind)
-        if msig != self._mass_sig:
-            ctx.mass_setup(self.mass.halo_dict, self.mass._kind)
+        new_mass = msig != self._mass_sig
+        if new_mass:
             self._mass_sig = msig
             self._nbar_valid = False
         build = 0
@@ -128,8 +132,11 @@ class Halo(object):
                 build |= bit
         if build or not self._nbar_valid:
             self._resolve_status(stacklevel=6)     # (the next set-up clears the device's words)
-            ctx.halo_setup(self._profile(), self.local_hod,
-                           build | (_lib.T_EXCLUSION if self._exclusion else 0))
+            tables = build | (_lib.T_EXCLUSION if self._exclusion else 0)
+            if new_mass:       # mass function and halo model in one call: one launch fewer
+                self._stage_k(ctx, tables)
+            else:
+                ctx.halo_setup(self._profile(), self.local_hod, tables)
             for flag, bit in _FLAG_BITS:
                 if build & bit:
                     setattr(self, flag, True)
@@ -139,6 +146,9 @@ class Halo(object):
         if not defer_status:
             self._resolve_status(stacklevel=5)
         return ctx
+
+    def _stage_k(self, ctx, tables):
+        ctx.stage_k(self.mass.halo_dict, self.mass._kind, self._profile(), self.local_hod, tables)
 
     def _before_epochs_set(self):
         pass
@@ -422,8 +432,28 @@ class HaloFit(Halo):
         if self._initialized_sigma_spline and self._hf_coef is not None:
             self._ctx.halofit_put(self._hf_coef, 0)
 
-    def _ensure_halofit(self, defer_status=False):
-        ctx = self._sync(0, defer_status=defer_status)
+    def _stage_k(self, ctx, tables):
+        """The first set-up of a HaloFit object builds its sigma spline as well: one call, the
+        HaloFit kernels beside the halo model's knot integrals (chomp_stage_k_halofit)."""
+        # (only on the way to a spectrum: the reference builds the spline at its first power_*
+        #  call, halo.py:1337-1338 -- a set-up made for n_bar or a table must not fix its redshift)
+        if self._initialized_sigma_spline or not getattr(self, "_building_halofit", False):
+            return Halo._stage_k(self, ctx, tables)
+        ctx.stage_k_halofit(self.mass.halo_dict, self.mass._kind, self._profile(), self.local_hod,
+                            tables, 0, float(self._f_1), float(self._f_2), float(self._f_3),
+                            float(self._omega_l), float(self._w))
+        self._hf_coef = None
+        self._initialized_sigma_spline = True
+
+    def _ensure_halofit(self, need=0, defer_status=False):
+        """The sigma spline (built once, at whatever redshift the object then has: halo.py:
+        1337-1338) and the knot tables of `need`, in one pass over the device where both are
+        missing."""
+        self._building_halofit = True
+        try:
+            ctx = self._sync(need, defer_status=defer_status)
+        finally:
+            self._building_halofit = False
         if not self._initialized_sigma_spline:
             ctx.halofit_setup(0, 0, float(self._f_1), float(self._f_2),
                               float(self._f_3), float(self._omega_l), float(self._w))
@@ -437,11 +467,11 @@ class HaloFit(Halo):
         return self._power(_lib.P_MM | _lib.P_HALOFIT, 0, k)
 
     def power_gm(self, k):
-        self._ensure_halofit()
+        self._ensure_halofit(_lib.FAM_GM)
         return self._power(_lib.P_GM | _lib.P_HALOFIT, _lib.FAM_GM, k)
 
     def power_gg(self, k):
-        self._ensure_halofit()
+        self._ensure_halofit(_lib.FAM_GG)
         return self._power(_lib.P_GG | _lib.P_HALOFIT, _lib.FAM_GG, k)
 
 

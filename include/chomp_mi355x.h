@@ -152,6 +152,15 @@ int chomp_stage_k(chomp_ctx* ctx, const chomp_halo_par* mass_par, int mf_kind,
                   const chomp_halo_par* profile, const chomp_hod_par* hod,
                   unsigned tables);
 
+/* chomp_stage_k followed by chomp_halofit_setup(epoch, epoch, ...) in one call -- a HaloFit
+ * object's first set-up (halo.py:1236-1266 then 1268-1319).  Same results, bit for bit; the
+ * HaloFit sigma table and fit run on a second HIP stream beside the halo model's knot
+ * integrals (neither needs the other's results) and are joined before the call returns. */
+int chomp_stage_k_halofit(chomp_ctx* ctx, const chomp_halo_par* mass_par, int mf_kind,
+                          const chomp_halo_par* profile, const chomp_hod_par* hod,
+                          unsigned tables, size_t epoch, double f_1, double f_2, double f_3,
+                          double omega_l, double w);
+
 /* HaloFit._initialize_sigma_spline (halo.py:1268-1319) for epoch `src_epoch`,
  * stored as the HaloFit coefficient set of epoch `dst_epoch`; f_1..f_3, omega_l
  * and w are passed explicitly because the reference fixes them at construction
@@ -481,6 +490,16 @@ int chomp_covariance_gaussian(chomp_ctx* ctx, double j0_limit, double area,
 /* CorrelationFourier.correlation(l) (correlation.py:360-392): Limber C_l. */
 int chomp_cell(chomp_ctx* ctx, int which, size_t epoch, double D_z,
                const double* ell, size_t n, double* out, int mem);
+
+/* Both observables of one survey set-up -- Correlation.correlation(theta) (correlation.py:
+ * 242-275) and CorrelationFourier.correlation(l) (correlation.py:360-392) on the same kernel,
+ * halo and spectrum -- in one call: the results of chomp_wtheta and chomp_cell, bit for bit,
+ * with C_l computed beside w(theta) on a second HIP stream when the buffers are device
+ * memory (neither integral needs anything of the other).  In the order of the context's
+ * stream the call is complete when it returns. */
+int chomp_wtheta_cell(chomp_ctx* ctx, int which, size_t epoch, double k_min, double k_max,
+                      double D_z, const double* theta, size_t n_theta, double* w_out,
+                      const double* ell, size_t n_ell, double* c_out, int mem);
 
 /* SingleEpoch(..., with_bao=...) (cosmology.py:39, 87, 556-572): which Eisenstein & Hu
  * transfer function the context's epochs use -- the no-wiggle fit (default,

@@ -288,3 +288,39 @@ def test_correlation_set_cosmology_equals_fresh_object(mods):
     assert a.kernel.z_bar == 0.5
     a.set_cosmology(c2)
     assert a.kernel.z_bar == b.kernel.z_bar
+
+
+@pytest.mark.parametrize("ggl", [False, True])
+def test_wtheta_and_cell_in_one_call(mods, ggl):
+    """chomp_wtheta_cell: both observables of a set-up in one call, C_l beside w(theta) on the
+    context's side stream (device buffers) -- the numbers of the two separate calls, bit for
+    bit, from torch tensors and from host arrays; and the projection set-up, which runs on the
+    side stream beside the halo set-up, is joined before anything reads its tables."""
+    import torch
+    cosmology, kernel, correlation, halo = mods
+    cm, kern = _projection(mods, ggl)
+    h = halo.HaloFit(0.0) if ggl else halo.Halo(0.0)
+    spec = "power_gm" if ggl else "power_gg"
+    corr = correlation.Correlation(0.001, 1.0, kern, input_halo=h, power_spec=spec)
+    theta = numpy.logspace(-3, 0, 300) * D2R
+    ell = numpy.logspace(1, 4, 500)
+    for rep in range(3):
+        # forget every table: halo model and projection are rebuilt, side by side
+        kern._done.clear()
+        h._epoch_sig = None
+        h._nbar_valid = False
+        h._reset_flags(all_tables=True)
+        ctx, code = corr._prepare(defer_status=True)
+        td = torch.as_tensor(theta, device="cuda")
+        ld = torch.as_tensor(ell, device="cuda")
+        w2, c2 = ctx.wtheta_cell(code, 0, corr._k_lim[0], corr._k_lim[1], corr.D_z, td, ld)
+        w1 = ctx.wtheta(code, 0, corr._k_lim[0], corr._k_lim[1], corr.D_z, td)
+        c1 = ctx.cell(code, 0, corr.D_z, ld)
+        torch.cuda.synchronize()
+        assert torch.equal(w1, w2) and torch.equal(c1, c2), rep
+        wh, ch = ctx.wtheta_cell(code, 0, corr._k_lim[0], corr._k_lim[1], corr.D_z, theta, ell)
+        assert numpy.array_equal(wh, w1.cpu().numpy()) and numpy.array_equal(ch, c1.cpu().numpy())
+    g = load_golden("g7b_ggl_halofit_full" if ggl else "g6b_limber_galgal_full")
+    if not ggl:        # (G7b's HaloFit was first evaluated at z = 0; this one at z_bar)
+        wf, cf_ = ctx.wtheta_cell(code, 0, corr._k_lim[0], corr._k_lim[1], corr.D_z, g["theta"], g["ell"])
+        assert rel_err(wf, g["w_power_gg"]) < PROJ_RTOL and rel_err(cf_, g["cl_power_gg"]) < PROJ_RTOL
