@@ -145,7 +145,7 @@ struct chomp_ctx {
   int slow_parity = 0;
   // opt-ins for more than 64 KiB of dynamic LDS, done once per context (hipFuncSetAttribute
   // applies to the current device: a process-wide flag would skip a second device)
-  bool lds_knots_set = false;
+  bool lds_knots_set = false, lds_lns_set = false;
   unsigned lds_cell_mask = 0;      // k_cell_deep<HF, BAO>: bit 2 HF + BAO
   bool slow_by_memset = false;     // set once a Stage E call has been captured into a HIP graph
   int precision = CHOMP_PREC_F64;  // chomp_set_precision
@@ -709,23 +709,38 @@ int chomp_epochs_set(chomp_ctx* ctx, size_t n_epoch, const chomp_cosmo* cosmo,
   if (rc) return rc;
   rc = upload(ctx, ctx->d_first, first.data(), n_epoch * sizeof(int), ctx->sh_first);
   if (rc) return rc;
-  const dim3 gs(kSigmaNodeBlocks + kSGrid + kGTabBlocks, (unsigned)(n_slots + (n_epoch + 255) / 256));
-  const dim3 gi((unsigned)n_epoch, 2 * kProbes);
-  if (ctx->with_bao) {
-    hipLaunchKernelGGL(k_sigma_nodes<true>, gs, dim3(256), 0, ctx->stream, ctx->cfg, ctx->d_cosmo,
-                       ctx->d_z, ctx->d_first, ctx->d_slot, (int)n_slots, (int)n_epoch,
-                       ctx->d_epochs, ctx->d_snodes, ctx->d_status);
-    hipLaunchKernelGGL(k_epoch_probe<true>, gi, dim3(64 * kInitNW), 0, ctx->stream, ctx->cfg,
-                       ctx->d_epochs, ctx->d_search, ctx->d_cand, ctx->d_snodes, ctx->d_probe,
-                       ctx->d_count, ctx->d_status);
+  // (one cosmology or a few: most blocks, shortest launch; a batch of many: four nodes per
+  //  thread and the ln S integrals one per wavefront -- see k_sigma_nodes)
+  const unsigned gy = (unsigned)(n_slots + (n_epoch + 255) / 256);
+#define CHOMP_SIGMA_NODES(BAO, NPT)                                                              \
+  hipLaunchKernelGGL((k_sigma_nodes<BAO, NPT>),                                                   \
+                     dim3(sigma_node_blocks<NPT>() + sigma_lns_blocks<NPT>() + sigma_gtab_blocks<NPT>(), gy), \
+                     dim3(256), 0, ctx->stream, ctx->cfg, ctx->d_cosmo, ctx->d_z, ctx->d_first,    \
+                     ctx->d_slot, (int)n_slots, (int)n_epoch, ctx->d_epochs, ctx->d_snodes,         \
+                     ctx->d_status)
+  if (n_slots >= 16) {
+    if (ctx->with_bao) CHOMP_SIGMA_NODES(true, 4); else CHOMP_SIGMA_NODES(false, 4);
+    // ... and the aiming tables behind them (the g table of a cosmology staged in LDS)
+    const size_t shl = (size_t)kGTabCount * sizeof(double);
+    if (!ctx->lds_lns_set) {
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sigma_lns<false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shl));
+      ctx->lds_lns_set = true;
+    }
+    if (ctx->with_bao)
+      hipLaunchKernelGGL(k_sigma_lns<true>, dim3((unsigned)n_slots), dim3(kLnsThreads), 0, ctx->stream,
+                         ctx->cfg, ctx->d_cosmo, ctx->d_z, ctx->d_first, ctx->d_snodes);
+    else
+      hipLaunchKernelGGL(k_sigma_lns<false>, dim3((unsigned)n_slots), dim3(kLnsThreads), shl, ctx->stream,
+                         ctx->cfg, ctx->d_cosmo, ctx->d_z, ctx->d_first, ctx->d_snodes);
   } else {
-    hipLaunchKernelGGL(k_sigma_nodes<false>, gs, dim3(256), 0, ctx->stream, ctx->cfg, ctx->d_cosmo,
-                       ctx->d_z, ctx->d_first, ctx->d_slot, (int)n_slots, (int)n_epoch,
-                       ctx->d_epochs, ctx->d_snodes, ctx->d_status);
-    hipLaunchKernelGGL(k_epoch_probe<false>, gi, dim3(64 * kInitNW), 0, ctx->stream, ctx->cfg,
-                       ctx->d_epochs, ctx->d_search, ctx->d_cand, ctx->d_snodes, ctx->d_probe,
-                       ctx->d_count, ctx->d_status);
+    if (ctx->with_bao) CHOMP_SIGMA_NODES(true, 1); else CHOMP_SIGMA_NODES(false, 1);
   }
+#undef CHOMP_SIGMA_NODES
+  // (k_epoch_probe lives in chomp_probe.hip: the one kernel that is faster WITH machine LICM)
+  chomp::launch_epoch_probe(ctx->with_bao != 0, (unsigned)n_epoch, ctx->stream, ctx->cfg,
+                            ctx->d_epochs, ctx->d_search, ctx->d_cand, ctx->d_snodes,
+                            ctx->d_probe, ctx->d_count, ctx->d_status);
   HIPCHK(hipGetLastError());
   ctx->have_epochs = true;
   return CHOMP_OK;

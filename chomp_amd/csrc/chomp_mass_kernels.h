@@ -171,6 +171,44 @@ constexpr int kGTabBlocks = (kGTabCount + 255) / 256;
 // doubles per cosmology: ..., then g / k^6 [kGTabCount] and k [kGTabCount]
 constexpr int kSigmaStride = kSigmaOffG + 2 * kGTabCount;
 
+// The same integrand where sigma_r's limits follow R: Delta^2 W^2 with the R-independent
+// factor and k interpolated from the cosmology's uniform ln k table (kGTab*; 6-point
+// Lagrange, k through a short series of exp over the fraction of a step).
+struct SigmaInterpIntegrand {
+  const double* g;         // g / k^6 on the grid (index 0 = first pad point)
+  double xlo, dx, inv_dx;
+  double scale, amp2_nine_over_r6, amp2;
+  // k R < 1 over the whole range (wave-uniform): the window in the reference's own form
+  // 3 (sin x / x^3 - cos x / x^2), whose rounding error at x << 1 is what ends a saturated
+  // mass-limit walk (search_status); s - x c is exactly 0 there and would never end it
+  bool tiny_r;
+  __device__ __forceinline__ double operator()(double ln_k) const {
+    const double u = (ln_k - xlo) * inv_dx;
+    int i = (int)u;
+    i = i < 0 ? 0 : (i > kGTabN - 1 ? kGTabN - 1 : i);
+    const double t = u - (double)i;
+    const double* q = g + i + kGTabPad - 2;            // stencil nodes -2 .. 3 around interval i
+    const double a = t + 2.0, b = t + 1.0, d = t - 1.0, e = t - 2.0, f = t - 3.0;
+    const double ab = a * b, ef = e * f, cd = t * d;
+    const double gv = q[0] * (b * cd * ef) * (-1.0 / 120.0) + q[1] * (a * cd * ef) * (1.0 / 24.0) +
+                      q[2] * (ab * d * ef) * (-1.0 / 12.0) + q[3] * (ab * t * ef) * (1.0 / 12.0) +
+                      q[4] * (ab * cd * f) * (-1.0 / 24.0) + q[5] * (ab * cd * e) * (1.0 / 120.0);
+    const double y = t * dx;                           // <= 2.6e-3: four terms reach 1e-16
+    const double ey = fma(y, fma(y, fma(y, fma(y, 1.0 / 24.0, 1.0 / 6.0), 0.5), 1.0), 1.0);
+    const double k = q[2 + kGTabCount] * ey;
+    const double kR = scale * k;
+    double s, c;
+    fast_sincos(kR, &s, &c);
+    if (tiny_r) {
+      const double kR2 = kR * kR, k3 = k * k * k;
+      const double W = 3.0 * (s / (kR2 * kR) - c / kR2);
+      return amp2 * (gv * (k3 * k3)) * (W * W);
+    }
+    const double w = s - kR * c;
+    return amp2_nine_over_r6 * gv * (w * w);
+  }
+};
+
 // Everything here depends on the cosmology only, not on z, so it is built once per
 // distinct cosmology of the batch ("slot"; the z-axis of a (k, z) grid is one slot).
 // grid (kSigmaNodeBlocks + kSGrid, n_slots + ceil(n_epoch / 256)), block 256;
@@ -183,129 +221,16 @@ constexpr int kSigmaStride = kSigmaOffG + 2 * kGTabCount;
 // closed-form part of every epoch record (SingleEpoch.__init__ minus its two integrals),
 // one epoch per thread, while the cosmology-only integrals run.
 // BAO: the context's transfer function (chomp_set_transfer), fixed at compile time.
+// sigma_8's integral I8 = int dlnk (k/H0)^(3+n) T^2 W(8k)^2 from the per-level partial sums the
+// node-table blocks of a cosmology left (n + kSigmaOffPart: nb rows of kSigmaLevel + 1): scipy's
+// rows and stopping test on the level sums; beyond the table (or off its range) the integral
+// directly.  Whole block (>= 64 threads; barriers inside); red: romberg_scratch<4, 1>() doubles
+// when blockDim.x == 256 (the direct fallback is a four-wavefront Romberg), else one wavefront's.
 template <bool BAO>
-__global__ __launch_bounds__(256) void k_sigma_nodes(chomp_config cfg,
-                                                     const chomp_cosmo* __restrict__ cosmo,
-                                                     const double* __restrict__ zin,
-                                                     const int* __restrict__ first,
-                                                     const int* __restrict__ slots, int n_slots,
-                                                     int n_epoch, Epoch* __restrict__ epochs,
-                                                     double* __restrict__ snodes,
-                                                     unsigned* __restrict__ status) {
-  __shared__ Epoch E;
-  __shared__ double red[romberg_scratch<4, 1>()];
-  if ((int)blockIdx.y >= n_slots) {
-    const int e = ((int)blockIdx.y - n_slots) * 256 + (int)threadIdx.x;
-    if (blockIdx.x != 0 || e >= n_epoch) return;
-    Epoch B;
-    double* q = reinterpret_cast<double*>(&B);
-    for (int i = 0; i < kEpochDoubles; ++i) q[i] = 0.0;
-    const chomp_cosmo c = cosmo[e];
-    B.om0 = c.omega_m0; B.ob0 = c.omega_b0; B.ol0 = c.omega_l0; B.or0 = c.omega_r0;
-    B.tcmb = c.cmb_temp; B.h = c.h; B.sigma8 = c.sigma_8; B.ns = c.n_scalar;
-    B.z = zin[e];
-    epoch_background(B, cfg.cosmo_precision, cfg.k_min, cfg.k_max, BAO ? 1 : 0);
-    B.cosmo_slot = slots[e];
-    epochs[e] = B;
-    status[e] = 0u;
-    return;
-  }
-  const int slot = blockIdx.y, e = first[slot];
-  const int nb = kSigmaNodeBlocks;                // node-table blocks
-  if (threadIdx.x == 0) {
-    const chomp_cosmo c = cosmo[e];
-    E.om0 = c.omega_m0; E.ob0 = c.omega_b0; E.ol0 = c.omega_l0; E.or0 = c.omega_r0;
-    E.tcmb = c.cmb_temp; E.h = c.h; E.sigma8 = c.sigma_8; E.ns = c.n_scalar;
-    E.z = zin[e];
-    epoch_shape_only(E, cfg.k_min, cfg.k_max, BAO ? 1 : 0);    // (amp = 1: bare integrals)
-  }
-  __syncthreads();
-  double* n = snodes + (size_t)slot * kSigmaStride;
-  if ((int)blockIdx.x >= nb + kSGrid) {           // ---- interpolation table of the direct path
-    const int i = ((int)blockIdx.x - nb - kSGrid) * 256 + (int)threadIdx.x;
-    if (i >= kGTabCount) return;
-    const double xlo = log(cfg.k_min / 100.0), xhi = log(cfg.k_max * 100.0);
-    const double x = xlo + (xhi - xlo) * ((double)(i - kGTabPad) / (double)kGTabN);
-    const double k = exp(x);
-    const double T = transfer_t<BAO>(E, k);
-    const double k3 = k * k * k;
-    n[kSigmaOffG + i] = exp((3.0 + E.ns) * (x - E.ln_H0)) * T * T / (k3 * k3);
-    n[kSigmaOffG + kGTabCount + i] = k;
-    return;
-  }
-  if ((int)blockIdx.x >= nb) {
-    const int i = (int)blockIdx.x - nb;           // ln S point
-    const double R = exp(make_sgrid(cfg.k_min, cfg.k_max).ln_r(i));
-    double lo, hi;
-    sigma_limits(E, R, &lo, &hi);
-    SigmaIntegrandT<BAO> f{&E, R};                // sigma_norm = 1: amp * integral
-    // (the ln S points only aim the search: 1e-5 and at most 2^10 panels are plenty -- only
-    //  R > 100 Mpc/h would go on to 2^11, where the cap costs ~1e-4 of an estimate that the
-    //  probes certify anyway)
-    const double s2 = romberg1<4>(f, lo, hi, cfg.global_precision, 1e-5,
-                                  cfg.divmax < 10 ? cfg.divmax : 10, red);
-    if (threadIdx.x == 0) n[kSigmaOffLnS + i] = log(s2);
-    return;
-  }
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = idx < kSigmaCount;
+__device__ __forceinline__ void sigma8_from_parts(const chomp_config& cfg, const Epoch& E,
+                                                  double* __restrict__ n, int nb, double* red) {
   const double a = log(cfg.k_min), b = log(cfg.k_max);
-  // sigma_8 on the table's range? (cosmology.py:611-632 keeps [k_min, k_max] for R = 8
-  // with any sensible limits; otherwise the finisher integrates directly)
   const bool tab8 = 0.1 / 8.0 > cfg.k_min && 14.0662 / 8.0 < cfg.k_max && cfg.divmax >= 1;
-  int lev = 0;
-  double g = 0.0;
-  if (live) {
-    double x;
-    if (idx < 2) {
-      x = idx == 0 ? a : b;
-    } else {
-      const int m = idx - 1;
-      lev = 32 - __builtin_clz((unsigned)m);
-      const long j = m - (1 << (lev - 1));
-      const double h = (b - a) / (double)(1L << (lev - 1));
-      x = (a + 0.5 * h) + h * (double)j;
-    }
-    const double k = exp(x);
-    const double T = transfer_t<BAO>(E, k);
-    n[idx] = k;
-    // Delta^2 shape over k^6: W(kR)^2 = 9 (sin y - y cos y)^2 / (k R)^6 then needs no division
-    const double k3 = k * k * k;
-    const double d2k6 = exp((3.0 + E.ns) * (x - E.ln_H0)) * T * T / (k3 * k3);
-    n[kSigmaCount + idx] = d2k6;
-    double sn, cs;
-    fast_sincos(8.0 * k, &sn, &cs);
-    const double t = sn - 8.0 * k * cs;
-    g = d2k6 * (9.0 / 262144.0) * (t * t);        // 9 / 8^6
-  }
-  // per-level sums of this block's nodes (level-major order: a block holds <= 2 levels,
-  // block 0 levels 0..8)
-  double* part = n + kSigmaOffPart + (size_t)blockIdx.x * (kSigmaLevel + 1);
-  __shared__ double wsum[4][kSigmaLevel + 1];
-  __shared__ int last_block;
-  const int first_idx = blockIdx.x * blockDim.x, last_idx = first_idx + (int)blockDim.x - 1;
-  const int lev_lo = first_idx < 2 ? 0 : 32 - __builtin_clz((unsigned)(first_idx - 1));
-  const int lev_hi = last_idx < 2 ? 0 : 32 - __builtin_clz((unsigned)(last_idx - 1));
-  const int wv = threadIdx.x >> 6;
-  for (int l = 0; l <= kSigmaLevel; ++l) {
-    double v = 0.0;
-    if (l >= lev_lo && l <= lev_hi) v = wave_sum(live && lev == l ? g : 0.0);
-    if ((threadIdx.x & 63) == 0) wsum[wv][l] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x <= kSigmaLevel)
-    part[threadIdx.x] = ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) +
-                        wsum[3][threadIdx.x];
-  int* arrivals = reinterpret_cast<int*>(n + kSigmaOffI8 + 1);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();               // partial sums (and table) visible before the arrival counts
-    last_block = atomicAdd(arrivals, 1) == nb - 1 ? 1 : 0;
-  }
-  __syncthreads();
-  if (!last_block) return;
-  // ---- last node block of this cosmology: sigma_8 from the level sums
-  __threadfence();
   __shared__ double stage[kSigmaNodeBlocks * (kSigmaLevel + 1)];
   __shared__ double S[kSigmaLevel + 1];
   __shared__ double i8;
@@ -353,7 +278,6 @@ __global__ __launch_bounds__(256) void k_sigma_nodes(chomp_config cfg,
     if (lane == 0) {
       converged = conv;
       i8 = result;
-      *arrivals = 0;
     }
   }
   __syncthreads();
@@ -361,50 +285,258 @@ __global__ __launch_bounds__(256) void k_sigma_nodes(chomp_config cfg,
     double lo, hi;
     sigma_limits(E, 8.0, &lo, &hi);
     SigmaIntegrandT<BAO> f{&E, 8.0};              // sigma_norm = 1: amp * integral
-    const double s2 = romberg1<4>(f, lo, hi, cfg.global_precision, cfg.cosmo_precision,
-                                  cfg.divmax, red);
+    double s2;
+    if (blockDim.x == 256) {
+      s2 = romberg1<4>(f, lo, hi, cfg.global_precision, cfg.cosmo_precision, cfg.divmax, red);
+    } else {                       // (block-uniform) the first wavefront alone
+      s2 = 0.0;
+      if (threadIdx.x < 64)
+        s2 = romberg1<1>(f, lo, hi, cfg.global_precision, cfg.cosmo_precision, cfg.divmax, nullptr);
+    }
     if (threadIdx.x == 0) i8 = s2;
   }
   if (threadIdx.x == 0) n[kSigmaOffI8] = i8;
 }
 
-// The same integrand where sigma_r's limits follow R: Delta^2 W^2 with the R-independent
-// factor and k interpolated from the cosmology's uniform ln k table (kGTab*; 6-point
-// Lagrange, k through a short series of exp over the fraction of a step).
-struct SigmaInterpIntegrand {
-  const double* g;         // g / k^6 on the grid (index 0 = first pad point)
-  double xlo, dx, inv_dx;
-  double scale, amp2_nine_over_r6, amp2;
-  // k R < 1 over the whole range (wave-uniform): the window in the reference's own form
-  // 3 (sin x / x^3 - cos x / x^2), whose rounding error at x << 1 is what ends a saturated
-  // mass-limit walk (search_status); s - x c is exactly 0 there and would never end it
+// NPT: table nodes per thread.  1: most blocks, shortest launch (a (k, z) grid has ONE cosmology
+// and the launch is a link of its latency chain).  4: a batch of many cosmologies (a design, an
+// MCMC population) -- a quarter of the blocks, each paying the serial head (the transfer-function
+// constants, by one thread) once for four times the nodes; the 48 ln S integrals -- two thirds
+// of a cosmology's work when every node is evaluated directly -- are left to k_sigma_lns, behind
+// this launch.  18 blocks per cosmology instead of 114 (k_sigma_nodes was 56 % of a
+// 1024-cosmology step).  Same node values; level sums in a different order (sigma_8 to ~1e-16).
+template <int NPT>
+__host__ __device__ constexpr int sigma_node_blocks() { return (kSigmaCount + 256 * NPT - 1) / (256 * NPT); }
+template <int NPT>
+__host__ __device__ constexpr int sigma_lns_blocks() { return NPT == 1 ? kSGrid : 0; }
+template <int NPT>
+__host__ __device__ constexpr int sigma_gtab_blocks() { return (kGTabCount + 256 * NPT - 1) / (256 * NPT); }
+
+template <bool BAO, int NPT>
+__global__ __launch_bounds__(256) void k_sigma_nodes(chomp_config cfg,
+                                                     const chomp_cosmo* __restrict__ cosmo,
+                                                     const double* __restrict__ zin,
+                                                     const int* __restrict__ first,
+                                                     const int* __restrict__ slots, int n_slots,
+                                                     int n_epoch, Epoch* __restrict__ epochs,
+                                                     double* __restrict__ snodes,
+                                                     unsigned* __restrict__ status) {
+  static_assert(NPT == 1 || NPT == 4, "nodes per thread");
+  static_assert(kSGrid % 4 == 0, "four ln S points to a block");
+  __shared__ Epoch E;
+  __shared__ double red[romberg_scratch<4, 1>()];
+  if ((int)blockIdx.y >= n_slots) {
+    const int e = ((int)blockIdx.y - n_slots) * 256 + (int)threadIdx.x;
+    if (blockIdx.x != 0 || e >= n_epoch) return;
+    Epoch B;
+    double* q = reinterpret_cast<double*>(&B);
+    for (int i = 0; i < kEpochDoubles; ++i) q[i] = 0.0;
+    const chomp_cosmo c = cosmo[e];
+    B.om0 = c.omega_m0; B.ob0 = c.omega_b0; B.ol0 = c.omega_l0; B.or0 = c.omega_r0;
+    B.tcmb = c.cmb_temp; B.h = c.h; B.sigma8 = c.sigma_8; B.ns = c.n_scalar;
+    B.z = zin[e];
+    epoch_background(B, cfg.cosmo_precision, cfg.k_min, cfg.k_max, BAO ? 1 : 0);
+    B.cosmo_slot = slots[e];
+    epochs[e] = B;
+    status[e] = 0u;
+    return;
+  }
+  const int slot = blockIdx.y, e = first[slot];
+  constexpr int nb = sigma_node_blocks<NPT>();    // node-table blocks
+  constexpr int nl = sigma_lns_blocks<NPT>();     // ln S blocks
+  if (threadIdx.x == 0) {
+    const chomp_cosmo c = cosmo[e];
+    E.om0 = c.omega_m0; E.ob0 = c.omega_b0; E.ol0 = c.omega_l0; E.or0 = c.omega_r0;
+    E.tcmb = c.cmb_temp; E.h = c.h; E.sigma8 = c.sigma_8; E.ns = c.n_scalar;
+    E.z = zin[e];
+    epoch_shape_only(E, cfg.k_min, cfg.k_max, BAO ? 1 : 0);    // (amp = 1: bare integrals)
+  }
+  __syncthreads();
+  double* n = snodes + (size_t)slot * kSigmaStride;
+  if ((int)blockIdx.x >= nb + nl) {               // ---- interpolation table of the direct path
+    const double xlo = log(cfg.k_min / 100.0), xhi = log(cfg.k_max * 100.0);
+#pragma unroll
+    for (int r = 0; r < NPT; ++r) {
+      const int i = (((int)blockIdx.x - nb - nl) * NPT + r) * 256 + (int)threadIdx.x;
+      if (i < kGTabCount) {
+        const double x = xlo + (xhi - xlo) * ((double)(i - kGTabPad) / (double)kGTabN);
+        const double k = exp(x);
+        const double T = transfer_t<BAO>(E, k);
+        const double k3 = k * k * k;
+        n[kSigmaOffG + i] = exp((3.0 + E.ns) * (x - E.ln_H0)) * T * T / (k3 * k3);
+        n[kSigmaOffG + kGTabCount + i] = k;
+      }
+    }
+    return;
+  }
+  if ((int)blockIdx.x >= nb) {
+    // ln S point (the ln S points only aim the search: 1e-5 and at most 2^10 panels are plenty
+    // -- only R > 100 Mpc/h would go on to 2^11, where the cap costs ~1e-4 of an estimate that
+    // the probes certify anyway)
+    const int i = (int)blockIdx.x - nb;
+    const double R = exp(make_sgrid(cfg.k_min, cfg.k_max).ln_r(i));
+    double lo, hi;
+    sigma_limits(E, R, &lo, &hi);
+    SigmaIntegrandT<BAO> f{&E, R};              // sigma_norm = 1: amp * integral
+    const double s2 = romberg1<4>(f, lo, hi, cfg.global_precision, 1e-5,
+                                  cfg.divmax < 10 ? cfg.divmax : 10, red);
+    if (threadIdx.x == 0) n[kSigmaOffLnS + i] = log(s2);
+    return;
+  }
+  const double a = log(cfg.k_min), b = log(cfg.k_max);
+  // sigma_8 on the table's range? (cosmology.py:611-632 keeps [k_min, k_max] for R = 8
+  // with any sensible limits; otherwise the finisher integrates directly)
+  const bool tab8 = 0.1 / 8.0 > cfg.k_min && 14.0662 / 8.0 < cfg.k_max && cfg.divmax >= 1;
+  // per-level sums of this block's nodes (level-major order: a run of 256 nodes holds <= 2
+  // levels, the first run levels 0..8)
+  __shared__ double wsum[4][kSigmaLevel + 1];
+  __shared__ int last_block;
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) <= kSigmaLevel) wsum[wv][threadIdx.x & 63] = 0.0;
+#pragma unroll
+  for (int r = 0; r < NPT; ++r) {
+    const int first_idx = ((int)blockIdx.x * NPT + r) * 256;
+    const int idx = first_idx + (int)threadIdx.x;
+    const bool live = idx < kSigmaCount;
+    int lev = 0;
+    double g = 0.0;
+    if (live) {
+      double x;
+      if (idx < 2) {
+        x = idx == 0 ? a : b;
+      } else {
+        const int m = idx - 1;
+        lev = 32 - __builtin_clz((unsigned)m);
+        const long j = m - (1 << (lev - 1));
+        const double h = (b - a) / (double)(1L << (lev - 1));
+        x = (a + 0.5 * h) + h * (double)j;
+      }
+      const double k = exp(x);
+      const double T = transfer_t<BAO>(E, k);
+      n[idx] = k;
+      // Delta^2 shape over k^6: W(kR)^2 = 9 (sin y - y cos y)^2 / (k R)^6 then needs no division
+      const double k3 = k * k * k;
+      const double d2k6 = exp((3.0 + E.ns) * (x - E.ln_H0)) * T * T / (k3 * k3);
+      n[kSigmaCount + idx] = d2k6;
+      double sn, cs;
+      fast_sincos(8.0 * k, &sn, &cs);
+      const double t = sn - 8.0 * k * cs;
+      g = d2k6 * (9.0 / 262144.0) * (t * t);        // 9 / 8^6
+    }
+    if (first_idx < kSigmaCount) {                  // (block-uniform)
+      const int last_idx = first_idx + 255;
+      const int lev_lo = first_idx < 2 ? 0 : 32 - __builtin_clz((unsigned)(first_idx - 1));
+      const int lev_hi = last_idx < 2 ? 0 : 32 - __builtin_clz((unsigned)(last_idx - 1));
+      for (int l = lev_lo; l <= lev_hi && l <= kSigmaLevel; ++l) {
+        const double v = wave_sum(live && lev == l ? g : 0.0);
+        if ((threadIdx.x & 63) == 0) wsum[wv][l] += v;
+      }
+    }
+  }
+  double* part = n + kSigmaOffPart + (size_t)blockIdx.x * (kSigmaLevel + 1);
+  __syncthreads();
+  if (threadIdx.x <= kSigmaLevel)
+    part[threadIdx.x] = ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) +
+                        wsum[3][threadIdx.x];
+  if constexpr (NPT != 1) {
+    return;                        // (k_sigma_lns, behind this launch, finishes sigma_8)
+  } else {
+    int* arrivals = reinterpret_cast<int*>(n + kSigmaOffI8 + 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();             // partial sums (and table) visible before the arrival counts
+      last_block = atomicAdd(arrivals, 1) == nb - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!last_block) return;
+    // ---- last node block of this cosmology: sigma_8 from the level sums
+    __threadfence();
+    if (threadIdx.x == 0) *arrivals = 0;
+    sigma8_from_parts<BAO>(cfg, E, n, nb, red);
+  }
+}
+
+// The interpolated integrand with the g table in LDS and k from exp (k_sigma_lns).
+struct SigmaInterpLds {
+  const double* g;         // g / k^6 on the grid, in LDS (index 0 = first pad point)
+  double xlo, dx, inv_dx, scale, nine_over_r6;
   bool tiny_r;
   __device__ __forceinline__ double operator()(double ln_k) const {
     const double u = (ln_k - xlo) * inv_dx;
     int i = (int)u;
     i = i < 0 ? 0 : (i > kGTabN - 1 ? kGTabN - 1 : i);
     const double t = u - (double)i;
-    const double* q = g + i + kGTabPad - 2;            // stencil nodes -2 .. 3 around interval i
+    const double* q = g + i + kGTabPad - 2;
     const double a = t + 2.0, b = t + 1.0, d = t - 1.0, e = t - 2.0, f = t - 3.0;
     const double ab = a * b, ef = e * f, cd = t * d;
     const double gv = q[0] * (b * cd * ef) * (-1.0 / 120.0) + q[1] * (a * cd * ef) * (1.0 / 24.0) +
                       q[2] * (ab * d * ef) * (-1.0 / 12.0) + q[3] * (ab * t * ef) * (1.0 / 12.0) +
                       q[4] * (ab * cd * f) * (-1.0 / 24.0) + q[5] * (ab * cd * e) * (1.0 / 120.0);
-    const double y = t * dx;                           // <= 2.6e-3: four terms reach 1e-16
-    const double ey = fma(y, fma(y, fma(y, fma(y, 1.0 / 24.0, 1.0 / 6.0), 0.5), 1.0), 1.0);
-    const double k = q[2 + kGTabCount] * ey;
+    const double k = exp(ln_k);
     const double kR = scale * k;
     double s, c;
     fast_sincos(kR, &s, &c);
     if (tiny_r) {
       const double kR2 = kR * kR, k3 = k * k * k;
       const double W = 3.0 * (s / (kR2 * kR) - c / kR2);
-      return amp2 * (gv * (k3 * k3)) * (W * W);
+      return (gv * (k3 * k3)) * (W * W);
     }
     const double w = s - kR * c;
-    return amp2_nine_over_r6 * gv * (w * w);
+    return nine_over_r6 * gv * (w * w);
   }
 };
+
+// k_sigma_lns: grid n_slots, block 512, dynamic LDS kGTabCount doubles.  sigma_8's integral and
+// the coarse ln S(R) table
+// of every cosmology of a large batch (behind k_sigma_nodes<.., 4>, which leaves it out): 48
+// Romberg integrals, one per wavefront, six rounds of eight, on the integrand interpolated from
+// the cosmology's g table -- a third of the instructions of the direct evaluation -- which the
+// block first stages into LDS: read from HBM they cost a thousand cosmologies 6 GB of scattered
+// 64-byte fetches (measured: 5 ms), staged 67 MB of streaming reads.
+constexpr int kLnsThreads = 512;
+template <bool BAO>
+__global__ __launch_bounds__(kLnsThreads) void k_sigma_lns(chomp_config cfg,
+                                                           const chomp_cosmo* __restrict__ cosmo,
+                                                           const double* __restrict__ zin,
+                                                           const int* __restrict__ first,
+                                                           double* __restrict__ snodes) {
+  extern __shared__ __align__(16) double gl[];
+  __shared__ Epoch E;
+  const int slot = blockIdx.x, e = first[slot];
+  double* n = snodes + (size_t)slot * kSigmaStride;
+  if (threadIdx.x == 0) {
+    const chomp_cosmo c = cosmo[e];
+    E.om0 = c.omega_m0; E.ob0 = c.omega_b0; E.ol0 = c.omega_l0; E.or0 = c.omega_r0;
+    E.tcmb = c.cmb_temp; E.h = c.h; E.sigma8 = c.sigma_8; E.ns = c.n_scalar;
+    E.z = zin[e];
+    epoch_shape_only(E, cfg.k_min, cfg.k_max, BAO ? 1 : 0);    // (amp = 1: bare integrals)
+  }
+  if constexpr (!BAO) copy_doubles(gl, n + kSigmaOffG, kGTabCount);
+  __syncthreads();
+  // sigma_8 from the node blocks' level sums (k_sigma_nodes<.., 4> leaves that to this kernel:
+  // a fence and an arrival count per block cost a thousand cosmologies more than the tables)
+  sigma8_from_parts<BAO>(cfg, E, n, sigma_node_blocks<4>(), nullptr);
+  __syncthreads();
+  const SGrid G = make_sgrid(cfg.k_min, cfg.k_max);
+  const double xlo = log(cfg.k_min / 100.0), xhi = log(cfg.k_max * 100.0);
+  const double dx = (xhi - xlo) / (double)kGTabN;
+  const int dmax = cfg.divmax < 10 ? cfg.divmax : 10;
+  for (int i = (int)(threadIdx.x >> 6); i < kSGrid; i += kLnsThreads / 64) {
+    const double R = exp(G.ln_r(i));
+    double lo, hi;
+    sigma_limits(E, R, &lo, &hi);
+    double s2;
+    if constexpr (BAO) {
+      SigmaIntegrandT<BAO> f{&E, R};              // (the wiggles are not smooth enough to interpolate)
+      s2 = romberg1<1>(f, lo, hi, cfg.global_precision, 1e-5, dmax, nullptr);
+    } else {
+      const double r3 = R * R * R;
+      SigmaInterpLds f{gl, xlo, dx, 1.0 / dx, R, 9.0 / (r3 * r3), 100.0 * E.k_max * R < 1.0};
+      s2 = romberg1<1>(f, lo, hi, cfg.global_precision, 1e-5, dmax, nullptr);
+    }
+    if ((threadIdx.x & 63) == 0) n[kSigmaOffLnS + i] = log(s2);
+  }
+}
 
 // Delta^2(k) W(kR)^2 / (amp sigma_norm^2) from the table (levels <= kSigmaLevel); beyond it
 // the nodes no longer come from the level-major table but the R-independent factor is still
@@ -580,6 +712,11 @@ __device__ __forceinline__ SideThresholds side_thresholds(int side, const double
   return t;
 }
 
+// nu(M) at a probe.  The probe only has to decide on which side of the band edges nu lies,
+// so the Romberg may stop at a looser tolerance as soon as its result is clear of both edges
+// by kAmbiguous (in ln nu); a result within that of an edge walks on to the reference's
+// tolerance (RombergLoose: the same rows, no second integral), so every comparison that
+// decides the stopping step is either clear of the edge or exact.
 // nu(M) at a probe.  The probe only has to decide on which side of the band edges nu lies,
 // so the Romberg may stop at a looser tolerance as soon as its result is clear of both edges
 // by kAmbiguous (in ln nu); a result within that of an edge walks on to the reference's
@@ -789,198 +926,14 @@ __device__ __forceinline__ SidePlan plan_side(const Epoch& E, const double* lns,
   return P;
 }
 
-// grid (n_epoch, 2 * kProbes), block 64 * kInitNW.  blockIdx.y = kProbes * side + p
-// certifies candidate j - 2 + p of side 0 (mass_min) / 1 (mass_max); role kProbes also
-// does the comoving distance (or only that, with fixed mass limits).  The last block of
-// an epoch to finish combines the results (count[e], reset by it): a side whose probes
-// show "fails at c - 1, passes at c" is settled; any other (the estimate off by more than
-// the probes cover, a walk that leaves the ln S table: rare) falls back to the bracketing
-// secant search on exact integrals, seeded with what the probes established.
-// epochs[e] holds the closed-form part of the record (k_sigma_nodes) on entry and the
-// complete record on exit.
+// k_epoch_probe (chomp_probe_kernel.h) is compiled in its own translation unit, chomp_probe.hip
+// -- WITH LLVM's machine LICM, which every other kernel of the library is faster without
+// (chomp_amd/_lib.py: HIPCC_FLAGS): 38.5 against 41.8 us per C2 launch.  This is its launcher.
+void launch_epoch_probe(bool bao, unsigned n_epoch, hipStream_t stream, const chomp_config& cfg,
+                        Epoch* epochs, double* search, const double* cand, const double* snodes,
+                        double* probe, int* count, unsigned* status);
 constexpr int kProbes = 4;
 constexpr int kProbeStride = 24;   // doubles per epoch: nu[2][kProbes], chi, pad[3], plan[2][4]
-template <bool BAO>
-__global__ __launch_bounds__(64 * kInitNW) void k_epoch_probe(
-    chomp_config cfg, Epoch* __restrict__ epochs, double* __restrict__ search,
-    const double* __restrict__ cand, const double* __restrict__ snodes,
-    double* __restrict__ probe, int* __restrict__ count, unsigned* __restrict__ status) {
-  __shared__ Epoch E;
-  __shared__ double red[romberg_scratch<kInitNW, 1>()];
-  __shared__ double lns[kSGrid];   // the cosmology's coarse ln S(R) table
-  __shared__ int last, sh_j;
-  __shared__ double seeds[2][6];   // per side: dir, jl, nu_l, jh, nu_h, n_eval (uncertified)
-  __shared__ int open_side[2];
-  const int e = blockIdx.x, role = blockIdx.y;
-  const bool chi_role = role == kProbes;
-  const int side = role / kProbes, p = role % kProbes;
-  const bool fixed = cfg.mass_min > 0.0 && cfg.mass_max > 0.0;     // mass_function.py:163-170
-  if (fixed && !chi_role) return;
-  copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
-               kEpochDoubles);
-  __syncthreads();
-  const double* snode = snodes + (size_t)E.cosmo_slot * kSigmaStride;
-  copy_doubles(lns, snode + kSigmaOffLnS, kSGrid);
-  if (threadIdx.x == 0) {
-    // sigma_8 normalisation, cosmology.py:118-119: sigma_r(8)^2 = amp * I8 with the
-    // cosmology-only integral I8 from k_sigma_nodes
-    E.sigma_norm = E.sigma8 * E.growth / sqrt(E.amp * snode[kSigmaOffI8]);
-  }
-  __syncthreads();
-  double* pr = probe + (size_t)e * kProbeStride;
-  if (chi_role) {                  // comoving distance, cosmology.py:106-110
-    EIntegrand f{E.om0, E.ol0, E.or0, E.H0};
-    const double chi = romberg1<kInitNW>(f, 0.0, E.z, cfg.global_precision,
-                                         cfg.cosmo_precision, cfg.divmax, red);
-    __syncthreads();
-    if (threadIdx.x == 0) { E.chi = chi; pr[2 * kProbes] = chi; }
-    __syncthreads();
-    if (fixed) {
-      if (threadIdx.x == 0) {
-        search[(e * 2 + 0) * 2 + 0] = log(cfg.mass_min);
-        search[(e * 2 + 0) * 2 + 1] = 0.0;
-        search[(e * 2 + 1) * 2 + 0] = log(cfg.mass_max);
-        search[(e * 2 + 1) * 2 + 1] = 0.0;
-      }
-      __syncthreads();
-      copy_doubles(reinterpret_cast<double*>(&epochs[e]), reinterpret_cast<const double*>(&E),
-                   kEpochDoubles);
-      return;
-    }
-  }
-  {
-    // ---- this block's probe: candidate j - 2 + p of its side
-    const SidePlan plan = plan_side(E, lns, side, cand, &sh_j);
-    const SideThresholds T = side_thresholds(side, cand);
-    double nu_mine = NAN;
-    if (plan.ok && plan.dir != 0) {
-      const int c = plan.j - 2 + p;
-      // (away from an edge candidate 0 fails by the margin of the estimate)
-      if ((c > 0 || (c == 0 && plan.at_edge)) && c < kSearchJ) {
-        const double* tab = plan.dir < 0 ? T.down : T.up;
-        nu_mine = nu_probe<kInitNW, BAO>(E, snode, tab[c], cfg, T.thr_lo, T.thr_hi, red);
-      }
-    }
-    if (threadIdx.x == 0) {
-      pr[role] = nu_mine;
-      if (p == 0) {
-        double* pl = pr + 2 * kProbes + 4 + 4 * side;
-        pl[0] = plan.ok ? (plan.at_edge ? 2.0 : 1.0) : 0.0; pl[1] = (double)plan.dir;
-        pl[2] = (double)plan.j; pl[3] = plan.nu_start;
-      }
-    }
-  }
-  if (threadIdx.x == 0) {
-    __threadfence();               // results visible before the arrival is counted
-    last = atomicAdd(&count[e], 1) == 2 * kProbes - 1 ? 1 : 0;
-  }
-  __syncthreads();
-  if (!last) return;
-  // ---- last block of the epoch: certify both sides (thread 0: scalar logic on 8 numbers)
-  __threadfence();
-  if (threadIdx.x == 0) {
-    auto peek = [](const double* q) {
-      return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    for (int sd = 0; sd < 2; ++sd) {
-      const double* pl = pr + 2 * kProbes + 4 + 4 * sd;
-      const double mode = peek(pl);
-      const bool ok = mode != 0.0, at_edge = mode == 2.0;
-      const int dir = (int)peek(pl + 1);
-      const int j = (int)peek(pl + 2);
-      double nu_start = peek(pl + 3);
-      const SideThresholds S = side_thresholds(sd, cand);
-      double mass = S.down[0];
-      int n_eval = 0;
-      bool certified = ok;
-      int seed_dir = 0, seed_jl = 0, seed_jh = -1;
-      double nu_l = 0.0, nu_h = 0.0;
-      bool walk = ok && dir != 0;
-      if (at_edge) {               // the exact nu of the starting mass decides the direction
-        nu_start = peek(pr + kProbes * sd);
-        const int dir_exact = S.thr_hi < nu_start ? -1 : (S.thr_lo > nu_start ? +1 : 0);
-        n_eval = 1;
-        if (!(nu_start == nu_start)) { certified = false; walk = false; n_eval = 0; }
-        else if (dir_exact == 0) walk = false;                   // stays at the start: done
-        else if (dir_exact != dir) {                             // guessed the other way
-          certified = false; walk = false;
-          seed_dir = dir_exact; seed_jl = 0; nu_l = nu_start;
-        }
-      }
-      if (walk) {
-        const double* tab = dir < 0 ? S.down : S.up;
-        const double thr = dir < 0 ? S.thr_hi : S.thr_lo;
-        // status of candidates j - 2 .. j + 1: 0 fails, 1 passes, -1 unknown
-        // (scalars, not arrays: dynamic indexing would put them in scratch)
-        int st0, st1, st2, st3;
-        double nu0, nu1, nu2, nu3;
-        auto classify = [&](int q, int* st, double* nu) {
-          const int c = j - 2 + q;
-          *nu = peek(pr + kProbes * sd + q);
-          if (c <= 0) *st = 0;     // (at an edge: candidate 0 fails exactly, see above)
-          else if (!(*nu == *nu)) *st = -1;
-          else { *st = (dir < 0 ? !(thr < *nu) : !(thr > *nu)) ? 1 : 0; ++n_eval; }
-        };
-        classify(0, &st0, &nu0); classify(1, &st1, &nu1);
-        classify(2, &st2, &nu2); classify(3, &st3, &nu3);
-        certified = false;
-        int first_pass = -1, before = -1;        // status of the candidate before it
-        double nu_first = 0.0;
-        if (st3 == 1) { first_pass = 3; nu_first = nu3; before = st2; }
-        if (st2 == 1) { first_pass = 2; nu_first = nu2; before = st1; }
-        if (st1 == 1) { first_pass = 1; nu_first = nu1; before = st0; }
-        if (st0 == 1) { first_pass = 0; nu_first = nu0; before = -1; }
-        if (first_pass > 0 && before == 0) {                     // fails at c - 1, passes at c
-          certified = true;
-          mass = tab[j - 2 + first_pass];
-        } else if (first_pass == 0 && j - 2 == 1) {              // passes at 1, 0 fails
-          certified = true;
-          mass = tab[1];
-        }
-        if (!certified) {          // the estimate was off by more than the probes cover:
-          seed_dir = dir;          // the exact search starts from what they established
-          seed_jl = 0; nu_l = nu_start;
-          if (st0 == 0 && j - 2 > 0) { seed_jl = j - 2; nu_l = nu0; }
-          if (st1 == 0 && j - 1 > 0) { seed_jl = j - 1; nu_l = nu1; }
-          if (st2 == 0 && j > 0) { seed_jl = j; nu_l = nu2; }
-          if (st3 == 0 && j + 1 > 0) { seed_jl = j + 1; nu_l = nu3; }
-          if (first_pass >= 0 && j - 2 + first_pass > seed_jl) {
-            seed_jh = j - 2 + first_pass; nu_h = nu_first;
-          }
-        }
-      }
-      seeds[sd][0] = (double)seed_dir; seeds[sd][1] = (double)seed_jl; seeds[sd][2] = nu_l;
-      seeds[sd][3] = (double)seed_jh; seeds[sd][4] = nu_h; seeds[sd][5] = (double)n_eval;
-      open_side[sd] = certified ? 0 : 1;
-      if (certified) {
-        search[(e * 2 + sd) * 2 + 0] = log(mass);
-        search[(e * 2 + sd) * 2 + 1] = (double)n_eval;
-        const unsigned st = search_status(E, sd, mass, false);
-        if (st) atomicOr(&status[e], st);
-      }
-    }
-    E.chi = peek(pr + 2 * kProbes);
-    count[e] = 0;
-  }
-  __syncthreads();
-  for (int sd = 0; sd < 2; ++sd) {
-    if (!open_side[sd]) continue;                // block-uniform
-    int n_eval = (int)seeds[sd][5];
-    bool exhausted = false;
-    const double mass = search_side_exact<kInitNW, BAO>(
-        E, snode, sd, cfg, cand, red, &n_eval, &exhausted, (int)seeds[sd][0], (int)seeds[sd][1],
-        seeds[sd][2], (int)seeds[sd][3], seeds[sd][4]);
-    if (threadIdx.x == 0) {
-      search[(e * 2 + sd) * 2 + 0] = log(mass);
-      search[(e * 2 + sd) * 2 + 1] = (double)n_eval;
-      const unsigned st = search_status(E, sd, mass, exhausted);
-      if (st) atomicOr(&status[e], st);
-    }
-  }
-  __syncthreads();
-  copy_doubles(reinterpret_cast<double*>(&epochs[e]), reinterpret_cast<const double*>(&E),
-               kEpochDoubles);
-}
 
 // ---------------------------------------------------------------------------
 // k_nu_table: grid (NM, n_epoch), block 64 NW: one sigma(R) Romberg of the nu table per block,

@@ -741,3 +741,34 @@ def test_launch_shapes_by_batch_size_agree():
     mid = grid.HaloGrid(z[:8])                   # 8 x 50 x 2 = 800 knots: four-knot blocks
     p_mid = mid.power("power_gm", k)
     assert numpy.max(numpy.abs(p_mid / p_big[:8] - 1)) < 1e-12
+
+
+def test_many_cosmologies_in_one_batch_equal_single_epochs():
+    """From 16 distinct cosmologies on, the cosmology-only tables are built four nodes per thread
+    and the aiming integrals one per wavefront (k_sigma_nodes<.., 4>: a design or MCMC batch
+    is throughput-, not latency-bound).  Every epoch of such a batch must come out as it does
+    on its own -- mass limits bit for bit, tables to the order of the additions."""
+    from chomp_amd import grid
+    rng = numpy.random.default_rng(11)
+    base = dict(grid.defaults.default_cosmo_dict)
+    n = 20
+    cds, zs = [], []
+    for i in range(n):
+        om = rng.uniform(0.24, 0.34)
+        cds.append(dict(base, omega_m0=om - base["omega_r0"], omega_l0=1.0 - om,
+                        sigma_8=rng.uniform(0.75, 0.88), h=rng.uniform(0.65, 0.75),
+                        n_scalar=rng.uniform(0.94, 1.0)))
+        zs.append(float(rng.uniform(0.0, 1.2)))
+    k = numpy.logspace(-3, 2, 50)
+    big = grid.HaloGrid(numpy.array(zs), cosmo_dict=cds)
+    p_big = big.power("power_mm", k)
+    assert not big.status().any()
+    for i in (0, 7, 13, 19):
+        one = grid.HaloGrid(numpy.array([zs[i]]), cosmo_dict=cds[i])
+        p_one = one.power("power_mm", k)[0]
+        a, b = one.ctx.scalars(0), big.ctx.scalars(i)
+        assert a["ln_mass_min"] == b["ln_mass_min"] and a["ln_mass_max"] == b["ln_mass_max"], i
+        assert abs(a["sigma_norm"] / b["sigma_norm"] - 1) < 1e-13, i
+        assert numpy.array_equal(one.ctx.table("ln_mass", 0), big.ctx.table("ln_mass", i))
+        assert numpy.max(numpy.abs(one.ctx.table("nu", 0) / big.ctx.table("nu", i) - 1)) < 1e-12, i
+        assert numpy.max(numpy.abs(p_one / p_big[i] - 1)) < 1e-12, i

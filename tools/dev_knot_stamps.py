@@ -14,9 +14,7 @@ def build():
     sys.path.insert(0, R)
     from chomp_amd import _lib
     os.makedirs(os.path.join(R, "build_exp"), exist_ok=True)
-    subprocess.check_call(["/opt/rocm/bin/hipcc"] + _lib.HIPCC_FLAGS + ["-DCHOMP_STAMPS", "-o", SO, "chomp_capi.hip"],
-                          cwd=os.path.join(R, "chomp_amd/csrc"))
-    print("built", SO)
+    print("built", _lib.build(extra_flags=["-DCHOMP_STAMPS"], out=SO))
 
 
 def run():
