@@ -532,7 +532,13 @@ __global__ __launch_bounds__(kLnsThreads) void k_sigma_lns(chomp_config cfg,
     } else {
       const double r3 = R * R * R;
       SigmaInterpLds f{gl, xlo, dx, 1.0 / dx, R, 9.0 / (r3 * r3), 100.0 * E.k_max * R < 1.0};
-      s2 = romberg1<1>(f, lo, hi, cfg.global_precision, 1e-5, dmax, nullptr);
+      if (dmax >= 6) {             // levels 0..6 in one pass (seven dependent round trips less)
+        Scalar1<SigmaInterpLds> w{f};
+        const double fb[1] = {f(hi)};
+        s2 = romberg_wave6<1>(w, lo, hi, fb, cfg.global_precision, 1e-5, dmax).value[0];
+      } else {
+        s2 = romberg1<1>(f, lo, hi, cfg.global_precision, 1e-5, dmax, nullptr);
+      }
     }
     if ((threadIdx.x & 63) == 0) n[kSigmaOffLnS + i] = log(s2);
   }

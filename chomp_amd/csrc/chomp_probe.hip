@@ -10,13 +10,17 @@ namespace chomp {
 void launch_epoch_probe(bool bao, unsigned n_epoch, hipStream_t stream, const chomp_config& cfg,
                         Epoch* epochs, double* search, const double* cand, const double* snodes,
                         double* probe, int* count, unsigned* status) {
-  const dim3 grid(n_epoch, 2 * kProbes);
-  if (bao)
-    hipLaunchKernelGGL(k_epoch_probe<true>, grid, dim3(64 * kInitNW), 0, stream, cfg, epochs, search,
-                       cand, snodes, probe, count, status);
-  else
-    hipLaunchKernelGGL(k_epoch_probe<false>, grid, dim3(64 * kInitNW), 0, stream, cfg, epochs, search,
-                       cand, snodes, probe, count, status);
+  const dim3 grid(n_epoch, 2 * kProbes), block(64 * kInitNW);
+#define CHOMP_PROBE(BAO, PHASE, GRID)                                                         \
+  hipLaunchKernelGGL((k_epoch_probe<BAO, PHASE>), GRID, block, 0, stream, cfg, epochs, search, \
+                     cand, snodes, probe, count, status)
+  if (n_epoch >= 128) {            // a large batch: probe, then certify behind the boundary
+    if (bao) { CHOMP_PROBE(true, 1, grid); CHOMP_PROBE(true, 2, dim3(n_epoch)); }
+    else { CHOMP_PROBE(false, 1, grid); CHOMP_PROBE(false, 2, dim3(n_epoch)); }
+  } else {
+    if (bao) CHOMP_PROBE(true, 0, grid); else CHOMP_PROBE(false, 0, grid);
+  }
+#undef CHOMP_PROBE
 }
 
 }  // namespace chomp

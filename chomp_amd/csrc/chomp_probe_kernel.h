@@ -15,7 +15,11 @@ namespace chomp {
 // secant search on exact integrals, seeded with what the probes established.
 // epochs[e] holds the closed-form part of the record (k_sigma_nodes) on entry and the
 // complete record on exit.
-template <bool BAO>
+// PHASE 0: as described (one launch: a (k, z) grid's set-up is a latency chain).  A large
+// batch is throughput-bound, and there the fence in front of every block's arrival count -- an
+// L2 write-back on this chip -- costs more than the probes: PHASE 1 (the same grid) only
+// probes, PHASE 2 (grid n_epoch) certifies behind the kernel boundary.  Same numbers.
+template <bool BAO, int PHASE>
 __global__ __launch_bounds__(64 * kInitNW) void k_epoch_probe(
     chomp_config cfg, Epoch* __restrict__ epochs, double* __restrict__ search,
     const double* __restrict__ cand, const double* __restrict__ snodes,
@@ -26,8 +30,8 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_probe(
   __shared__ int last, sh_j;
   __shared__ double seeds[2][6];   // per side: dir, jl, nu_l, jh, nu_h, n_eval (uncertified)
   __shared__ int open_side[2];
-  const int e = blockIdx.x, role = blockIdx.y;
-  const bool chi_role = role == kProbes;
+  const int e = blockIdx.x, role = PHASE == 2 ? 0 : (int)blockIdx.y;
+  const bool chi_role = PHASE != 2 && role == kProbes;
   const int side = role / kProbes, p = role % kProbes;
   const bool fixed = cfg.mass_min > 0.0 && cfg.mass_max > 0.0;     // mass_function.py:163-170
   if (fixed && !chi_role) return;
@@ -63,7 +67,7 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_probe(
       return;
     }
   }
-  {
+  if constexpr (PHASE != 2) {
     // ---- this block's probe: candidate j - 2 + p of its side
     const SidePlan plan = plan_side(E, lns, side, cand, &sh_j);
     const SideThresholds T = side_thresholds(side, cand);
@@ -85,14 +89,17 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_probe(
       }
     }
   }
-  if (threadIdx.x == 0) {
-    __threadfence();               // results visible before the arrival is counted
-    last = atomicAdd(&count[e], 1) == 2 * kProbes - 1 ? 1 : 0;
+  if constexpr (PHASE == 1) return;
+  if constexpr (PHASE == 0) {
+    if (threadIdx.x == 0) {
+      __threadfence();             // results visible before the arrival is counted
+      last = atomicAdd(&count[e], 1) == 2 * kProbes - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
   }
-  __syncthreads();
-  if (!last) return;
   // ---- last block of the epoch: certify both sides (thread 0: scalar logic on 8 numbers)
-  __threadfence();
   if (threadIdx.x == 0) {
     auto peek = [](const double* q) {
       return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_probe(
       }
     }
     E.chi = peek(pr + 2 * kProbes);
-    count[e] = 0;
+    if (PHASE == 0) count[e] = 0;
   }
   __syncthreads();
   for (int sd = 0; sd < 2; ++sd) {

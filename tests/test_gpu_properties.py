@@ -744,14 +744,16 @@ def test_launch_shapes_by_batch_size_agree():
 
 
 def test_many_cosmologies_in_one_batch_equal_single_epochs():
-    """From 16 distinct cosmologies on, the cosmology-only tables are built four nodes per thread
-    and the aiming integrals one per wavefront (k_sigma_nodes<.., 4>: a design or MCMC batch
-    is throughput-, not latency-bound).  Every epoch of such a batch must come out as it does
-    on its own -- mass limits bit for bit, tables to the order of the additions."""
+    """A design or MCMC batch is throughput-, not latency-bound, and takes other launch shapes:
+    from 16 distinct cosmologies on the cosmology-only tables are built four nodes per thread
+    without arrival counts, sigma_8 and the aiming table by k_sigma_lns; from 128 epochs on the
+    probes of the mass-limit search and their certification are two launches.  Every epoch of
+    such a batch must come out as it does on its own -- mass limits bit for bit, tables to the
+    order of the additions."""
     from chomp_amd import grid
     rng = numpy.random.default_rng(11)
     base = dict(grid.defaults.default_cosmo_dict)
-    n = 20
+    n = 140
     cds, zs = [], []
     for i in range(n):
         om = rng.uniform(0.24, 0.34)
@@ -763,7 +765,7 @@ def test_many_cosmologies_in_one_batch_equal_single_epochs():
     big = grid.HaloGrid(numpy.array(zs), cosmo_dict=cds)
     p_big = big.power("power_mm", k)
     assert not big.status().any()
-    for i in (0, 7, 13, 19):
+    for i in (0, 7, 13, 19, 77, 139):
         one = grid.HaloGrid(numpy.array([zs[i]]), cosmo_dict=cds[i])
         p_one = one.power("power_mm", k)[0]
         a, b = one.ctx.scalars(0), big.ctx.scalars(i)
