@@ -655,8 +655,9 @@ struct WthetaIntegrand {
 // nodes and the theta-independent factor k^2/(2 pi) P(k)/D_z^2 of the integrand is
 // tabulated once per call on the level-LT grid (level-major, as the sigma(R) and halo node
 // tables): per node a theta block then only evaluates the kernel spline.
-// grid ceil((2^LT + 1) / 256), block 256.
+// grid ceil((2^LT + 1) / (256 kWthNodesPerThread)), block 256.
 constexpr int kWthetaTabLevel = 20;     // 2^20 + 1 doubles = 8 MiB: the default divmax
+constexpr int kWthNodesPerThread = 8;
 template <bool HF, bool BAO>
 __global__ __launch_bounds__(256) void k_wtheta_nodes(chomp_config cfg, TabLayout HL,
                                                       const Epoch* __restrict__ epochs, int e,
@@ -671,21 +672,26 @@ __global__ __launch_bounds__(256) void k_wtheta_nodes(chomp_config cfg, TabLayou
   P.stage(cfg, HL, &E, htab + (size_t)e * HL.stride, which, sm);
   __syncthreads();
   P.template finish_t<BAO>();
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx > (1L << LT)) return;
   const double a = log(k_min), b = log(k_max), intrange = b - a;
-  double x;
-  if (idx < 2) {
-    x = idx == 0 ? a : b;
-  } else {                                   // the node arithmetic of chomp_romberg.h
-    const unsigned m = (unsigned)(idx - 1);
-    const int lev = 32 - __builtin_clz(m);
-    const long j = (long)m - (1L << (lev - 1));
-    const double h = intrange / (double)(1L << (lev - 1));
-    x = (a + 0.5 * h) + h * (double)j;
+  // (kWthNodesPerThread nodes per thread: a block stages 5 KB of spline tables before its first
+  //  node -- at one node per thread, 4097 blocks of it, that staging was most of the 33 us)
+#pragma unroll 2
+  for (int r = 0; r < kWthNodesPerThread; ++r) {
+    const long idx = ((long)blockIdx.x * kWthNodesPerThread + r) * blockDim.x + threadIdx.x;
+    if (idx > (1L << LT)) return;
+    double x;
+    if (idx < 2) {
+      x = idx == 0 ? a : b;
+    } else {                                   // the node arithmetic of chomp_romberg.h
+      const unsigned m = (unsigned)(idx - 1);
+      const int lev = 32 - __builtin_clz(m);
+      const long j = (long)m - (1L << (lev - 1));
+      const double h = intrange / (double)(1L << (lev - 1));
+      x = (a + 0.5 * h) + h * (double)j;
+    }
+    const double k = exp(x);
+    nodes[idx] = k * k / (2.0 * kPi) * P.template at_ln<HF, BAO>(x, k) * (1.0 / (D_z * D_z));
   }
-  const double k = exp(x);
-  nodes[idx] = k * k / (2.0 * kPi) * P.template at_ln<HF, BAO>(x, k) * (1.0 / (D_z * D_z));
 }
 
 // correlation.py:270-275 from the node table (levels <= LT), directly beyond
@@ -785,15 +791,21 @@ struct WthSeg {
 };
 
 // grid (nseg, LT, kWthParts), block 256: inclusive prefix sums of g_j u_j^q, q = 0..3, u_j = x_j
-// - O_m, over the nodes of segment m of level blockIdx.y + 1, into mom[4 idx + q] (idx: the
-// node's index in the level-major table).  A long segment (deep levels) is cut into up to
-// kWthParts parts, one block each: a part first sums the moments of the parts before it (a plain
-// strided reduction of nodes already in L2) for its carry, then scans its own tiles of
+// - O_m, over the nodes of segment m of level blockIdx.y + 1 -- KEPT only where k_wtheta_fast
+// cannot cheaply rebuild them: at every kWthItems-th node (rec: the record of node j with
+// (j + 1) % kWthItems == 0 lives at index (2^(lev-1) + j + 1) / kWthItems, a heap over the levels;
+// a look-up adds the <= kWthItems - 1 nodes behind the record itself) and at the last node of the
+// segment (segtot[(lev nseg + m)]).  Four moments for every node were 32 MiB of writes per call
+// (0.18 of the HBM rate for a scan); these are 4 MiB.  A long segment (deep levels) is cut into
+// up to kWthParts parts, one block each: a part first sums the moments of the parts before it (a
+// plain strided reduction of nodes already in L2) for its carry, then scans its own tiles of
 // 256 * kWthItems nodes.  No block waits for another.
 constexpr int kWthParts = 8;
+__host__ __device__ inline size_t wth_rec_count(int LT) { return ((size_t)1 << LT) / kWthItems + 2; }
 __global__ __launch_bounds__(256) void k_wtheta_moments(const double* __restrict__ nodes, int LT,
                                                         int nseg, double a, double b,
-                                                        double* __restrict__ mom) {
+                                                        double* __restrict__ rec,
+                                                        double* __restrict__ segtot) {
   __shared__ double wtot[2][4][4];
   __shared__ double ctot[4][4];
   const int m = blockIdx.x, lev = blockIdx.y + 1, t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -811,6 +823,7 @@ __global__ __launch_bounds__(256) void k_wtheta_moments(const double* __restrict
   const double h = (b - a) / (double)n, lox = a + 0.5 * h;
   const double O = G.origin(m);
   const long base = 1 + n;                                  // level-major index of j = 0
+  static_assert((kWthItems & (kWthItems - 1)) == 0, "records at a power-of-two spacing");
   double carry[4] = {0.0, 0.0, 0.0, 0.0};
   if (p0 > j0) {                                            // (block-uniform)
     double r[4] = {0.0, 0.0, 0.0, 0.0};
@@ -880,13 +893,23 @@ __global__ __launch_bounds__(256) void k_wtheta_moments(const double* __restrict
       pre[q] = carry[q] + before + (inc[q] - s[q]);
       next[q] = carry[q] + all;
     }
+    // of this thread's kWthItems consecutive nodes exactly one closes a record; the segment's
+    // last node also leaves the segment's total
+    const int i_rec = (int)((kWthItems - ((c0 + 1) & (kWthItems - 1))) & (kWthItems - 1));
 #pragma unroll
     for (int i = 0; i < kWthItems; ++i) {
       const long j = c0 + i;
-      if (j < p1) {
-        double2* o = reinterpret_cast<double2*>(mom + 4 * (base + j));
-        o[0] = make_double2(pre[0] + v[i][0], pre[1] + v[i][1]);
-        o[1] = make_double2(pre[2] + v[i][2], pre[3] + v[i][3]);
+      if (j < p1 && (i == i_rec || j == j1 - 1)) {
+        const double2 lo2 = make_double2(pre[0] + v[i][0], pre[1] + v[i][1]);
+        const double2 hi2 = make_double2(pre[2] + v[i][2], pre[3] + v[i][3]);
+        if (i == i_rec) {
+          double2* o = reinterpret_cast<double2*>(rec + 4 * ((n + j + 1) / kWthItems));
+          o[0] = lo2; o[1] = hi2;
+        }
+        if (j == j1 - 1) {
+          double2* o = reinterpret_cast<double2*>(segtot + 4 * ((size_t)lev * nseg + m));
+          o[0] = lo2; o[1] = hi2;
+        }
       }
     }
 #pragma unroll
@@ -895,11 +918,11 @@ __global__ __launch_bounds__(256) void k_wtheta_moments(const double* __restrict
 }
 
 // Moments of the whole of segment m (0 for an empty one).
-__device__ __forceinline__ void wth_seg_total(const double* __restrict__ mom, long base, int m,
+__device__ __forceinline__ void wth_seg_total(const double* __restrict__ segtot, int m,
                                               const WthSeg& G, int lev, double (&T)[4]) {
   const long g0 = G.start(m, lev), g1 = G.start(m + 1, lev);
   if (g1 > g0) {
-    const double2* p = reinterpret_cast<const double2*>(mom + 4 * (base + g1 - 1));
+    const double2* p = reinterpret_cast<const double2*>(segtot + 4 * ((size_t)lev * G.nseg + m));
     const double2 x = p[0], y = p[1];
     T[0] = x.x; T[1] = x.y; T[2] = y.x; T[3] = y.y;
   } else {
@@ -925,7 +948,8 @@ __global__ __launch_bounds__(256) void k_wtheta_fast(chomp_config cfg, ProjLayou
                                                      double k_max, const double* __restrict__ theta,
                                                      double* __restrict__ out,
                                                      const double* __restrict__ nodes,
-                                                     const double* __restrict__ mom, int LT,
+                                                     const double* __restrict__ rec,
+                                                     const double* __restrict__ segtot, int LT,
                                                      int nseg) {
   __shared__ double level_sum[2][4];
   __shared__ double ctab[(kWthetaTabLevel + 1) * 32];   // the rows' weights (RombergRows2::ctab)
@@ -965,26 +989,48 @@ __global__ __launch_bounds__(256) void k_wtheta_fast(chomp_config cfg, ProjLayou
         const double q = floor((hi - s - lox) * inv_h) + 1.0;
         B = q <= 0.0 ? 0 : (q >= (double)n ? n : (long)q);
       }
-      // prefix moments just below B, and the total of that segment (both loads issued before
-      // anything waits for them; for B = 0 a valid address whose value is not used)
+      // prefix moments just below B -- the record at or before node B - 1 and the nodes behind
+      // it, or the nodes from the segment's start -- and the total of that segment (every load
+      // issued before anything waits for it; for B = 0 valid addresses whose values are not used)
       const bool has = lane <= NP && B >= 1;
       const int mB = has ? wth_seg_of(B - 1, nseg, lv) : 0;
-      const long end = has ? G.start(mB + 1, lv) : 1;    // (>= B: the segment holds node B - 1)
-      const double2* pP = reinterpret_cast<const double2*>(mom + 4 * (base + (has ? B - 1 : 0)));
-      const double2* pT = reinterpret_cast<const double2*>(mom + 4 * (base + end - 1));
-      const double2 P01 = pP[0], P23 = pP[1], T01 = pT[0], T23 = pT[1];
+      const long jl = has ? B - 1 : 0;                   // the last node of the prefix
+      const long js = has ? G.start(mB, lv) : 0;         // ... the first node of its segment
+      const long jb = ((jl + 1) / kWthItems) * kWthItems;     // nodes < jb are in the record
+      const bool from_rec = jb > js;
+      const long i0 = from_rec ? jb : js;                // the nodes i0 .. jl are added here
+      const double2* pR = reinterpret_cast<const double2*>(rec + 4 * (from_rec ? (n + jb) / kWthItems : 0));
+      const double2* pT = reinterpret_cast<const double2*>(segtot + 4 * ((size_t)lv * nseg + mB));
+      const double2 R01 = pR[0], R23 = pR[1], T01 = pT[0], T23 = pT[1];
+      double gtail[kWthItems - 1];
+#pragma unroll
+      for (int i = 0; i < kWthItems - 1; ++i) {
+        const long jn = i0 + i;
+        gtail[i] = nodes[base + (jn <= jl ? jn : jl)];
+      }
+      double P[4] = {from_rec ? R01.x : 0.0, from_rec ? R01.y : 0.0, from_rec ? R23.x : 0.0,
+                     from_rec ? R23.y : 0.0};
+      {
+        const double O = G.origin(mB);
+#pragma unroll
+        for (int i = 0; i < kWthItems - 1; ++i) {
+          const long jn = i0 + i;
+          const double g = jn <= jl ? gtail[i] : 0.0;
+          const double u = (lox + h * (double)jn) - O;
+          P[0] += g; P[1] += g * u; P[2] += g * (u * u); P[3] += g * (u * u * u);
+        }
+      }
+      if (!has) { P[0] = P[1] = P[2] = P[3] = 0.0; }
       const long B0 = __shfl((long long)B, 0, 64);
       const int m0 = __shfl(mB, 0, 64);
       double below = 0.0;                                // plain sum of g over the segments < m0
       if (B0 >= 1) {
         for (int m = lane; m < m0; m += 64) {
           double T[4];
-          wth_seg_total(mom, base, m, G, lv, T);
+          wth_seg_total(segtot, m, G, lv, T);
           below += T[0];
         }
       }
-      const double P[4] = {has ? P01.x : 0.0, has ? P01.y : 0.0, has ? P23.x : 0.0,
-                           has ? P23.y : 0.0};
       // the next knot's
       const long Bn = __shfl_down((long long)B, 1, 64);
       const int mn = __shfl_down(mB, 1, 64);
@@ -1003,7 +1049,7 @@ __global__ __launch_bounds__(256) void k_wtheta_fast(chomp_config cfg, ProjLayou
           }
           for (int m = B >= 1 ? mB + 1 : 0; m < mn; ++m) {
             double T[4];
-            wth_seg_total(mom, base, m, G, lv, T);
+            wth_seg_total(segtot, m, G, lv, T);
             contrib += wth_combine(T, G.origin(m) + s - X, c0, c1, c2, c3);
           }
           contrib += wth_combine(Pn, G.origin(mn) + s - X, c0, c1, c2, c3);
