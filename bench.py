@@ -284,13 +284,26 @@ def batch_leg(D, n, distinct, steps, warmup, stream, which="power_mm", mf="st"):
            "ms_per_step": 1e3 * elapsed / steps, "samples_per_s": n * NK * steps / elapsed,
            "us_per_epoch": 1e6 * elapsed / steps / n, "stage_k_ms": t_k * 1e3, "steps": steps,
            "epochs_flagged": int(numpy.count_nonzero(status))}
-    rk = stage_k_roofline(t_k, "batch_%d_%s" % (n, "distinct" if distinct else "one"))
+    kind = "distinct" if distinct else "one"
+    rk = stage_k_roofline(t_k, "batch_%d_%s" % (n, kind))
     if rk is not None:
         res["stage_k_frac"] = rk["frac"]
         res["stage_k_tflops"] = rk["achieved"]
         res["flop_per_step"] = rk["flop_per_step"]
+        res["flop_source"] = "SQ counters of this batch (%s)" % rk["note"].split("counters: ")[-1]
     else:
-        res["stage_k_frac"] = None
+        # no counter pass of this size: FLOP per epoch of the measured 1024-epoch batch of the
+        # same kind (the per-epoch work does not depend on the batch size; the cosmology-only
+        # part is counted per epoch there too)
+        ref = stage_k_roofline(t_k, "batch_1024_%s" % kind)
+        if ref is not None:
+            flop = ref["flop_per_step"] * n / 1024.0
+            res["stage_k_tflops"] = flop / t_k / 1e12
+            res["stage_k_frac"] = flop / t_k / 1e12 / FP64_VALU_PEAK_TFLOPS
+            res["flop_per_step"] = flop
+            res["flop_source"] = "scaled by n / 1024 from the counters of the 1024-epoch batch"
+        else:
+            res["stage_k_frac"] = None
     return res
 
 
