@@ -352,6 +352,47 @@ def test_non_default_precision_vs_oracle(over):
         defaults.default_precision.update(saved)
 
 
+def test_tight_halo_precision_lists_smooth_knots_too():
+    """With halo_precision tightened to 1.48e-9 the smooth h_m / pp_mm integrals do not converge
+    within the node tables either.  A set-up without HOD integrands (P_mm) then evaluates its
+    listed knots literally inside k_halo_knots_fast<.., true> (no hand-over launch on that
+    chain); in a P_gm set-up the same knots take the fast level sums.  Values and Romberg
+    levels against the oracle."""
+    from chomp_amd import defaults, halo
+    from oracle import chomp_oracle as o
+    saved = copy.deepcopy(defaults.default_precision)
+    try:
+        over = dict(halo_precision=1.48e-9)
+        defaults.default_precision.update(over)
+        prec = dict(o.default_precision, **over)
+        k = numpy.logspace(-3, 2, 48)
+        e = o.epoch(None, 0.3, prec=prec)
+        t = o.halo_table(e, o.mass_table(e), o.zheng(prec=prec), families=("mm", "gm"))
+        h = halo.Halo(0.3)
+        got_mm = h.power_mm(k)
+        ctx = h._sync(0)
+        f, l = ctx.deep_stats()
+        assert f == 0 and l >= 1, (f, l)               # listed, and done in the same launch
+        lev = ctx.table("levels", 0).reshape(5, -1)
+        assert lev[:2].max() > 10
+        assert numpy.array_equal(lev[0], t.levels["_h_m_integrand"])
+        assert numpy.array_equal(lev[1], t.levels["_pp_mm_integrand"])
+        assert rel_err(ctx.table("h_m", 0), t.h_m) < 1e-9 and rel_err(ctx.table("pp_mm", 0), t.pp_mm) < 1e-9
+        assert rel_err(got_mm, o.halo_power(t, "mm", k)) < 1e-8
+        h2 = halo.Halo(0.3)
+        got_gm = h2.power_gm(k)
+        ctx2 = h2._sync(0)
+        f2, l2 = ctx2.deep_stats()
+        assert f2 > 10 and l2 == 0, (f2, l2)
+        lev2 = ctx2.table("levels", 0).reshape(5, -1)
+        assert numpy.array_equal(lev2[0], t.levels["_h_m_integrand"])
+        assert rel_err(ctx2.table("h_m", 0), t.h_m) < 1e-9
+        assert rel_err(got_gm, o.halo_power(t, "gm", k)) < RTOL
+    finally:
+        defaults.default_precision.clear()
+        defaults.default_precision.update(saved)
+
+
 def test_fixed_mass_limits_vs_oracle():
     """defaults.default_limits mass_min/mass_max > 0 skip the search
     (mass_function.py:163-170)."""
