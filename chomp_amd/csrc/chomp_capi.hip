@@ -131,6 +131,8 @@ struct chomp_ctx {
   double* d_wnodes = nullptr;      // w(theta): theta-independent integrand factor on the Romberg nodes
   double* d_cnodes = nullptr;      // C_l: chi-only factors on the Romberg nodes
   size_t cap_cnodes = 0;
+  double* d_kept = nullptr;        // integrand pairs the HOD knots evaluated (k_halo_knots -> _fast)
+  size_t cap_kept = 0;
   double* d_deepw = nullptr;       // k_halo_knots_fast: level weights (deep_weights_host)
   int* d_deepstat = nullptr;       // k_halo_knots_fast: knots done by the fast / literal path
   size_t cap_slow = 0, cap_winfo = 0, cap_ktab = 0, cap_wnodes = 0;
@@ -509,7 +511,7 @@ void chomp_ctx_destroy(chomp_ctx* ctx) {
                   ctx->d_cand, ctx->d_cosmo, ctx->d_z, ctx->d_epochs, ctx->d_search, ctx->d_probe, ctx->d_count, ctx->d_pending,
                   ctx->d_tab, ctx->d_mass_par, ctx->d_profile, ctx->d_hod, ctx->d_nodes, ctx->d_snodes, ctx->d_slot, ctx->d_first, ctx->d_status, ctx->d_endp, ctx->d_npend,
                   ctx->d_stage_in, ctx->d_stage_in2, ctx->d_stage_out, ctx->d_slow, ctx->d_wnodes, ctx->d_cnodes, ctx->d_deepw, ctx->d_deepstat,
-                  ctx->d_winfo, ctx->d_ktab};
+                  ctx->d_winfo, ctx->d_ktab, ctx->d_kept};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (void* p : ctx->graveyard) (void)hipFree(p);
@@ -837,12 +839,24 @@ static int launch_halo_knots(chomp_ctx* ctx, const HaloPlan& P) {
   const bool lone = !wide && (size_t)L.NK * n * ng > 4096;
   const unsigned kb = (wide || lone) ? (unsigned)L.NK : (unsigned)((L.NK + 3) / 4);
   const size_t shk = (size_t)(L.NM + 8 * (L.NM - 1) + kKnotScratch) * sizeof(double);
+  // The integrand pairs an HOD knot evaluates on its way through the node table are kept for
+  // k_halo_knots_fast (half its coarse samples): compact slots of the plan's HOD groups.
+  int ks[3] = {-1, -1, -1}, n_hod = 0;
+  for (int q = 0; q < P.ng && q < 3; ++q)
+    if (P.groups[q] > 0) ks[q] = n_hod++;
+  double* kept = nullptr;
+  if (n_hod > 0 && ctx->cfg.divmax > kNodeLevel) {
+    const int rck = ensure(ctx, &ctx->d_kept, &ctx->cap_kept,
+                           (size_t)n_hod * n * (size_t)L.NK * 2 * (size_t)kNodeBase);
+    if (rck) return rck;
+    kept = ctx->d_kept;
+  }
 #define CHOMP_KNOTS(KNW)                                                                          \
   hipLaunchKernelGGL((k_halo_knots<KNW>), dim3(kb + (P.want_nbar ? 1u : 0u), (unsigned)n, (unsigned)ng), \
                      dim3(KNW == 0 ? 64 : 256), shk, ctx->stream, ctx->cfg, L, ctx->d_epochs, ctx->d_tab,        \
                      ctx->d_profile, ctx->d_hod, ctx->d_sici, ctx->d_nodes, ctx->d_endp,          \
                      P.groups[0], P.groups[1], P.groups[2], P.kmask, P.want_nbar, ctx->d_pending, \
-                     ctx->d_npend, ctx->d_status)
+                     ctx->d_npend, ctx->d_status, kept, ks[0], ks[1], ks[2])
   if (wide) CHOMP_KNOTS(4); else if (lone) CHOMP_KNOTS(0); else CHOMP_KNOTS(1);
 #undef CHOMP_KNOTS
   // blocks 0..n-1 take the epochs' tokens; with integrands that can run beyond the node
@@ -877,7 +891,7 @@ static int launch_halo_knots(chomp_ctx* ctx, const HaloPlan& P) {
                      ctx->cfg, L, ctx->d_epochs, ctx->d_tab, ctx->d_sici, P.groups[0], P.groups[1], \
                      P.groups[2], P.kmask, (int)n, ctx->d_pending, ctx->d_npend, ctx->d_epochs,     \
                      P.fam, ctx->d_status, ctx->d_deepw, all_literal, deep_tol, max_rough, max_fine, \
-                     ctx->d_deepstat, ctx->d_nodes)
+                     ctx->d_deepstat, ctx->d_nodes, kept, ks[0], ks[1], ks[2])
 #define CHOMP_KNOTS_LITERAL(NT, GRID)                                                            \
   hipLaunchKernelGGL((k_halo_knots_literal<NT>), dim3(GRID), dim3(NT), shl, ctx->stream, ctx->cfg,  \
                      L, ctx->d_epochs, ctx->d_tab, ctx->d_profile, ctx->d_hod, ctx->d_sici,         \

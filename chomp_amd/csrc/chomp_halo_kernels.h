@@ -472,12 +472,21 @@ struct NodeIntegrand {
   const double* node;     // this (epoch, group)'s table
   double ln_k;
   bool exclusion;         // HaloExclusion (halo.py:1208-1233): window on the 2-halo term
+  // (HOD groups) where the pair of every node this knot evaluates is kept, [node_index] x 2: a
+  // knot that has to be listed has evaluated half of k_halo_knots_fast's coarse samples by then
+  double* keep;
   __device__ __forceinline__ void operator()(double, double (&out)[2], int lev, long j) const {
-    const double* n = node + node_index(lev, j);
+    const int idx = node_index(lev, j);
+    const double* n = node + idx;
     node_pair(*sici, ln_k, exclusion, n[0], n[kNodeCount], n[2 * kNodeCount], n[3 * kNodeCount],
               n[4 * kNodeCount], n[5 * kNodeCount], n[6 * kNodeCount], out);
+    if (keep) reinterpret_cast<double2*>(keep)[idx] = make_double2(out[0], out[1]);
   }
 };
+// The kept pairs of knot ik of epoch e in the compact slot sc of an HOD group (see NodeIntegrand).
+__host__ __device__ inline size_t kept_offset(int sc, int n_epoch, int e, int NK, int ik) {
+  return (((size_t)sc * n_epoch + e) * NK + ik) * 2 * (size_t)kNodeBase;
+}
 
 __device__ __forceinline__ int group_fa(int group) { return group == 0 ? F_HM : F_HG; }
 __device__ __forceinline__ int group_fb(int group) {
@@ -508,7 +517,8 @@ __global__ __launch_bounds__(KNW == 0 ? 64 : 256) void k_halo_knots(
     const chomp_halo_par* __restrict__ profile, const HodDev* __restrict__ hod,
     const SiCiTab* __restrict__ sici_g, const double* __restrict__ nodes,
     const double* __restrict__ endp, int g0, int g1, int g2, unsigned mask, int want_nbar,
-    int* __restrict__ pending, int* __restrict__ npend, unsigned* __restrict__ status) {
+    int* __restrict__ pending, int* __restrict__ npend, unsigned* __restrict__ status,
+    double* __restrict__ kept, int s0, int s1, int s2) {
   extern __shared__ __align__(16) double sm[];
   __shared__ SiCiTab S;
   __shared__ Epoch E;              // (the n_bar block only)
@@ -540,7 +550,10 @@ __global__ __launch_bounds__(KNW == 0 ? 64 : 256) void k_halo_knots(
   const double fb[2] = {ep[0], ep[1]};
   double* t = tab + (size_t)e * L.stride;
   const double ln_k = linspace_at(log(cfg.k_min), log(cfg.k_max), NK, ik);   // halo.py:52-54
-  NodeIntegrand f{&S, node, ln_k, (mask & kMaskExclusion) != 0};
+  const int sc = blockIdx.z == 0 ? s0 : (blockIdx.z == 1 ? s1 : s2);
+  NodeIntegrand f{&S, node, ln_k, (mask & kMaskExclusion) != 0,
+                  (kept != nullptr && sc >= 0) ? kept + kept_offset(sc, (int)gridDim.y, e, NK, ik)
+                                               : nullptr};
   const int dmax = cfg.divmax < kNodeLevel ? cfg.divmax : kNodeLevel;
   RombergOut<2> r;
   if constexpr (KNW <= 1) {
@@ -982,7 +995,7 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
     int* __restrict__ pending, int* __restrict__ npend, Epoch* __restrict__ epochs_rw,
     unsigned fam_mask, unsigned* __restrict__ status, const double* __restrict__ deepw,
     int all_literal, double tol, int max_rough, int max_fine, int* __restrict__ stats,
-    const double* __restrict__ nodes) {
+    const double* __restrict__ nodes, const double* __restrict__ kept, int s0, int s1, int s2) {
   static_assert(LC == kNodeTabLevel, "the coarse samples are the node table's grid");
   constexpr int NC = 1 << LC;
   constexpr int NWV = NT / 64;
@@ -1124,6 +1137,12 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
       // butterfly per level present -- a separate pass over the samples in position order
       // would read LDS at power-of-two strides (2.8 M bank conflicts per C3 launch)
       const double* nd = nodes + ((size_t)e * 3 + group) * kNodeStride;
+      // (the levels <= kNodeLevel of an HOD knot are the very values k_halo_knots summed and
+      //  kept -- all but the upper end point, which it takes from d_endp: read, not re-evaluated)
+      const int sc = zg == 0 ? s0 : (zg == 1 ? s1 : s2);
+      const double2* kp = (kept != nullptr && sc >= 0)
+                              ? reinterpret_cast<const double2*>(kept + kept_offset(sc, n_epoch, e, NK, ik))
+                              : nullptr;
       for (int base = 0; base <= NC; base += NT) {
         const int idx = base + tid;
         const bool live = idx <= NC;
@@ -1139,9 +1158,14 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
             q = (2 * (m - (1 << (lv - 1))) + 1) << (LC - lv);
           }
           const double state = nd[6 * kNodeCount + idx];
-          node_pair(S, c.ln_k, c.exclusion, nd[idx], nd[kNodeCount + idx], nd[2 * kNodeCount + idx],
-                    nd[3 * kNodeCount + idx], nd[4 * kNodeCount + idx], nd[5 * kNodeCount + idx],
-                    state, o);
+          if (kp != nullptr && idx < kNodeBase && idx != 1) {
+            const double2 v = kp[idx];
+            o[0] = v.x; o[1] = v.y;
+          } else {
+            node_pair(S, c.ln_k, c.exclusion, nd[idx], nd[kNodeCount + idx], nd[2 * kNodeCount + idx],
+                      nd[3 * kNodeCount + idx], nd[4 * kNodeCount + idx], nd[5 * kNodeCount + idx],
+                      state, o);
+          }
           F0[q] = o[0];
           F1[q] = o[1];
           code[q] = (unsigned char)(int)state;
