@@ -525,8 +525,12 @@ __global__ __launch_bounds__(KNW == 0 ? 64 : 256) void k_halo_knots(
   const int NK = L.NK;
   const int e = blockIdx.y;
   const int kb = KNW == 1 ? (NK + 3) / 4 : NK;     // knot blocks
-  if ((int)blockIdx.x >= kb) {     // ---- n_bar
-    if (!want_nbar || blockIdx.z != 0) return;
+  // Blocks are dispatched x fastest, z slowest: the long units first -- the n_bar integral, the
+  // highest k (the deepest Romberg), the HOD groups (plan slots 1, 2) before the smooth one --
+  // so that the launch ends with the knots that stop at level 6.
+  const int bx = (int)gridDim.x - 1 - (int)blockIdx.x, bz = (int)gridDim.z - 1 - (int)blockIdx.z;
+  if (bx >= kb) {                  // ---- n_bar
+    if (!want_nbar || bz != 0) return;
     HaloLds H;
     H.stage(L, E, S, epochs, e, tab + (size_t)e * L.stride, profile, hod, sici_g, sm);
     HaloCtx c{&E, &S, H.nu_knots, H.lnm_pp, L.NM, 0.0, false};
@@ -537,12 +541,12 @@ __global__ __launch_bounds__(KNW == 0 ? 64 : 256) void k_halo_knots(
     if (threadIdx.x == 0) tab[(size_t)e * L.stride + L.off_misc] = v;
     return;
   }
-  const int group = blockIdx.z == 0 ? g0 : (blockIdx.z == 1 ? g1 : g2);
+  const int group = bz == 0 ? g0 : (bz == 1 ? g1 : g2);
   if (group < 0 || group > 2) return;
   copy_doubles(reinterpret_cast<double*>(&S), reinterpret_cast<const double*>(sici_g),
                (int)(sizeof(SiCiTab) / sizeof(double)));
   __syncthreads();
-  const int ik = KNW == 1 ? (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6) : (int)blockIdx.x;
+  const int ik = KNW == 1 ? bx * 4 + (int)(threadIdx.x >> 6) : bx;
   if (ik >= NK) return;            // (KNW = 1: no barrier below, the wavefronts are independent)
   const double* node = nodes + ((size_t)e * 3 + group) * kNodeStride;
   const double a = node[kNodeFields * kNodeCount], b = node[kNodeFields * kNodeCount + 1];
@@ -550,7 +554,7 @@ __global__ __launch_bounds__(KNW == 0 ? 64 : 256) void k_halo_knots(
   const double fb[2] = {ep[0], ep[1]};
   double* t = tab + (size_t)e * L.stride;
   const double ln_k = linspace_at(log(cfg.k_min), log(cfg.k_max), NK, ik);   // halo.py:52-54
-  const int sc = blockIdx.z == 0 ? s0 : (blockIdx.z == 1 ? s1 : s2);
+  const int sc = bz == 0 ? s0 : (bz == 1 ? s1 : s2);
   NodeIntegrand f{&S, node, ln_k, (mask & kMaskExclusion) != 0,
                   (kept != nullptr && sc >= 0) ? kept + kept_offset(sc, (int)gridDim.y, e, NK, ik)
                                                : nullptr};
@@ -591,7 +595,7 @@ __global__ __launch_bounds__(KNW == 0 ? 64 : 256) void k_halo_knots(
     // the highest k -- at the front, the rest from the back of the buffer downwards
     if (any) {
       atomicAdd(&npend[e], 1);
-      const int item = (int)((blockIdx.z * gridDim.y + e) * NK + ik);
+      const int item = (int)((bz * gridDim.y + e) * NK + ik);
       const int cap = 3 * (int)gridDim.y * NK;
       if (4 * ik >= 3 * NK) pending[kPendingHead + atomicAdd(&pending[0], 1)] = item;
       else pending[kPendingHead + cap - 1 - atomicAdd(&pending[2], 1)] = item;
