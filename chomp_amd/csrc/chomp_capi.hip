@@ -800,7 +800,7 @@ static int launch_nu_mass(chomp_ctx* ctx, int mf_kind, const HaloPlan* plan) {
   const size_t n = ctx->n_epoch;
   const TabLayout& L = ctx->L;
 #define CHOMP_NU_TABLE(BAO, NW)                                                                 \
-  hipLaunchKernelGGL((k_nu_table<BAO, NW>), dim3(L.NM, (unsigned)n), dim3(64 * NW), 0, ctx->stream, \
+  hipLaunchKernelGGL((k_nu_table<BAO, NW>), dim3((unsigned)n, L.NM), dim3(64 * NW), 0, ctx->stream, \
                      ctx->cfg, L, ctx->d_epochs, ctx->d_search, ctx->d_snodes, ctx->d_tab,       \
                      ctx->d_status)
   if ((size_t)L.NM * n <= 512) {      // (fewer integrals than SIMDs to put them on)

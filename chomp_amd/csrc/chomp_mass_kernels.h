@@ -942,7 +942,7 @@ constexpr int kProbes = 4;
 constexpr int kProbeStride = 24;   // doubles per epoch: nu[2][kProbes], chi, pad[3], plan[2][4]
 
 // ---------------------------------------------------------------------------
-// k_nu_table: grid (NM, n_epoch), block 64 NW: one sigma(R) Romberg of the nu table per block,
+// k_nu_table: grid (n_epoch, NM), block 64 NW: one sigma(R) Romberg of the nu table per block,
 // nu_i = nu_m(exp(ln_mass_i)) (mass_function.py:205-210).  NW = 1 (one wavefront per integral:
 // most integrals in flight) for a batch of epochs; NW = 4 when the whole launch is a few dozen
 // integrals (one epoch) and lasts as long as one of them.
@@ -956,7 +956,10 @@ __global__ __launch_bounds__(64 * NW) void k_nu_table(chomp_config cfg, TabLayou
                                                       unsigned* __restrict__ status) {
   __shared__ Epoch E;
   __shared__ double red[romberg_scratch<NW, 1>()];
-  const int i = blockIdx.x, e = blockIdx.y;
+  // grid (n_epoch, NM), epochs fastest, the LARGEST mass first: its integral is the longest of an
+  // epoch's fifty (level 12 where the others stop at 10-11), and a launch of single-wavefront
+  // integrals ends with whatever was dispatched last.
+  const int e = blockIdx.x, i = (int)gridDim.y - 1 - (int)blockIdx.y;
   copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
                kEpochDoubles);
   __syncthreads();

@@ -30,7 +30,8 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_probe(
   __shared__ int last, sh_j;
   __shared__ double seeds[2][6];   // per side: dir, jl, nu_l, jh, nu_h, n_eval (uncertified)
   __shared__ int open_side[2];
-  const int e = blockIdx.x, role = PHASE == 2 ? 0 : (int)blockIdx.y;
+  // (roles in reverse dispatch order: the mass_max-side probes -- Romberg levels 12-13 -- first)
+  const int e = blockIdx.x, role = PHASE == 2 ? 0 : 2 * kProbes - 1 - (int)blockIdx.y;
   const bool chi_role = PHASE != 2 && role == kProbes;
   const int side = role / kProbes, p = role % kProbes;
   const bool fixed = cfg.mass_min > 0.0 && cfg.mass_max > 0.0;     // mass_function.py:163-170
