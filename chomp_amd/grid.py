@@ -48,10 +48,14 @@ class HaloGrid(object):
     """
 
     def __init__(self, z, cosmo_dict=None, halo_dict=None, hod_dict=None,
-                 mass_function="st", device=None, stream=None, rank=0, world=1):
+                 mass_function="st", device=None, stream=None, rank=0, world=1,
+                 collective_at_world_1=False):
         self.z_all = numpy.atleast_1d(numpy.asarray(z, dtype=numpy.float64))
         self.n_all = self.z_all.size
         self.rank, self.world = rank, world
+        # (a single rank normally skips the all-gather; True sends it through the process
+        #  group anyway -- how the RCCL path is exercised on a one-GPU box)
+        self._collective_1 = bool(collective_at_world_1)
         self.idx = shard_indices(self.n_all, rank, world)
         pick = lambda v: [v[i] for i in self.idx] if isinstance(v, (list, tuple)) else v
         self.cosmo = pick(cosmo_dict if cosmo_dict is not None
@@ -135,6 +139,7 @@ class HaloGrid(object):
         until the second call after the one that produced it."""
         import torch
         rpr = rows_per_rank(self.n_all, self.world)
+        gathers = self.world > 1 or self._collective_1
         key = (rpr, k.numel(), str(k.device))
         if self._bufs.get("key") != key:
             self._bufs = {"key": key, "turn": 0, "local": [], "full": []}
@@ -143,13 +148,14 @@ class HaloGrid(object):
                     torch.zeros((rpr, k.numel()), dtype=torch.float64, device=k.device))
                 self._bufs["full"].append(
                     torch.empty((self.world * rpr, k.numel()), dtype=torch.float64,
-                                device=k.device) if self.world > 1 else None)
+                                device=k.device) if gathers else None)
         turn = self._bufs["turn"]
         self._bufs["turn"] = turn ^ 1
         local = self._bufs["local"][turn]
         if len(self.idx):
             self.power(which, k, out=local[:len(self.idx)])
-        return gather_rows_async(local, self.n_all, self.world, out=self._bufs["full"][turn])
+        return gather_rows_async(local, self.n_all, self.world, out=self._bufs["full"][turn],
+                                 collective_at_world_1=self._collective_1)
 
 
 _ORDER_CACHE = {}
@@ -175,21 +181,22 @@ class PendingRows(object):
 
     def wait(self):
         import torch
-        if self._world == 1:
-            return self._full[:self._n_all]
         if self._work is not None:
             self._work.wait()
+        if self._world == 1:
+            return self._full[:self._n_all]
         return self._full.index_select(0, _order_tensor(self._n_all, self._world,
                                                         self._full.device))
 
 
-def gather_rows_async(local, n_all, world, out=None):
+def gather_rows_async(local, n_all, world, out=None, collective_at_world_1=False):
     """Launch the all-gather of the per-rank row blocks ([rows_per_rank, nk], zero
     padded) into `out` (allocated if None).  RCCL on GPUs ("nccl" backend), gloo on CPU
-    tensors (the multi-process CPU tests)."""
+    tensors (the multi-process CPU tests).  A single rank has nothing to gather and returns
+    its block, unless collective_at_world_1 asks for the collective all the same."""
     import torch
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not collective_at_world_1:
         return PendingRows(local, None, n_all, world)
     rpr = rows_per_rank(n_all, world)
     assert local.shape[0] == rpr
@@ -218,12 +225,12 @@ def shard_samples(x, rank, world):
     return mine.contiguous()
 
 
-def gather_samples(local, n_all, world):
+def gather_samples(local, n_all, world, collective_at_world_1=False):
     """All-gather the per-rank results of shard_samples and undo the interleaving: the n_all
     values in the caller's sample order on every rank."""
     import torch
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not collective_at_world_1:
         return local[:n_all]
     per = local.shape[0]
     full = torch.empty(world * per, dtype=local.dtype, device=local.device)
