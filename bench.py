@@ -159,14 +159,14 @@ def rehearsal_gathers():
     import torch.distributed as dist
     from chomp_amd import grid
 
-    def gather_rows_async(local, n_all, world, out=None):
+    def gather_rows_async(local, n_all, world, out=None, **_):
         rpr = grid.rows_per_rank(n_all, world)
         assert local.shape[0] == rpr
         host = torch.empty((world * rpr, local.shape[1]), dtype=local.dtype)
         dist.all_gather_into_tensor(host, local.cpu().contiguous())
         return grid.PendingRows(host.to(local.device), None, n_all, world)
 
-    def gather_samples(local, n_all, world):
+    def gather_samples(local, n_all, world, **_):
         per = local.shape[0]
         host = torch.empty(world * per, dtype=local.dtype)
         dist.all_gather_into_tensor(host, local.cpu().contiguous())

@@ -584,6 +584,14 @@ int chomp_debug_ks(long long* out, int n, int clear) {
   }
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(chomp::g_ks), (size_t)n * sizeof(long long));
 }
+// (... and of k_mass_nodes)
+int chomp_debug_ms(long long* out, int n, int clear) {
+  if (clear) {
+    static long long z[64 * 16 * kMStampSlots];
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(chomp::g_ms), z, sizeof(z));
+  }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(chomp::g_ms), (size_t)n * sizeof(long long));
+}
 #endif
 
 int chomp_set_tuning(chomp_ctx* ctx, int what, long long value) {
@@ -852,7 +860,7 @@ static int launch_halo_knots(chomp_ctx* ctx, const HaloPlan& P) {
     kept = ctx->d_kept;
   }
 #define CHOMP_KNOTS(KNW)                                                                          \
-  hipLaunchKernelGGL((k_halo_knots<KNW>), dim3(kb + (P.want_nbar ? 1u : 0u), (unsigned)n, (unsigned)ng), \
+  hipLaunchKernelGGL((k_halo_knots<KNW>), dim3((unsigned)n, kb + (P.want_nbar ? 1u : 0u), (unsigned)ng), \
                      dim3(KNW == 0 ? 64 : 256), shk, ctx->stream, ctx->cfg, L, ctx->d_epochs, ctx->d_tab,        \
                      ctx->d_profile, ctx->d_hod, ctx->d_sici, ctx->d_nodes, ctx->d_endp,          \
                      P.groups[0], P.groups[1], P.groups[2], P.kmask, P.want_nbar, ctx->d_pending, \

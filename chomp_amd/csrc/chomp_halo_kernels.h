@@ -416,6 +416,7 @@ __global__ __launch_bounds__(256) void k_mass_nodes(
   const bool first = blockIdx.y == 0 && blockIdx.z == 0;
   __shared__ unsigned scratch_status;
   __shared__ int scratch_npend;
+  MSTAMP(0);
   copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
                kEpochDoubles);
   if (do_nodes)
@@ -427,12 +428,14 @@ __global__ __launch_bounds__(256) void k_mass_nodes(
   const int n_search = (int)(search[(e * 2 + 0) * 2 + 1] + search[(e * 2 + 1) * 2 + 1]);
   mass_setup_block(cfg, L, E, epochs, e, first, search[(e * 2 + 0) * 2], search[(e * 2 + 1) * 2],
                    n_search, tab + (size_t)e * L.stride, mass_par[e], mf_kind, tinker, gl16, M);
+  MSTAMP(5);
   if (!do_nodes) return;
   if (threadIdx.x < 64)
     halo_epoch_begin(E, profile[e], hod[e], M.c_nu, M.x_lnm[0], L.NM,
                      first ? &status[e] : &scratch_status, first ? &npend[e] : &scratch_npend,
                      pending, first && e == 0);
   __syncthreads();
+  MSTAMP(6);
   if (first)
     copy_doubles(reinterpret_cast<double*>(&epochs[e]), reinterpret_cast<const double*>(&E),
                  kEpochDoubles);
@@ -442,6 +445,7 @@ __global__ __launch_bounds__(256) void k_mass_nodes(
                    nodes + ((size_t)e * 3 + group) * kNodeStride,
                    endp + ((size_t)e * 3 + group) * 2 * L.NK, (mask & kMaskDeepNodes) != 0,
                    (int)blockIdx.z, (int)gridDim.z);
+  MSTAMP(7);
 }
 
 // Halo.calculate_bias / calculate_m_eff / calculate_f_sat (halo.py:709-838): grid (3, n),
@@ -511,8 +515,11 @@ __device__ __forceinline__ int group_fb(int group) {
 // ---------------------------------------------------------------------------
 // KNW = 0: one wavefront per knot pair AND per block (64 threads): a finished knot frees its
 // slot for the next block at once, instead of idling beside the one slow knot of its four.
+#ifndef CHOMP_KNOTS_WAVES
+#define CHOMP_KNOTS_WAVES 3
+#endif
 template <int KNW>
-__global__ __launch_bounds__(KNW == 0 ? 64 : 256) void k_halo_knots(
+__global__ __launch_bounds__(KNW == 0 ? 64 : 256, KNW == 1 ? CHOMP_KNOTS_WAVES : 1) void k_halo_knots(
     chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs, double* __restrict__ tab,
     const chomp_halo_par* __restrict__ profile, const HodDev* __restrict__ hod,
     const SiCiTab* __restrict__ sici_g, const double* __restrict__ nodes,
@@ -523,12 +530,13 @@ __global__ __launch_bounds__(KNW == 0 ? 64 : 256) void k_halo_knots(
   __shared__ SiCiTab S;
   __shared__ Epoch E;              // (the n_bar block only)
   const int NK = L.NK;
-  const int e = blockIdx.y;
+  const int e = blockIdx.x, n_epoch = (int)gridDim.x;
   const int kb = KNW == 1 ? (NK + 3) / 4 : NK;     // knot blocks
-  // Blocks are dispatched x fastest, z slowest: the long units first -- the n_bar integral, the
-  // highest k (the deepest Romberg), the HOD groups (plan slots 1, 2) before the smooth one --
-  // so that the launch ends with the knots that stop at level 6.
-  const int bx = (int)gridDim.x - 1 - (int)blockIdx.x, bz = (int)gridDim.z - 1 - (int)blockIdx.z;
+  KNSTAMP(0, __builtin_amdgcn_s_memrealtime());
+  // Blocks are dispatched x (the epochs) fastest, z slowest: the long units of EVERY epoch first
+  // -- the n_bar integrals, the highest k (the deepest Romberg), the HOD groups (plan slots 1, 2)
+  // before the smooth one -- so that the launch ends with the knots that stop at level 6.
+  const int bx = (int)gridDim.y - 1 - (int)blockIdx.y, bz = (int)gridDim.z - 1 - (int)blockIdx.z;
   if (bx >= kb) {                  // ---- n_bar
     if (!want_nbar || bz != 0) return;
     HaloLds H;
@@ -546,21 +554,115 @@ __global__ __launch_bounds__(KNW == 0 ? 64 : 256) void k_halo_knots(
   copy_doubles(reinterpret_cast<double*>(&S), reinterpret_cast<const double*>(sici_g),
                (int)(sizeof(SiCiTab) / sizeof(double)));
   __syncthreads();
-  const int ik = KNW == 1 ? bx * 4 + (int)(threadIdx.x >> 6) : bx;
-  if (ik >= NK) return;            // (KNW = 1: no barrier below, the wavefronts are independent)
+#ifndef CHOMP_KNOTS_COOP
+#define CHOMP_KNOTS_COOP 1
+#endif
+  constexpr bool kCoop = KNW == 1 && CHOMP_KNOTS_COOP != 0;
+  // KNW = 1 with the cooperative tail (below): wavefront w of block bx takes knot bx + kb w --
+  // the knots that run deep are the highest k, and this way a block holds one of them at most
+  const int ik = KNW == 1 ? (kCoop ? bx + kb * (int)(threadIdx.x >> 6) : bx * 4 + (int)(threadIdx.x >> 6)) : bx;
+  KNSTAMP(1, __builtin_amdgcn_s_memrealtime());
+  const bool have = ik < NK;
+  if (!kCoop && !have) return;     // (no barrier below unless kCoop: the wavefronts are independent)
   const double* node = nodes + ((size_t)e * 3 + group) * kNodeStride;
   const double a = node[kNodeFields * kNodeCount], b = node[kNodeFields * kNodeCount + 1];
-  const double* ep = endp + ((size_t)e * 3 + group) * 2 * NK + 2 * ik;
+  const double* ep = endp + ((size_t)e * 3 + group) * 2 * NK + 2 * (have ? ik : 0);
   const double fb[2] = {ep[0], ep[1]};
   double* t = tab + (size_t)e * L.stride;
-  const double ln_k = linspace_at(log(cfg.k_min), log(cfg.k_max), NK, ik);   // halo.py:52-54
+  const double ln_k0 = log(cfg.k_min), ln_k1 = log(cfg.k_max);
+  const double ln_k = linspace_at(ln_k0, ln_k1, NK, have ? ik : 0);          // halo.py:52-54
   const int sc = bz == 0 ? s0 : (bz == 1 ? s1 : s2);
-  NodeIntegrand f{&S, node, ln_k, (mask & kMaskExclusion) != 0,
-                  (kept != nullptr && sc >= 0) ? kept + kept_offset(sc, (int)gridDim.y, e, NK, ik)
-                                               : nullptr};
+  const bool keeps = kept != nullptr && sc >= 0;
+  const bool exclusion = (mask & kMaskExclusion) != 0;
+  NodeIntegrand f{&S, node, ln_k, exclusion,
+                  keeps ? kept + kept_offset(sc, n_epoch, e, NK, have ? ik : 0) : nullptr};
   const int dmax = cfg.divmax < kNodeLevel ? cfg.divmax : kNodeLevel;
   RombergOut<2> r;
-  if constexpr (KNW <= 1) {
+  if constexpr (kCoop) {
+    // Four knots to a block, one per wavefront, up to level kCoopLevel (four fifths of the
+    // knots stop there: one or two NFW transforms per lane).  The tail -- the one knot in ten
+    // that goes on to levels 8..10, another 2 + 4 + 8 transforms per lane on its own wavefront,
+    // which is what the launch lasted -- is then walked by the WHOLE block, knot after knot
+    // (RombergResume from the state the wavefront left: 1 + 1 + 2 transforms per thread).
+    constexpr int kCoopLevel = 7;
+    __shared__ double co_dump[4][2 * kRombergDump];
+    __shared__ double co_val[4][2];
+    __shared__ int co_lev[4][2], co_conv[4][2], co_need[4];
+    const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    const bool coop = dmax > kCoopLevel;
+    r.value[0] = r.value[1] = 0.0;
+    r.level[0] = r.level[1] = 0;
+    r.converged[0] = r.converged[1] = true;
+    if (have) {
+      if (dmax >= 6)
+        r = romberg_wave6<2>(f, a, b, fb, cfg.global_precision, cfg.halo_precision,
+                             coop ? kCoopLevel : dmax, co_dump[wave]);
+      else
+        r = romberg_group<1, 2>(f, a, b, cfg.global_precision, cfg.halo_precision, dmax, nullptr);
+    }
+    if (lane == 0) {
+      co_need[wave] = (have && coop && !(r.converged[0] && r.converged[1])) ? 1 : 0;
+      co_val[wave][0] = r.value[0]; co_val[wave][1] = r.value[1];
+      co_lev[wave][0] = r.level[0]; co_lev[wave][1] = r.level[1];
+      co_conv[wave][0] = r.converged[0] ? 1 : 0; co_conv[wave][1] = r.converged[1] ? 1 : 0;
+    }
+    __syncthreads();
+    for (int w = 0; w < 4; ++w) {
+      if (!co_need[w]) continue;                 // (block-uniform)
+      const int ikw = bx + kb * w;
+      NodeIntegrand fw{&S, node, linspace_at(ln_k0, ln_k1, NK, ikw), exclusion,
+                       keeps ? kept + kept_offset(sc, n_epoch, e, NK, ikw) : nullptr};
+      RombergResume R[2];
+      bool dn[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        R[q].load(co_dump[w] + q * kRombergDump, kCoopLevel, b - a, cfg.global_precision,
+                  cfg.halo_precision);
+        R[q].value = co_val[w][q];
+        R[q].level = co_lev[w][q];
+        dn[q] = co_conv[w][q] != 0;
+      }
+      bool all = dn[0] && dn[1];
+      int flip = 0;
+      for (int i = kCoopLevel + 1; i <= dmax && !all; ++i) {
+        const double c_il = CHOMP_ROMBERG_C[i][lane & 31];
+        const long numtosum = 1L << (i - 1);
+        const double h = (b - a) / (double)numtosum;
+        const double lox = a + 0.5 * h;
+        double part[2] = {0.0, 0.0};
+        for (long j = threadIdx.x; j < numtosum; j += 256) {
+          double v[2];
+          fw(lox + h * (double)j, v, i, j);
+          part[0] += v[0];
+          part[1] += v[1];
+        }
+        all = true;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const double Sq = group_sum<4>(part[q], sm, flip);
+          if (!dn[q]) {
+            R[q].advance(i, Sq, c_il);
+            dn[q] = R[q].done;
+          }
+          all = all && dn[q];
+        }
+      }
+      __syncthreads();                            // (sm: the last sums have been read)
+      if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          co_val[w][q] = R[q].value;
+          co_lev[w][q] = R[q].level;
+          co_conv[w][q] = dn[q] ? 1 : 0;
+        }
+      }
+    }
+    __syncthreads();
+    if (!have) return;
+    r.value[0] = co_val[wave][0]; r.value[1] = co_val[wave][1];
+    r.level[0] = co_lev[wave][0]; r.level[1] = co_lev[wave][1];
+    r.converged[0] = co_conv[wave][0] != 0; r.converged[1] = co_conv[wave][1] != 0;
+  } else if constexpr (KNW <= 1) {
     if (dmax >= 6)
       r = romberg_wave6<2>(f, a, b, fb, cfg.global_precision, cfg.halo_precision, dmax);
     else
@@ -569,6 +671,8 @@ __global__ __launch_bounds__(KNW == 0 ? 64 : 256) void k_halo_knots(
     (void)fb;
     r = romberg_group<KNW, 2>(f, a, b, cfg.global_precision, cfg.halo_precision, dmax, sm);
   }
+  KNSTAMP(2, __builtin_amdgcn_s_memrealtime());
+  KNSTAMP(3, (r.level[0] > r.level[1] ? r.level[0] : r.level[1]) + 100 * ik);
   if ((KNW <= 1 ? (threadIdx.x & 63) : threadIdx.x) == 0) {
     double* lev = t + L.off_levels;
     const int fa = group_fa(group), fb_ = group_fb(group);
@@ -595,8 +699,8 @@ __global__ __launch_bounds__(KNW == 0 ? 64 : 256) void k_halo_knots(
     // the highest k -- at the front, the rest from the back of the buffer downwards
     if (any) {
       atomicAdd(&npend[e], 1);
-      const int item = (int)((bz * gridDim.y + e) * NK + ik);
-      const int cap = 3 * (int)gridDim.y * NK;
+      const int item = (int)((bz * n_epoch + e) * NK + ik);
+      const int cap = 3 * n_epoch * NK;
       if (4 * ik >= 3 * NK) pending[kPendingHead + atomicAdd(&pending[0], 1)] = item;
       else pending[kPendingHead + cap - 1 - atomicAdd(&pending[2], 1)] = item;
     }

@@ -98,6 +98,33 @@ constexpr unsigned kStNonfinite = CHOMP_ST_NONFINITE;
 constexpr unsigned kStHaloBits = (31u * CHOMP_ST_HALO_DIVMAX_H_M) | CHOMP_ST_NONFINITE;
 
 // Cooperative copy of POD blocks as doubles.
+// Development stamps (-DCHOMP_STAMPS, absent from the product build): s_memtime at the phase
+// boundaries of every block of k_mass_nodes (tools/dev_mass_stamps.py; block (x, 0, z) < (64, 1, 8))
+// or, with -DCHOMP_STAMPS=2, of k_halo_knots<1> (block (x, y, 0) < (64, 14, 1)).
+#ifdef CHOMP_STAMPS
+constexpr int kMStampSlots = 16;
+static __device__ long long g_ms[64 * 16 * kMStampSlots];
+#endif
+#if defined(CHOMP_STAMPS) && CHOMP_STAMPS != 2
+#define MSTAMP(k)                                                                              \
+  do {                                                                                         \
+    if (threadIdx.x == 0 && blockIdx.x < 64 && blockIdx.y == 0 && blockIdx.z < 8)              \
+      g_ms[(blockIdx.x * 8 + blockIdx.z) * kMStampSlots + (k)] =                               \
+          (long long)__builtin_amdgcn_s_memtime();                                             \
+  } while (0)
+#else
+#define MSTAMP(k) do { } while (0)
+#endif
+#if defined(CHOMP_STAMPS) && CHOMP_STAMPS == 2
+#define KNSTAMP(k, v)                                                                          \
+  do {                                                                                         \
+    if ((threadIdx.x & 63) == 0 && blockIdx.y < 14 && blockIdx.x < 64 && blockIdx.z == 0)      \
+      g_ms[((blockIdx.x * 14 + blockIdx.y) * 4 + (threadIdx.x >> 6)) * 4 + (k)] = (long long)(v); \
+  } while (0)
+#else
+#define KNSTAMP(k, v) do { } while (0)
+#endif
+
 __device__ __forceinline__ void copy_doubles(double* dst, const double* src, int n) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
 }
@@ -1044,11 +1071,13 @@ __device__ __forceinline__ void mass_setup_block(
   copy_doubles(M.y_nu, t + L.off_nu, NM);
   copy_doubles(M.gl, gl16, 32);
   __syncthreads();
+  MSTAMP(1);
   {   // nu(ln M) on threads 0..127, ln M(nu) on threads 128..255, in lockstep
     const int sys = threadIdx.x >> 7, tid = threadIdx.x & 127;
     spline_build_pcr(sys == 0 ? M.x_lnm : M.y_nu, sys == 0 ? M.y_nu : M.x_lnm, NM,
                      sys == 0 ? M.c_nu : M.c_lnm, M.work + sys * 9 * NM, tid, 128, true);
   }
+  MSTAMP(2);
   if (threadIdx.x == 0) {
     E.ln_mass_min = ln_mass_min;
     E.ln_mass_max = ln_mass_max;
@@ -1077,6 +1106,7 @@ __device__ __forceinline__ void mass_setup_block(
     }
   }
   __syncthreads();
+  MSTAMP(3);
   // Normalisations (mass_function.py:225-241; Tinker: bias only, :532-545).  The
   // reference integrates in linear nu with Romberg to rtol 1.48e-8 (8193 nodes);
   // the integrand is analytic, so 8 x 16 Gauss-Legendre nodes in ln nu give the
@@ -1127,6 +1157,7 @@ __device__ __forceinline__ void mass_setup_block(
     }
     __syncthreads();
   }
+  MSTAMP(4);
   if (!publish) return;
   copy_doubles(reinterpret_cast<double*>(&epochs[e]), reinterpret_cast<const double*>(&E),
                kEpochDoubles);

@@ -402,11 +402,13 @@ __device__ __forceinline__ RombergOut<NF> romberg_group(const F& f, double a, do
 // Rows 0..6 and their stopping tests are replayed from the per-level sums exactly as in
 // romberg_group's multi-wavefront first round; deeper levels walk on as romberg_group<1>.
 // A knot that scipy stops at level 6 costs one evaluation per lane, at level 7 two.
-// Needs divmax >= 6.
+// Needs divmax >= 6.  dump (optional, kRombergDump * NF doubles, LDS or global): the state the
+// integral stopped in, as romberg_group leaves it, for whoever carries it on (RombergResume).
 template <int NF, class F>
 __device__ __forceinline__ RombergOut<NF> romberg_wave6(const F& f, double a, double b,
                                                         const double (&fb)[NF], double tol,
-                                                        double rtol, int divmax) {
+                                                        double rtol, int divmax,
+                                                        double* dump = nullptr) {
   constexpr int L0max = 6;
   const int lane = threadIdx.x & 63;
   const int cl = lane & 31;
@@ -511,6 +513,16 @@ __device__ __forceinline__ RombergOut<NF> romberg_wave6(const F& f, double a, do
   }
 #pragma unroll
   for (int q = 0; q < NF; ++q) out.converged[q] = done[q];
+  if (dump != nullptr) {
+#pragma unroll
+    for (int q = 0; q < NF; ++q) {
+      if (lane < 32) dump[q * kRombergDump + lane] = Tl[q];
+      if (lane == 0) {
+        dump[q * kRombergDump + 32] = ordsum[q];
+        dump[q * kRombergDump + 33] = prev[q];
+      }
+    }
+  }
   return out;
 }
 
