@@ -156,6 +156,7 @@ struct chomp_ctx {
   bool timing_valid = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<int> slot;           // host copy: epoch -> cosmology slot
+  size_t n_slots = 1;              // distinct cosmologies of the batch
   size_t cap_in = 0, cap_in2 = 0, cap_out = 0;
 
   // projection
@@ -713,6 +714,7 @@ int chomp_epochs_set(chomp_ctx* ctx, size_t n_epoch, const chomp_cosmo* cosmo,
     }
   }
   const size_t n_slots = first.size();
+  ctx->n_slots = n_slots;
   ctx->slot = slot;
   first.resize(n_epoch, 0);
   rc = upload(ctx, ctx->d_slot, slot.data(), n_epoch * sizeof(int), ctx->sh_slot);
@@ -807,10 +809,13 @@ static int halo_prepare(chomp_ctx* ctx, const chomp_halo_par* profile, const cho
 static int launch_nu_mass(chomp_ctx* ctx, int mf_kind, const HaloPlan* plan) {
   const size_t n = ctx->n_epoch;
   const TabLayout& L = ctx->L;
+  // (one cosmology or a few: epochs fastest in dispatch order, the longest integrals first;
+  //  a cosmology per epoch: an epoch's masses side by side -- see k_nu_table)
+  const int ef = ctx->n_slots < 16 ? 1 : 0;
 #define CHOMP_NU_TABLE(BAO, NW)                                                                 \
-  hipLaunchKernelGGL((k_nu_table<BAO, NW>), dim3((unsigned)n, L.NM), dim3(64 * NW), 0, ctx->stream, \
-                     ctx->cfg, L, ctx->d_epochs, ctx->d_search, ctx->d_snodes, ctx->d_tab,       \
-                     ctx->d_status)
+  hipLaunchKernelGGL((k_nu_table<BAO, NW>), ef ? dim3((unsigned)n, L.NM) : dim3(L.NM, (unsigned)n), \
+                     dim3(64 * NW), 0, ctx->stream, ctx->cfg, L, ctx->d_epochs, ctx->d_search,   \
+                     ctx->d_snodes, ctx->d_tab, ctx->d_status, ef)
   if ((size_t)L.NM * n <= 512) {      // (fewer integrals than SIMDs to put them on)
     if (ctx->with_bao) CHOMP_NU_TABLE(true, 4); else CHOMP_NU_TABLE(false, 4);
   } else {

@@ -498,7 +498,7 @@ __device__ __forceinline__ int group_fb(int group) {
 }
 
 // ---------------------------------------------------------------------------
-// k_halo_knots: grid (ceil(NK / 4) [+ 1], n_epoch, n_groups), block 256 = four wavefronts,
+// k_halo_knots: grid (n_epoch, ceil(NK / 4) [+ 1], n_groups), block 256 = four wavefronts,
 // each with one knot ln k_i of group groups[blockIdx.z] (0: h_m + pp_mm, 1: h_g + pp_gm,
 // 2: pp_gg): the pair's Romberg on the node table, levels <= kNodeLevel.  The first round
 // fills the wavefront exactly (romberg_wave6: lane p on node p of the level-6 grid, the
@@ -507,19 +507,24 @@ __device__ __forceinline__ int group_fb(int group) {
 // converged at the depth of the node table are listed for k_halo_knots_fast (pending[];
 // npend[e] counts an epoch's listed knots on top of its token).  A block only stages the
 // Si/Ci tables: everything else it needs is in the (epoch, group) node table.
-// With want_nbar the extra x-block of z == 0 does the epoch's n_bar integral
+// With want_nbar the extra y-block of z == 0 does the epoch's n_bar integral
 // (halo.py:674-700) beside the knots.
-// KNW = 4 (a whole block per knot pair, grid x = NK [+ 1]): for a set-up of one or a few epochs,
+// The epochs are the FASTEST grid axis: blocks are dispatched in linear order, a (k, z) grid's
+// launch is 900 blocks for 512-768 resident ones, and with the epochs slowest the last epochs'
+// deepest knots entered the chip 11-15 us into the launch (tools/dev_knots_stamps2.py).
+// KNW = 1 (a batch of a few dozen epochs): four knots to a block up to level 7, then the
+// block's knots that go on are walked by all four wavefronts together (below), capped at three
+// wavefronts per SIMD (168 registers, 4 spills: every block of a 64-epoch launch but the last
+// 128 is resident at once).  37.9 -> 29.6 us per configs[1] launch.
+// KNW = 4 (a whole block per knot pair, grid y = NK [+ 1]): for a set-up of one or a few epochs,
 // whose launch lasts as long as its slowest knot -- 1, 1, 2, 4, 8 NFW transforms per lane at
 // levels 6..10 on one wavefront, 1, 1, 1, 1, 2 on four.
 // ---------------------------------------------------------------------------
 // KNW = 0: one wavefront per knot pair AND per block (64 threads): a finished knot frees its
-// slot for the next block at once, instead of idling beside the one slow knot of its four.
-#ifndef CHOMP_KNOTS_WAVES
-#define CHOMP_KNOTS_WAVES 3
-#endif
+// slot for the next block at once, instead of idling beside the one slow knot of its four
+// (from ~80 epochs x 50 knots on, and for the two-group HOD set-ups).
 template <int KNW>
-__global__ __launch_bounds__(KNW == 0 ? 64 : 256, KNW == 1 ? CHOMP_KNOTS_WAVES : 1) void k_halo_knots(
+__global__ __launch_bounds__(KNW == 0 ? 64 : 256, KNW == 1 ? 3 : 1) void k_halo_knots(
     chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs, double* __restrict__ tab,
     const chomp_halo_par* __restrict__ profile, const HodDev* __restrict__ hod,
     const SiCiTab* __restrict__ sici_g, const double* __restrict__ nodes,
@@ -554,10 +559,7 @@ __global__ __launch_bounds__(KNW == 0 ? 64 : 256, KNW == 1 ? CHOMP_KNOTS_WAVES :
   copy_doubles(reinterpret_cast<double*>(&S), reinterpret_cast<const double*>(sici_g),
                (int)(sizeof(SiCiTab) / sizeof(double)));
   __syncthreads();
-#ifndef CHOMP_KNOTS_COOP
-#define CHOMP_KNOTS_COOP 1
-#endif
-  constexpr bool kCoop = KNW == 1 && CHOMP_KNOTS_COOP != 0;
+  constexpr bool kCoop = KNW == 1;
   // KNW = 1 with the cooperative tail (below): wavefront w of block bx takes knot bx + kb w --
   // the knots that run deep are the highest k, and this way a block holds one of them at most
   const int ik = KNW == 1 ? (kCoop ? bx + kb * (int)(threadIdx.x >> 6) : bx * 4 + (int)(threadIdx.x >> 6)) : bx;

@@ -105,7 +105,16 @@ constexpr unsigned kStHaloBits = (31u * CHOMP_ST_HALO_DIVMAX_H_M) | CHOMP_ST_NON
 constexpr int kMStampSlots = 16;
 static __device__ long long g_ms[64 * 16 * kMStampSlots];
 #endif
-#if defined(CHOMP_STAMPS) && CHOMP_STAMPS != 2
+#if defined(CHOMP_STAMPS) && CHOMP_STAMPS == 3   /* k_nu_table<., 1>, block (x, y) < (64, 50) */
+#define NUSTAMP(k, v)                                                                          \
+  do {                                                                                         \
+    if (threadIdx.x == 0 && blockIdx.x < 64 && blockIdx.y < 50)                                \
+      g_ms[(blockIdx.x * 50 + blockIdx.y) * 4 + (k)] = (long long)(v);                         \
+  } while (0)
+#else
+#define NUSTAMP(k, v) do { } while (0)
+#endif
+#if defined(CHOMP_STAMPS) && CHOMP_STAMPS == 1
 #define MSTAMP(k)                                                                              \
   do {                                                                                         \
     if (threadIdx.x == 0 && blockIdx.x < 64 && blockIdx.y == 0 && blockIdx.z < 8)              \
@@ -609,7 +618,8 @@ template <int NW, int UNROLL = 1, bool BAO = false>
 __device__ __forceinline__ double sigma2_block(const Epoch& E, const double* snode, double R,
                                                const chomp_config& cfg, double rtol,
                                                double* red, bool* converged = nullptr,
-                                               const RombergLoose* loose = nullptr) {
+                                               const RombergLoose* loose = nullptr,
+                                               int* level_out = nullptr) {
   double lo, hi;
   sigma_limits(E, R, &lo, &hi);
   const double need_min = 1.0 / R / 10.0, need_max = 1.0 / R * 14.0662;
@@ -639,6 +649,7 @@ __device__ __forceinline__ double sigma2_block(const Epoch& E, const double* sno
           f, lo, hi, cfg.global_precision, rtol, cfg.divmax, red, nullptr, loose ? &ls : nullptr);
     }
     if (converged) *converged = r.converged[0];
+    if (level_out) *level_out = r.level[0];
     return amp2 * r.value[0];
   }
   if constexpr (!BAO) {
@@ -658,6 +669,7 @@ __device__ __forceinline__ double sigma2_block(const Epoch& E, const double* sno
       r = romberg_group<NW, 1>(w, lo, hi, cfg.global_precision, rtol, cfg.divmax, red, nullptr, loose);
     }
     if (converged) *converged = r.converged[0];
+    if (level_out) *level_out = 100 + r.level[0];     // (100 +: the interpolated integrand)
     return r.value[0];
   } else {
     SigmaIntegrandT<BAO> f{&E, R};
@@ -706,9 +718,10 @@ __device__ __forceinline__ double nu_of_mass_block(const Epoch& E, const double*
                                                    double mass, const chomp_config& cfg,
                                                    double rtol, double* red,
                                                    bool* converged = nullptr,
-                                                   const RombergLoose* loose = nullptr) {
+                                                   const RombergLoose* loose = nullptr,
+                                                   int* level_out = nullptr) {
   const double s2 = sigma2_block<NW, UNROLL, BAO>(E, snode, scale_of_mass(E, mass), cfg, rtol, red,
-                                                  converged, loose);
+                                                  converged, loose, level_out);
   const double sq = E.delta_c / sqrt(s2);
   return sq * sq;
 }
@@ -969,10 +982,16 @@ constexpr int kProbes = 4;
 constexpr int kProbeStride = 24;   // doubles per epoch: nu[2][kProbes], chi, pad[3], plan[2][4]
 
 // ---------------------------------------------------------------------------
-// k_nu_table: grid (n_epoch, NM), block 64 NW: one sigma(R) Romberg of the nu table per block,
+// k_nu_table: one sigma(R) Romberg of the nu table per block of 64 NW threads,
 // nu_i = nu_m(exp(ln_mass_i)) (mass_function.py:205-210).  NW = 1 (one wavefront per integral:
 // most integrals in flight) for a batch of epochs; NW = 4 when the whole launch is a few dozen
 // integrals (one epoch) and lasts as long as one of them.
+// epochs_fastest != 0: grid (n_epoch, NM), the LARGEST mass first -- its integral is the longest
+// of an epoch's fifty (level 12 where the others stop at 10-11), and a launch of single-wavefront
+// integrals ends with whatever was dispatched last (a (k, z) grid: one cosmology, one sigma(R)
+// node table for everybody).  epochs_fastest == 0: grid (NM, n_epoch), an epoch's fifty masses
+// side by side -- a batch of many cosmologies, where the blocks in flight should share as few of
+// the 131 KB node tables as possible (1024 cosmologies, epochs fastest: 600 us against 420).
 // ---------------------------------------------------------------------------
 template <bool BAO, int NW>
 __global__ __launch_bounds__(64 * NW) void k_nu_table(chomp_config cfg, TabLayout L,
@@ -980,22 +999,32 @@ __global__ __launch_bounds__(64 * NW) void k_nu_table(chomp_config cfg, TabLayou
                                                       const double* __restrict__ search,
                                                       const double* __restrict__ snodes,
                                                       double* __restrict__ tab,
-                                                      unsigned* __restrict__ status) {
+                                                      unsigned* __restrict__ status,
+                                                      int epochs_fastest) {
   __shared__ Epoch E;
   __shared__ double red[romberg_scratch<NW, 1>()];
-  // grid (n_epoch, NM), epochs fastest, the LARGEST mass first: its integral is the longest of an
-  // epoch's fifty (level 12 where the others stop at 10-11), and a launch of single-wavefront
-  // integrals ends with whatever was dispatched last.
-  const int e = blockIdx.x, i = (int)gridDim.y - 1 - (int)blockIdx.y;
+  const int e = epochs_fastest ? (int)blockIdx.x : (int)blockIdx.y;
+  const int i = epochs_fastest ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.x;
+  NUSTAMP(0, __builtin_amdgcn_s_memrealtime());
   copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
                kEpochDoubles);
   __syncthreads();
+  NUSTAMP(1, __builtin_amdgcn_s_memrealtime());
   const double* snode = snodes + (size_t)E.cosmo_slot * kSigmaStride;
   const double ln_lo = search[(e * 2 + 0) * 2], ln_hi = search[(e * 2 + 1) * 2];
   const double lnm = linspace_at(ln_lo, ln_hi, L.NM, i);
   bool conv = true;
+#if defined(CHOMP_STAMPS) && CHOMP_STAMPS == 3
+  int lev_dbg = 0;
+  const double nu = nu_of_mass_block<NW, 1, BAO>(E, snode, exp(lnm), cfg, cfg.cosmo_precision,
+                                                 red, &conv, nullptr, &lev_dbg);
+  NUSTAMP(1, lev_dbg);
+#else
   const double nu = nu_of_mass_block<NW, 1, BAO>(E, snode, exp(lnm), cfg, cfg.cosmo_precision,
                                                  red, &conv);
+#endif
+  NUSTAMP(2, __builtin_amdgcn_s_memrealtime());
+  NUSTAMP(3, (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32));   // HW_ID, XCC_ID
   if (threadIdx.x == 0) {
     double* t = tab + (size_t)e * L.stride;
     t[L.off_ln_mass + i] = lnm;
