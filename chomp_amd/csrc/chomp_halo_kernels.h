@@ -325,10 +325,14 @@ __device__ __forceinline__ void halo_nodes_block(const chomp_config& cfg, const 
     node[kNodeFields * kNodeCount] = a;
     node[kNodeFields * kNodeCount + 1] = b;
   }
-  if (chunk + n_chunks * (int)threadIdx.x >= L.NK) return;
+  // (the knots' end points from the TOP of the block: with six or more chunks of a level-10
+  //  table the node loop leaves the last wavefront idle, and its lanes do this beside it -- a
+  //  second node's fields and an NFW transform that the threads of wavefront 0 did after theirs)
+  const int rt = (int)blockDim.x - 1 - (int)threadIdx.x;
+  if (chunk + n_chunks * rt >= L.NK) return;
   double fb[kNodeFields];
   halo_node_fields(E, nu_knots, lnm_pp, L.NM, group, b, fb);   // (every thread: no exchange)
-  for (int ik = chunk + n_chunks * (int)threadIdx.x; ik < L.NK; ik += n_chunks * (int)blockDim.x) {
+  for (int ik = chunk + n_chunks * rt; ik < L.NK; ik += n_chunks * (int)blockDim.x) {
     const double ln_k = linspace_at(log(cfg.k_min), log(cfg.k_max), L.NK, ik);
     double o[2];
     node_pair(S, ln_k, exclusion, fb[0], fb[1], fb[2], fb[3], fb[4], fb[5], fb[6], o);
