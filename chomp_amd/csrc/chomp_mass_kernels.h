@@ -114,6 +114,15 @@ static __device__ long long g_ms[64 * 16 * kMStampSlots];
 #else
 #define NUSTAMP(k, v) do { } while (0)
 #endif
+#if defined(CHOMP_STAMPS) && CHOMP_STAMPS == 4   /* k_epoch_probe<., 0>, block (x, y) < (64, 8) */
+#define PSTAMP(k)                                                                              \
+  do {                                                                                         \
+    if (threadIdx.x == 0 && blockIdx.x < 64 && blockIdx.y < 8)                                 \
+      g_ms[(blockIdx.x * 8 + blockIdx.y) * 8 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define PSTAMP(k) do { } while (0)
+#endif
 #if defined(CHOMP_STAMPS) && CHOMP_STAMPS == 1
 #define MSTAMP(k)                                                                              \
   do {                                                                                         \
@@ -1004,7 +1013,21 @@ __global__ __launch_bounds__(64 * NW) void k_nu_table(chomp_config cfg, TabLayou
   __shared__ Epoch E;
   __shared__ double red[romberg_scratch<NW, 1>()];
   const int e = epochs_fastest ? (int)blockIdx.x : (int)blockIdx.y;
-  const int i = epochs_fastest ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.x;
+  int i = (int)blockIdx.x;
+  if (epochs_fastest) {
+    // Largest mass first -- but the first two and the last two rows take four masses from the
+    // MIDDLE of the table.  Blocks go to the SIMDs round-robin (1024 of them: a SIMD gets linear
+    // blocks b, b + 1024, b + 2048, ...), a 64-epoch launch is 3200 wavefronts, so the SIMDs of
+    // the first two rows get a fourth one from the last two; the SIMDs run at their VALU issue
+    // rate from the first microsecond to the last (tools/dev_nu_stamps3.py), so the launch lasts
+    // as long as the most loaded of them -- and the largest masses (Romberg level 12) are the
+    // longest integrals, the middle ones (level 10-11 on the node table) the shortest.
+    const int NM = (int)gridDim.y, y = (int)blockIdx.y, m0 = NM / 2 - 1;
+    if (NM < 8) i = NM - 1 - y;
+    else if (y < 2) i = m0 + y;
+    else if (y >= NM - 2) i = m0 + 2 + (y - (NM - 2));
+    else { i = NM - 1 - (y - 2); if (i <= m0 + 3) i -= 4; }
+  }
   NUSTAMP(0, __builtin_amdgcn_s_memrealtime());
   copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
                kEpochDoubles);

@@ -24,3 +24,14 @@ void launch_epoch_probe(bool bao, unsigned n_epoch, hipStream_t stream, const ch
 }
 
 }  // namespace chomp
+
+#if defined(CHOMP_STAMPS) && CHOMP_STAMPS == 4
+// (development builds only: the stamps of k_epoch_probe, tools/dev_probe_stamps4.py)
+extern "C" int chomp_debug_ps(long long* out, int n, int clear) {
+  if (clear) {
+    static long long z[64 * 16 * chomp::kMStampSlots];
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(chomp::g_ms), z, sizeof(z));
+  }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(chomp::g_ms), (size_t)n * sizeof(long long));
+}
+#endif

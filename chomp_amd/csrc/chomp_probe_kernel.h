@@ -36,6 +36,7 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_probe(
   const int side = role / kProbes, p = role % kProbes;
   const bool fixed = cfg.mass_min > 0.0 && cfg.mass_max > 0.0;     // mass_function.py:163-170
   if (fixed && !chi_role) return;
+  PSTAMP(0);
   copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
                kEpochDoubles);
   __syncthreads();
@@ -48,6 +49,7 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_probe(
   }
   __syncthreads();
   double* pr = probe + (size_t)e * kProbeStride;
+  PSTAMP(1);
   if (chi_role) {                  // comoving distance, cosmology.py:106-110
     EIntegrand f{E.om0, E.ol0, E.or0, E.H0};
     const double chi = romberg1<kInitNW>(f, 0.0, E.z, cfg.global_precision,
@@ -70,7 +72,9 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_probe(
   }
   if constexpr (PHASE != 2) {
     // ---- this block's probe: candidate j - 2 + p of its side
+    PSTAMP(2);
     const SidePlan plan = plan_side(E, lns, side, cand, &sh_j);
+    PSTAMP(3);
     const SideThresholds T = side_thresholds(side, cand);
     double nu_mine = NAN;
     if (plan.ok && plan.dir != 0) {
@@ -90,6 +94,7 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_probe(
       }
     }
   }
+  PSTAMP(4);
   if constexpr (PHASE == 1) return;
   if constexpr (PHASE == 0) {
     if (threadIdx.x == 0) {
@@ -97,6 +102,7 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_probe(
       last = atomicAdd(&count[e], 1) == 2 * kProbes - 1 ? 1 : 0;
     }
     __syncthreads();
+    PSTAMP(5);
     if (!last) return;
     __threadfence();
   }
@@ -203,6 +209,7 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_probe(
   __syncthreads();
   copy_doubles(reinterpret_cast<double*>(&epochs[e]), reinterpret_cast<const double*>(&E),
                kEpochDoubles);
+  PSTAMP(6);
 }
 
 }  // namespace chomp
