@@ -827,7 +827,7 @@ static int launch_nu_mass(chomp_ctx* ctx, int mf_kind, const HaloPlan* plan) {
   // (node-table chunks: as many blocks per (epoch, group) as keep the launch under ~2 blocks
   //  per CU -- below that the chip is idle anyway and each block's node loop gets shorter)
   unsigned chunks = plan ? (unsigned)(512 / (n * ng)) : 1u;
-  chunks = chunks < 1 ? 1 : (chunks > 6 ? 6 : chunks);
+  chunks = chunks < 1 ? 1 : (chunks > 12 ? 12 : chunks);
   hipLaunchKernelGGL(k_mass_nodes, dim3((unsigned)n, (unsigned)ng, chunks), dim3(256), sh, ctx->stream,
                      ctx->cfg, L, ctx->d_epochs, ctx->d_search, ctx->d_tab, ctx->d_mass_par, mf_kind,
                      ctx->d_tinker, ctx->d_gl16, plan ? 1 : 0, ctx->d_profile, ctx->d_hod,
