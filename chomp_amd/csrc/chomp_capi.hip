@@ -811,7 +811,8 @@ static int launch_nu_mass(chomp_ctx* ctx, int mf_kind, const HaloPlan* plan) {
   const TabLayout& L = ctx->L;
   // (one cosmology or a few: epochs fastest in dispatch order, the longest integrals first;
   //  a cosmology per epoch: an epoch's masses side by side -- see k_nu_table)
-  const int ef = ctx->n_slots < 16 ? 1 : 0;
+  //  (the epochs as the grid's y axis: at most 65535 of them)
+  const int ef = (ctx->n_slots < 16 || n > 65535) ? 1 : 0;
 #define CHOMP_NU_TABLE(BAO, NW)                                                                 \
   hipLaunchKernelGGL((k_nu_table<BAO, NW>), ef ? dim3((unsigned)n, L.NM) : dim3(L.NM, (unsigned)n), \
                      dim3(64 * NW), 0, ctx->stream, ctx->cfg, L, ctx->d_epochs, ctx->d_search,   \
