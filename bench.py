@@ -733,32 +733,34 @@ def main():
     if world == 1 and not args.no_other_configs and args.workload == "c2":
         other = {}
         del hg
-        e3, hg3, k3, _ = grid_leg(D, "power_gm", "tinker", NZ, 10, 2, stream)
+        n_o = 30                                     # (timed steps of each of these legs)
+        e3, hg3, k3, _ = grid_leg(D, "power_gm", "tinker", NZ, n_o, 3, stream)
         ts3 = timed(lambda: hg3.setup("power_gm"), 5)
         f3 = stage_k_roofline(ts3, "c3")
         other["c3"] = {"workload": "configs[2]: power_gm, Tinker10 + Zheng07, 4096 k x 64 z",
-                       "ms_per_step": 1e3 * e3 / 10, "value": NZ * NK * 10 / e3,
-                       "unit": "samples/s", "steps": 10,
+                       "ms_per_step": 1e3 * e3 / n_o, "value": NZ * NK * n_o / e3,
+                       "unit": "samples/s", "steps": n_o,
                        "dominant_kernel": "k_halo_knots_fast (knots beyond the node tables: "
                                           "level sums from 2049 coarse samples)",
                        "stage_k_ms": ts3 * 1e3,
                        "frac": f3["frac"] if f3 else None,
-                       "frac_of": "vector-fp64 peak, Stage K (profiles/round2_stage_k_counters.json)",
+                       "frac_of": "vector-fp64 peak, Stage K (FLOP per step: profiles/%s)"
+                                  % STAGE_K_COUNTER_FILES[0],
                        "deep_knots_fast_literal_cumulative": list(hg3.ctx.deep_stats())}
         del hg3
         for name, ggl in (("c4", False), ("c5", True)):
-            ep = projection_leg(D, ggl, 10, 2)
+            ep = projection_leg(D, ggl, n_o, 3)
             other[name] = {"workload": "configs[%d]: %s, 1024 theta + 2048 l" % (
                                4 if ggl else 3, "GGL J2 kernel + HaloFit power_gm" if ggl
                                else "clustering J0 kernel + power_gg"),
-                           "ms_per_step": 1e3 * ep / 10, "value": (N_THETA + N_ELL) * 10 / ep,
-                           "unit": "samples/s", "steps": 10,
+                           "ms_per_step": 1e3 * ep / n_o, "value": (N_THETA + N_ELL) * n_o / ep,
+                           "unit": "samples/s", "steps": n_o,
                            "dominant_kernel": "none above a fifth of the step: k_halo_knots_fast "
                                               "(knots beyond the node tables), k_cell + k_cell_deep, "
                                               "k_wtheta_nodes / _moments / _fast (level sums from "
                                               "prefix moments)",
                            "frac": None,
-                           "profile": "profiles/round2_kernel_stats_%s.csv" % name}
+                           "profile": "profiles/round3_kernel_stats_%s.csv" % name}
         res["other_configs"] = other
     # ---- the batch-over-parameters axis: where Stage K fills the chip
     if world == 1 and not args.no_batch_scaling and args.workload == "c2":
