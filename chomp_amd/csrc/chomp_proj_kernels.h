@@ -1535,6 +1535,117 @@ __global__ __launch_bounds__(256, DIRECT ? 2 : 3) void k_cell(chomp_config cfg, 
   }
 }
 
+// k_cell4: the same integrals, FOUR multipoles to a block -- one per wavefront up to level
+// kCell4Level (romberg_wave6: a multipole that stops at level 7..8, the rule, costs two to four
+// nodes per lane and no block barrier), then the block's multipoles that go on are walked by all
+// four wavefronts together up to `split` (RombergResume from the rows the wavefront left), and
+// what has not converged there is listed for k_cell_deep exactly as k_cell lists it.  The block's
+// staging (epoch record, spectrum splines, projection tables) is shared by its four multipoles,
+// and the 2048 multipoles of configs[3] / [4] are 512 blocks: resident at once, where k_cell's
+// 2048 blocks took three rounds.  Wavefront w of block b takes multipole b + gridDim.x w (the
+// deep ones are the highest l: one to a block).  grid ceil(n_ell / 4), block 256; the lean
+// instance only (split <= LT, split >= 6).
+constexpr int kCell4Level = 8;     // (7: 27.6, 8: 24.3, 9: 25.2, 10: 28.7 us per configs[3] launch)
+template <bool HF, bool BAO>
+__global__ __launch_bounds__(256, 3) void k_cell4(chomp_config cfg, TabLayout HL, ProjLayout L,
+                                              const Epoch* __restrict__ epochs, int e,
+                                              const double* __restrict__ htab, int which,
+                                              const ProjDev* __restrict__ pdg,
+                                              const double* __restrict__ ptab, double D_z,
+                                              const double* __restrict__ ell, int n_ell,
+                                              double* __restrict__ out,
+                                              const double* __restrict__ nodes, int LT,
+                                              const double* __restrict__ pk_tab, int split,
+                                              int* __restrict__ deep, double* __restrict__ state) {
+  extern __shared__ __align__(16) double sm[];
+  __shared__ Epoch E;
+  __shared__ ProjDev pd;
+  __shared__ double red[romberg_scratch<4, 2>()];
+  __shared__ double co_dump[4][kRombergDump];
+  __shared__ double co_val[4];
+  __shared__ int co_need[4], co_conv[4];
+  copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
+               kEpochDoubles);
+  copy_doubles(reinterpret_cast<double*>(&pd), reinterpret_cast<const double*>(pdg), kProjDoubles);
+  __syncthreads();
+  PowerEval P;
+  P.stage(cfg, HL, &E, htab + (size_t)e * HL.stride, which, sm);
+  ProjLds G;
+  G.stage(L, pd, ptab, sm + 12 * (HL.NK - 1));
+  G.bess = nullptr;
+  __syncthreads();
+  P.template finish_t<BAO>();
+  const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+  const int il = (int)blockIdx.x + (int)gridDim.x * wave;
+  const bool have = il < n_ell;
+  const double px0 = log(cfg.k_min), pdx = (log(cfg.k_max) - px0) / (double)kPTabN;
+  const double a = pd.chi_min, b = pd.chi_max;
+  const bool hand_over = split < cfg.divmax;
+  const int top = split < kCell4Level ? split : kCell4Level;      // (the wavefronts' own levels)
+  RombergOut<1> r;
+  r.value[0] = 0.0; r.level[0] = 0; r.converged[0] = true;
+  if (have) {
+    const double l = ell[il];
+    CellTabIntegrand<HF, BAO, false> f{&P, nodes, (1L << LT) + 1, LT, l, log(l), pk_tab, px0, pdx,
+                                       1.0 / pdx, {&P, &G, l, 1.0 / (D_z * D_z)}};
+    double fb[1];
+    f(b, fb, 0, 1L);                             // (the upper end point: node 1 of level 0)
+    r = romberg_wave6<1>(f, a, b, fb, cfg.global_precision, cfg.corr_precision, top, co_dump[wave]);
+  }
+  if (lane == 0) {
+    co_need[wave] = (have && !r.converged[0] && split > top) ? 1 : 0;
+    co_val[wave] = r.value[0];
+    co_conv[wave] = r.converged[0] ? 1 : 0;
+  }
+  __syncthreads();
+  for (int w = 0; w < 4; ++w) {
+    if (!co_need[w]) continue;                   // (block-uniform)
+    const int ilw = (int)blockIdx.x + (int)gridDim.x * w;
+    const double l = ell[ilw];
+    CellTabIntegrand<HF, BAO, false> f{&P, nodes, (1L << LT) + 1, LT, l, log(l), pk_tab, px0, pdx,
+                                       1.0 / pdx, {&P, &G, l, 1.0 / (D_z * D_z)}};
+    RombergResume R;
+    R.load(co_dump[w], top, b - a, cfg.global_precision, cfg.corr_precision);
+    int flip = 0;
+    for (int i = top + 1; i <= split && !R.done; ++i) {
+      const double c_il = CHOMP_ROMBERG_C[i][lane & 31];
+      const long numtosum = 1L << (i - 1);
+      const double h = (b - a) / (double)numtosum;
+      const double lox = a + 0.5 * h;
+      double part = 0.0;
+      for (long j = threadIdx.x; j < numtosum; j += 256) {
+        double v[1];
+        f(lox + h * (double)j, v, i, j);
+        part += v[0];
+      }
+      const double S = group_sum<4>(part, red, flip);
+      R.advance(i, S, c_il);
+    }
+    __syncthreads();                             // (red: the last sum has been read)
+    if (threadIdx.x < 64) {                      // (every wavefront holds the same rows)
+      if (!R.done && hand_over) {
+        double* st = state + (size_t)ilw * kRombergDump;
+        if (lane < 32) st[lane] = R.Tl;
+        if (lane == 0) { st[32] = R.ordsum; st[33] = R.prev; }
+      }
+      if (lane == 0) { co_val[w] = R.value; co_conv[w] = R.done ? 1 : 0; }
+    }
+  }
+  __syncthreads();
+  if (have && lane == 0) {
+    out[il] = co_val[wave];
+    if (hand_over && !co_conv[wave]) {
+      // (a multipole that never entered the cooperative walk -- split <= kCell4Level -- hands
+      //  on the rows its wavefront left)
+      if (split <= top) {
+        double* st = state + (size_t)il * kRombergDump;
+        for (int q = 0; q < kRombergDump; ++q) st[q] = co_dump[wave][q];
+      }
+      deep[2 + atomicAdd(&deep[0], 1)] = il;
+    }
+  }
+}
+
 // One node by the general route (inlined: a call would put a stack -- scratch memory -- behind
 // every launch of the kernel, used or not).
 template <bool HF, bool BAO>
