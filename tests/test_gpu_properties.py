@@ -784,6 +784,36 @@ def test_launch_shapes_by_batch_size_agree():
     assert numpy.max(numpy.abs(p_mid / p_big[:8] - 1)) < 1e-12
 
 
+def test_batch_shapes_with_other_point_counts():
+    """The four-knots-to-a-block kernel with its cooperative tail and the permuted dispatch order
+    of the nu table, at point counts other than 50 (30 knots: the last block of an epoch holds
+    fewer than four; 40 masses): a 16-epoch batch against its epochs one by one, which take the
+    block-per-knot / four-wavefronts-per-integral shapes."""
+    from chomp_amd import defaults, grid
+    saved = copy.deepcopy(defaults.default_precision)
+    try:
+        defaults.default_precision.update(dict(halo_npoints=30, mass_npoints=40))
+        k = numpy.logspace(-2.5, 1.5, 29)
+        z = numpy.linspace(0.0, 1.4, 16)
+        big = grid.HaloGrid(z)
+        p_big = big.power("power_mm", k)
+        assert not big.status().any()
+        for i in (0, 7, 15):
+            one = grid.HaloGrid(z[i:i + 1])
+            p_one = one.power("power_mm", k)[0]
+            assert numpy.array_equal(one.ctx.table("ln_mass", 0), big.ctx.table("ln_mass", i))
+            for name in ("nu", "h_m", "pp_mm"):
+                a, b = one.ctx.table(name, 0), big.ctx.table(name, i)
+                assert a.shape == b.shape and numpy.max(numpy.abs(a - b)) <= 1e-12 * numpy.max(numpy.abs(b)), (i, name)
+            la = one.ctx.table("levels", 0).reshape(5, -1)[:2]
+            lb = big.ctx.table("levels", i).reshape(5, -1)[:2]
+            assert numpy.array_equal(la, lb), i
+            assert numpy.max(numpy.abs(p_one / p_big[i] - 1)) < 1e-12, i
+    finally:
+        defaults.default_precision.clear()
+        defaults.default_precision.update(saved)
+
+
 def test_many_cosmologies_in_one_batch_equal_single_epochs():
     """A design or MCMC batch is throughput-, not latency-bound, and takes other launch shapes:
     from 16 distinct cosmologies on the cosmology-only tables are built four nodes per thread
