@@ -146,7 +146,9 @@ CHOMP_HD void sici_sc(double x, double s, double c, const SiCiTab& T, double* si
     const double t = 16.0 * u - (double)(2 * j + 1);
     const double F = cheb_eval<CHOMP_FG_NCOEF>(T.f[j], t);
     const double G = cheb_eval<CHOMP_FG_NCOEF>(T.g[j], t);
-    const double f = F / x, g = G / (x * x);
+    // (x f(x) = F, x^2 g(x) = G; with 1 / x = u / 4 at hand the two further divisions -- ten
+    //  instructions each in fp64 -- are multiplications)
+    const double f = F * (0.25 * u), g = G * ((0.0625 * u) * u);
     *si = kHalfPi - f * c - g * s;
     *ci = f * s - g * c;
   }
@@ -172,7 +174,9 @@ CHOMP_HD void sici_sc_ln(double x, double ln_x, double s, double c, const SiCiTa
     const double t = 16.0 * u - (double)(2 * j + 1);
     const double F = cheb_eval<CHOMP_FG_NCOEF>(T.f[j], t);
     const double G = cheb_eval<CHOMP_FG_NCOEF>(T.g[j], t);
-    const double f = F / x, g = G / (x * x);
+    // (x f(x) = F, x^2 g(x) = G; with 1 / x = u / 4 at hand the two further divisions -- ten
+    //  instructions each in fp64 -- are multiplications)
+    const double f = F * (0.25 * u), g = G * ((0.0625 * u) * u);
     *si = kHalfPi - f * c - g * s;
     *ci = f * s - g * c;
   }
