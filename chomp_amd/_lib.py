@@ -186,6 +186,15 @@ def source_hash():
     return h.hexdigest()
 
 
+def built_hash():
+    """The source hash the shipped library was built from (None if not recorded)."""
+    try:
+        with open(HASH_PATH) as f:
+            return f.read().strip() or None
+    except OSError:
+        return None
+
+
 def build(force=False, verbose=False, extra_flags=(), out=None):
     """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a
     GPU).  Rebuilds when the sources differ from the ones the .so was built from (their
@@ -260,8 +269,9 @@ def lib():
     with _lock:
         if _lib is not None:
             return _lib
-        # build() is a no-op when the library is newer than every source; a box without
-        # hipcc (or a read-only tree) keeps the prebuilt library it was shipped
+        # build() is a no-op when the library was built from exactly these sources (content
+        # hash beside it).  A library that was built from OTHER sources is never loaded
+        # silently: a test run would certify a binary that is not the tree.
         try:
             build()
         except Exception as exc:   # noqa: BLE001
@@ -270,9 +280,15 @@ def lib():
                     "chomp_amd: libchomp_mi355x.so is missing and could not be "
                     "built with hipcc (%s). This package has no CPU fallback."
                     % exc) from exc
+            have = built_hash()
+            msg = ("chomp_amd: libchomp_mi355x.so was built from other sources (library %s, "
+                   "tree %s) and the rebuild failed (%s)"
+                   % (have or "unknown", source_hash(), exc))
+            if os.environ.get("CHOMP_ALLOW_STALE_LIB") != "1":
+                raise ImportError(msg + "; set CHOMP_ALLOW_STALE_LIB=1 to load it all the "
+                                  "same (a box without hipcc)") from exc
             import warnings
-            warnings.warn("chomp_amd: sources are newer than libchomp_mi355x.so and the "
-                          "rebuild failed (%s); using the existing library" % exc)
+            warnings.warn(msg + "; CHOMP_ALLOW_STALE_LIB=1: using the existing library")
         _preload_hip_runtime()
         L = ctypes.CDLL(LIB_PATH)
         for name in EXPORTS:

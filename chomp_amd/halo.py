@@ -124,7 +124,6 @@ class Halo(object):
         msig = (tuple(sorted(self.mass.halo_dict.items())), self.mass._kind)
         new_mass = msig != self._mass_sig
         if new_mass:
-            self._mass_sig = msig
             self._nbar_valid = False
         build = 0
         for flag, bit in _FLAG_BITS:
@@ -134,7 +133,12 @@ class Halo(object):
             self._resolve_status(stacklevel=6)     # (the next set-up clears the device's words)
             tables = build | (_lib.T_EXCLUSION if self._exclusion else 0)
             if new_mass:       # mass function and halo model in one call: one launch fewer
+                # the signature is recorded only once the set-up has returned: after a raise
+                # (a status warning turned error above, a HIP / scope error in the set-up)
+                # the retry must run the mass function again, not halo_setup on old nu tables
+                self._mass_sig = None
                 self._stage_k(ctx, tables)
+                self._mass_sig = msig
             else:
                 ctx.halo_setup(self._profile(), self.local_hod, tables)
             for flag, bit in _FLAG_BITS:

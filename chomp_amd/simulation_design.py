@@ -160,11 +160,11 @@ class SimulationDesign(object):
                                            name="status", dtype="int64")
         for label, w in self.design_status.items():
             if w:
-                kind = (_lib.ChompParityWarning
-                        if w & (_lib.ST_SATURATED | _lib.ST_MASS_SEARCH_EXHAUSTED)
-                        else _lib.ChompAccuracyWarning)
+                category = (_lib.ChompParityWarning
+                            if w & (_lib.ST_SATURATED | _lib.ST_MASS_SEARCH_EXHAUSTED)
+                            else _lib.ChompAccuracyWarning)
                 warnings.warn("design point %s: %s" % (label, "; ".join(_lib.describe_status(w))),
-                              kind, stacklevel=3)
+                              category, stacklevel=3)
         return pandas.DataFrame(numpy.asarray(out).T, columns=self.points.index)
 
     def run_design(self, batched=None, with_status=False):
@@ -173,9 +173,9 @@ class SimulationDesign(object):
         one-launch path when the object / method allow it.
 
         The batched path keeps the status word of every design point (chomp_get_status bits) in
-        `self.design_status` and raises them as warnings naming the point; with_status=True
-        also appends them to the returned frame as a last row labelled 'status' (the frame the
-        reference returns has no such row, so this is opt-in)."""
+        `self.design_status` (an int64 Series indexed like the design points) and raises them as
+        warnings naming the point; with_status=True returns the pair (frame, design_status) --
+        the words are never mixed into the float frame, whose rows stay the method's output."""
         if not self._initialized_design:
             self._init_design_points()
         if batched is None:
@@ -186,9 +186,8 @@ class SimulationDesign(object):
         else:
             self.design_values = self.points.transpose().apply(self._run_des_point)
         self.values_frame = self.design_values
-        if with_status and self.design_status is not None:
-            return pandas.concat([self.design_values,
-                                  self.design_status.to_frame().transpose()])
+        if with_status:
+            return self.design_values, self.design_status
         return self.design_values
 
     def set_cosmology(self, cosmo_dict=None, values=None):

@@ -143,3 +143,71 @@ def test_covariance_host_logic():
     assert abs(p / o.covariance_P(center[1], delta[1], cv.area, 2e6, 3e6, 0.3) - 1) < 1e-14
     with pytest.raises(_lib.ChompScopeError):
         cv.covariance_NG(0.01, 0.01)
+
+
+def test_halo_sync_retries_the_mass_function_after_a_failed_setup():
+    """A set-up that raises (HIP error, scope error, a status warning turned error) must
+    not leave the Halo believing its mass function is on the device: the retry runs
+    stage_k (mass function + halo model) again, never halo_setup on the old nu tables."""
+    from chomp_amd import halo, _lib
+
+    class _Ctx(object):
+        def __init__(self):
+            self.calls = []
+            self.fail = 1
+
+        def epochs_set(self, *a):
+            self.calls.append("epochs_set")
+
+        def stage_k(self, *a):
+            self.calls.append("stage_k")
+            if self.fail:
+                self.fail -= 1
+                raise _lib.ChompError("injected")
+
+        def halo_setup(self, *a):
+            self.calls.append("halo_setup")
+
+        def status_post(self):
+            self.calls.append("status_post")
+
+        def warn_status(self, *a, **k):
+            return [0]
+
+    h = halo.Halo(0.0)
+    h._ctx = ctx = _Ctx()
+    with pytest.raises(_lib.ChompError):
+        h._sync(_lib.FAM_MM)
+    assert h._mass_sig is None and not h._nbar_valid and not h._initialized_h_m
+    h._sync(_lib.FAM_MM)
+    assert ctx.calls == ["epochs_set", "stage_k", "stage_k", "status_post"]
+    assert h._initialized_h_m and h._initialized_pp_mm and h._nbar_valid
+    h._sync(_lib.FAM_MM)                     # up to date: nothing more
+    assert len(ctx.calls) == 4
+    from chomp_amd import defaults
+    h.set_hod(dict(defaults.default_hod_dict))   # HOD only: halo model alone
+    h._sync(_lib.FAM_GM)
+    assert ctx.calls[4:] == ["halo_setup", "status_post"]
+
+
+def test_loader_refuses_a_library_built_from_other_sources(monkeypatch, tmp_path):
+    """chomp_amd/_lib.py: a hash mismatch whose rebuild fails is an error, not a warning
+    (a test run must never certify a binary that is not the tree); CHOMP_ALLOW_STALE_LIB=1
+    is the explicit opt-in of a box without hipcc."""
+    import warnings
+    from chomp_amd import _lib
+    if not __import__("os").path.exists(_lib.LIB_PATH):
+        pytest.skip("no built library in the tree")
+    monkeypatch.setattr(_lib, "_lib", None)
+
+    def _no_hipcc(*a, **k):
+        raise OSError("hipcc: not found (injected)")
+    monkeypatch.setattr(_lib, "build", _no_hipcc)
+    monkeypatch.delenv("CHOMP_ALLOW_STALE_LIB", raising=False)
+    with pytest.raises(ImportError, match="built from other sources"):
+        _lib.lib()
+    monkeypatch.setenv("CHOMP_ALLOW_STALE_LIB", "1")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        L = _lib.lib()
+    assert hasattr(L, "chomp_power") and any("CHOMP_ALLOW_STALE_LIB" in str(x.message) for x in w)

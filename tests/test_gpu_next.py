@@ -190,7 +190,7 @@ def test_simulation_design_reports_status_of_its_points():
     through Halo._sync: a design point whose mass-limit search saturates (the reference's own
     answer is decided by rounding noise there; P(k) may differ by percents) raises a
     ChompParityWarning naming the point, its word is kept in design_status, and with_status=True
-    appends the words to the frame."""
+    hands the words back beside the frame (an int64 Series, never a row of the float frame)."""
     import warnings
     from chomp_amd import halo, simulation_design as sd, _lib
     numpy.random.seed(5)
@@ -208,13 +208,13 @@ def test_simulation_design_reports_status_of_its_points():
     des.points.loc[1, ["omega_m0", "omega_b0", "h", "sigma_8", "n_scalar"]] = [
         0.30, 0.045, 0.7, 0.85, 0.96]
     with pytest.warns(_lib.ChompParityWarning, match="design point 3: .*saturated"):
-        frame = des.run_design(with_status=True)
-    assert des._batched() and frame.shape == (17, 5)
-    assert list(frame.index)[-1] == "status"
+        frame, words = des.run_design(with_status=True)
+    assert des._batched() and frame.shape == (16, 5)    # the reference's frame and nothing else
+    assert frame.values.dtype == numpy.float64 and words.dtype == numpy.int64
     st = des.design_status
+    assert words is st and list(st.index) == list(des.points.index)
     assert int(st[3]) & _lib.ST_MASS_MIN_SATURATED and int(st[1]) == 0
-    assert numpy.array_equal(frame.loc["status"].values, st.values)
-    assert des.design_values.shape == (16, 5)           # the reference's frame, without the row
+    assert des.design_values is frame
     # the loop path says the same about the same point
     loop = sd.SimulationDesignFlatUniverse(halo.Halo(z), "power_mm", params, n_design=5,
                                            independent_var=k)
