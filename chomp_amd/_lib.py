@@ -115,7 +115,7 @@ ST_NONFINITE = 0x10000
 ST_SATURATED = ST_MASS_MIN_SATURATED | ST_MASS_MAX_SATURATED
 TUNE_E_STREAM_MIN, TUNE_E_ROWS, TUNE_DEEP_LITERAL, TUNE_ROCTX, TUNE_WTHETA_DIRECT = 0, 1, 2, 3, 4
 TUNE_CELL_ONE_KERNEL = 5
-TUNE_DEEP_TOL, TUNE_DEEP_MAX_BREAKS, TUNE_DEEP_MAX_FINE = 6, 7, 8
+TUNE_DEEP_TOL, TUNE_DEEP_MAX_BREAKS, TUNE_DEEP_MAX_FINE, TUNE_HOD_CAP = 6, 7, 8, 9
 
 
 class ChompAccuracyWarning(UserWarning):
@@ -708,10 +708,11 @@ class Context(object):
 
     def deep_stats(self):
         """(knots done by the fast deep-level sums, knots done by literal evaluation) so far."""
-        out = (ctypes.c_longlong * 6)()
+        out = (ctypes.c_longlong * 7)()
         self._check(self._L.chomp_get_deep_stats(self._h, out))
         self.deep_detail = {"too_many_breaks": int(out[2]), "too_many_fine": int(out[3]),
-                            "self_check": int(out[4]), "worst_estimate": out[5] * 1e-15}
+                            "self_check": int(out[4]), "worst_estimate": out[5] * 1e-15,
+                            "needs_node_evaluation": int(out[6])}
         return int(out[0]), int(out[1])
 
     def set_tuning(self, what, value):

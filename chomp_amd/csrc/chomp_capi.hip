@@ -103,7 +103,7 @@ struct chomp_ctx {
   unsigned* d_status = nullptr;    // per-epoch status word (chomp_get_status)
   double* d_endp = nullptr;        // integrand pairs of the knots at the upper end point
   int* d_npend = nullptr;          // per epoch: listed knots + 1 token (k_halo_knots_fast)
-  long long tune[CHOMP_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};   // chomp_set_tuning
+  long long tune[CHOMP_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};   // chomp_set_tuning
   bool have_epochs = false, have_mass = false, have_halo = false;
   unsigned fam_mask = 0;          // families (F_* bits) with valid splines
   std::vector<char> have_halofit;
@@ -131,8 +131,9 @@ struct chomp_ctx {
   double* d_wnodes = nullptr;      // w(theta): theta-independent integrand factor on the Romberg nodes
   double* d_cnodes = nullptr;      // C_l: chi-only factors on the Romberg nodes
   size_t cap_cnodes = 0;
-  double* d_kept = nullptr;        // integrand pairs the HOD knots evaluated (k_halo_knots -> _fast)
-  size_t cap_kept = 0;
+  double* d_samples = nullptr;     // coarse samples of the listed knots, a slot each (k_halo_knots_samples -> _fast)
+  double* d_psum = nullptr;        // ... and their per-level sums
+  size_t cap_samples = 0, cap_psum = 0;
   double* d_deepw = nullptr;       // k_halo_knots_fast: level weights (deep_weights_host)
   int* d_deepstat = nullptr;       // k_halo_knots_fast: knots done by the fast / literal path
   size_t cap_slow = 0, cap_winfo = 0, cap_ktab = 0, cap_wnodes = 0;
@@ -512,7 +513,7 @@ void chomp_ctx_destroy(chomp_ctx* ctx) {
                   ctx->d_cand, ctx->d_cosmo, ctx->d_z, ctx->d_epochs, ctx->d_search, ctx->d_probe, ctx->d_count, ctx->d_pending,
                   ctx->d_tab, ctx->d_mass_par, ctx->d_profile, ctx->d_hod, ctx->d_nodes, ctx->d_snodes, ctx->d_slot, ctx->d_first, ctx->d_status, ctx->d_endp, ctx->d_npend,
                   ctx->d_stage_in, ctx->d_stage_in2, ctx->d_stage_out, ctx->d_slow, ctx->d_wnodes, ctx->d_cnodes, ctx->d_deepw, ctx->d_deepstat,
-                  ctx->d_winfo, ctx->d_ktab, ctx->d_kept};
+                  ctx->d_winfo, ctx->d_ktab, ctx->d_samples, ctx->d_psum};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (void* p : ctx->graveyard) (void)hipFree(p);
@@ -619,6 +620,7 @@ int chomp_get_deep_stats(chomp_ctx* ctx, long long* out) {
   float worst;
   std::memcpy(&worst, &v[5], sizeof worst);
   out[5] = (long long)((double)worst * 1e15);      // largest self-check estimate, in 1e-15
+  out[6] = v[6];
   return CHOMP_OK;
 }
 
@@ -766,6 +768,7 @@ struct HaloPlan {
   int groups[3] = {-1, -1, -1};
   int ng = 0;
   int want_nbar = 1;
+  bool eval = false;     // some epoch's HOD has alpha != 1: the deep-level sums evaluate nodes
 };
 static int halo_prepare(chomp_ctx* ctx, const chomp_halo_par* profile, const chomp_hod_par* hod,
                         unsigned tables, HaloPlan* P) {
@@ -787,6 +790,7 @@ static int halo_prepare(chomp_ctx* ctx, const chomp_halo_par* profile, const cho
                                       h.sigma * erfinv_host(2.0 * ctx->cfg.halo_precision - 1.0));
     d.second_zero = std::pow(10.0, h.log_M_0);
     d.safe_norm = std::pow(10.0, h.log_M_min + 1.0 * h.sigma);
+    if (h.alpha != 1.0) P->eval = true;
   }
   int rcu = upload(ctx, ctx->d_profile, profile, n * sizeof(chomp_halo_par), ctx->sh_profile);
   if (rcu) return rcu;
@@ -853,40 +857,50 @@ static int launch_halo_knots(chomp_ctx* ctx, const HaloPlan& P) {
   const bool lone = !wide && (size_t)L.NK * n * ng > 4096;
   const unsigned kb = (wide || lone) ? (unsigned)L.NK : (unsigned)((L.NK + 3) / 4);
   const size_t shk = (size_t)(L.NM + 8 * (L.NM - 1) + kKnotScratch) * sizeof(double);
-  // The integrand pairs an HOD knot evaluates on its way through the node table are kept for
-  // k_halo_knots_fast (half its coarse samples): compact slots of the plan's HOD groups.
-  int ks[3] = {-1, -1, -1}, n_hod = 0;
-  for (int q = 0; q < P.ng && q < 3; ++q)
-    if (P.groups[q] > 0) ks[q] = n_hod++;
-  double* kept = nullptr;
-  if (n_hod > 0 && ctx->cfg.divmax > kNodeLevel) {
-    const int rck = ensure(ctx, &ctx->d_kept, &ctx->cap_kept,
-                           (size_t)n_hod * n * (size_t)L.NK * 2 * (size_t)kNodeBase);
+  // The knots of the HOD groups that do not converge within the node tables are listed; every
+  // listed knot gets a slot of the sample buffer (k_halo_knots_samples fills it, k_halo_knots_fast
+  // sums the knot's levels from it).  The buffer holds every knot that CAN be listed while that
+  // stays under the budget; beyond it the two kernels work the list off in rounds of `slots`.
+  const bool hod_groups = P.groups[0] > 0 || P.groups[1] > 0 || P.groups[2] > 0;
+  const bool deep_route = hod_groups && ctx->cfg.divmax > kNodeLevel;
+  size_t slots = 0;
+  int rounds = 1;
+  if (deep_route) {
+    const size_t worst = (size_t)ng * n * (size_t)L.NK;
+    const size_t budget = ((size_t)1 << 30) / ((size_t)kDeepSlot * sizeof(double));
+    slots = worst < budget ? worst : budget;
+    if ((worst + slots - 1) / slots > (size_t)kPendingRounds)
+      slots = (worst + kPendingRounds - 1) / kPendingRounds;
+    rounds = (int)((worst + slots - 1) / slots);
+    int rck = ensure(ctx, &ctx->d_samples, &ctx->cap_samples, slots * (size_t)kDeepSlot);
     if (rck) return rck;
-    kept = ctx->d_kept;
+    rck = ensure(ctx, &ctx->d_psum, &ctx->cap_psum, slots * (size_t)(8 * kDeepPsum));
+    if (rck) return rck;
   }
+  int hod_cap = ctx->tune[CHOMP_TUNE_HOD_CAP] >= 0 ? (int)ctx->tune[CHOMP_TUNE_HOD_CAP] : kHodCapLevel;
+  if (hod_cap < 6) hod_cap = 6;
 #define CHOMP_KNOTS(KNW)                                                                          \
   hipLaunchKernelGGL((k_halo_knots<KNW>), dim3((unsigned)n, kb + (P.want_nbar ? 1u : 0u), (unsigned)ng), \
                      dim3(KNW == 0 ? 64 : 256), shk, ctx->stream, ctx->cfg, L, ctx->d_epochs, ctx->d_tab,        \
                      ctx->d_profile, ctx->d_hod, ctx->d_sici, ctx->d_nodes, ctx->d_endp,          \
                      P.groups[0], P.groups[1], P.groups[2], P.kmask, P.want_nbar, ctx->d_pending, \
-                     ctx->d_npend, ctx->d_status, kept, ks[0], ks[1], ks[2])
+                     ctx->d_npend, ctx->d_status, hod_cap)
   if (wide) CHOMP_KNOTS(4); else if (lone) CHOMP_KNOTS(0); else CHOMP_KNOTS(1);
 #undef CHOMP_KNOTS
   // blocks 0..n-1 take the epochs' tokens; with integrands that can run beyond the node
   // tables (the HOD ones) enough further blocks to fill the chip draw from the list
   unsigned gd = (unsigned)n;
-  const bool hod_groups = P.groups[0] > 0 || P.groups[1] > 0 || P.groups[2] > 0;
-  if (hod_groups && ctx->cfg.divmax > kNodeLevel) {
+  if (deep_route) {
     // (as many blocks as are resident at once -- two of 256 threads or one of 512 per CU, 256
     //  CUs: a block loops over the list until it is empty, and one that starts after that only
     //  stages its tables to find nothing left)
+    // (three of 256 threads -- the lean instance: 164 registers, 51 KB of LDS -- or one of 512)
     unsigned want = (unsigned)(L.NK * n * ng);
-    const unsigned resident = (size_t)L.NK * n * ng <= 768 ? 256u : 512u;
+    const unsigned resident = (size_t)L.NK * n * ng <= 768 ? 256u : (P.eval ? 512u : 768u);
     if (want > resident) want = resident;
     if (want > gd) gd = want;
   }
-  size_t shf = deep_fast_lds<kDeepCoarse>(L.NM);
+  size_t shf = deep_fast_lds<kDeepCoarse>(L.NM, ctx->cfg.divmax);
   if (shf < (size_t)finalize_lds_doubles(L.NK) * sizeof(double))
     shf = (size_t)finalize_lds_doubles(L.NK) * sizeof(double);
   // chomp_set_tuning: the checker (every listed knot by literal evaluation) and the two
@@ -900,12 +914,17 @@ static int launch_halo_knots(chomp_ctx* ctx, const HaloPlan& P) {
   int max_fine = ctx->tune[CHOMP_TUNE_DEEP_MAX_FINE] >= 0 ? (int)ctx->tune[CHOMP_TUNE_DEEP_MAX_FINE]
                                                           : kDeepMaxFine;
   if (max_fine > kDeepMaxFine) max_fine = kDeepMaxFine;
-#define CHOMP_KNOTS_FAST(NT, SELF)                                                               \
-  hipLaunchKernelGGL((k_halo_knots_fast<kDeepCoarse, NT, SELF>), dim3(gd), dim3(NT), shf, ctx->stream, \
+#define CHOMP_KNOTS_FAST(NT, SELF, EVAL, GRID, ROUND, LO, HI, FROM)                                         \
+  hipLaunchKernelGGL((k_halo_knots_fast<kDeepCoarse, NT, SELF, EVAL>), dim3(GRID), dim3(NT), shf, ctx->stream, \
                      ctx->cfg, L, ctx->d_epochs, ctx->d_tab, ctx->d_sici, P.groups[0], P.groups[1], \
                      P.groups[2], P.kmask, (int)n, ctx->d_pending, ctx->d_npend, ctx->d_epochs,     \
                      P.fam, ctx->d_status, ctx->d_deepw, all_literal, deep_tol, max_rough, max_fine, \
-                     ctx->d_deepstat, ctx->d_nodes, kept, ks[0], ks[1], ks[2])
+                     ctx->d_deepstat, ctx->d_samples, ctx->d_psum, parts, ROUND, LO, HI, FROM)
+#define CHOMP_KNOTS_SAMPLES(GRID, LO, HI)                                                        \
+  hipLaunchKernelGGL((k_halo_knots_samples<kDeepCoarse>), dim3(GRID), dim3(256), 0, ctx->stream,   \
+                     ctx->cfg, L, ctx->d_sici, P.groups[0], P.groups[1], P.groups[2], P.kmask,      \
+                     (int)n, ctx->d_pending, ctx->d_nodes, ctx->d_endp, ctx->d_samples, ctx->d_psum, \
+                     parts, LO, HI)
 #define CHOMP_KNOTS_LITERAL(NT, GRID)                                                            \
   hipLaunchKernelGGL((k_halo_knots_literal<NT>), dim3(GRID), dim3(NT), shl, ctx->stream, ctx->cfg,  \
                      L, ctx->d_epochs, ctx->d_tab, ctx->d_profile, ctx->d_hod, ctx->d_sici,         \
@@ -913,35 +932,63 @@ static int launch_halo_knots(chomp_ctx* ctx, const HaloPlan& P) {
                      ctx->d_npend, ctx->d_epochs, P.fam, ctx->d_status, ctx->d_deepstat)
   if (shf > 64 * 1024) {            // (more than 64 KiB of dynamic LDS: opt in, once per context)
     if (!ctx->lds_knots_set) {       // (per context: the attribute belongs to the current device)
-      HIPCHK(hipFuncSetAttribute(
-          reinterpret_cast<const void*>(&k_halo_knots_fast<kDeepCoarse, kDeepThreadsFew, false>),
-          hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-      HIPCHK(hipFuncSetAttribute(
-          reinterpret_cast<const void*>(&k_halo_knots_fast<kDeepCoarse, kDeepThreads, false>),
-          hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-      HIPCHK(hipFuncSetAttribute(
-          reinterpret_cast<const void*>(&k_halo_knots_fast<kDeepCoarse, kDeepThreadsFew, true>),
-          hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-      HIPCHK(hipFuncSetAttribute(
-          reinterpret_cast<const void*>(&k_halo_knots_fast<kDeepCoarse, kDeepThreads, true>),
-          hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+#define CHOMP_LDS_OPT_IN(NT, SELF, EVAL)                                                   \
+      HIPCHK(hipFuncSetAttribute(                                                          \
+          reinterpret_cast<const void*>(&k_halo_knots_fast<kDeepCoarse, NT, SELF, EVAL>), \
+          hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024))
+      CHOMP_LDS_OPT_IN(kDeepThreadsFew, false, false);
+      CHOMP_LDS_OPT_IN(kDeepThreads, false, false);
+      CHOMP_LDS_OPT_IN(kDeepThreadsFew, false, true);
+      CHOMP_LDS_OPT_IN(kDeepThreads, false, true);
+      CHOMP_LDS_OPT_IN(kDeepThreadsFew, true, true);
+      CHOMP_LDS_OPT_IN(kDeepThreads, true, true);
+#undef CHOMP_LDS_OPT_IN
       ctx->lds_knots_set = true;
     }
   }
   const bool few = (size_t)L.NK * n * ng <= 768;
+  // (the sampling launch: a listed knot's 2^11 + 1 samples in `parts` work items -- the fewer
+  //  knots there can be, the finer, so that a single epoch's handful still spreads over the chip)
+  const int parts = few ? 8 : ((size_t)L.NK * n * ng <= 8192 ? 4 : 2);
   if (!hod_groups) {                // (group 0 alone: listed knots are done in the same launch)
-    if (few) CHOMP_KNOTS_FAST(kDeepThreadsFew, true); else CHOMP_KNOTS_FAST(kDeepThreads, true);
+    if (few) CHOMP_KNOTS_FAST(kDeepThreadsFew, true, true, gd, 0, 0, 0x7fffffff, 0);
+    else CHOMP_KNOTS_FAST(kDeepThreads, true, true, gd, 0, 0, 0x7fffffff, 0);
+  } else if (!deep_route) {         // (divmax within the node tables: nothing is ever listed)
+    if (few) CHOMP_KNOTS_FAST(kDeepThreadsFew, false, false, gd, 0, 0, 0, 0);
+    else CHOMP_KNOTS_FAST(kDeepThreads, false, false, gd, 0, 0, 0, 0);
   } else {
-    if (few) CHOMP_KNOTS_FAST(kDeepThreadsFew, false); else CHOMP_KNOTS_FAST(kDeepThreads, false);
+    for (int r = 0; r < rounds; ++r) {
+      const int lo = (int)((size_t)r * slots), hi = (int)((size_t)(r + 1) * slots);
+      size_t gs = slots * (size_t)parts;
+      if (gs > 1536) gs = 1536;
+      CHOMP_KNOTS_SAMPLES((unsigned)gs, lo, hi);
+      const unsigned g = r == 0 ? gd : (gd < 512u ? gd : 512u);
+      if (P.eval) {
+        if (few) CHOMP_KNOTS_FAST(kDeepThreadsFew, false, true, g, r, lo, hi, 0);
+        else CHOMP_KNOTS_FAST(kDeepThreads, false, true, g, r, lo, hi, 0);
+      } else {
+        // (the lean instance, and behind it the evaluating one for the knots it hands on)
+        const unsigned ge = g < 256u ? g : 256u;
+        if (few) {
+          CHOMP_KNOTS_FAST(kDeepThreadsFew, false, false, g, r, lo, hi, 0);
+          CHOMP_KNOTS_FAST(kDeepThreadsFew, false, true, ge, r, lo, hi, 1);
+        } else {
+          // (the handed-on knots are few and long -- node-by-node intervals: 512 threads each)
+          CHOMP_KNOTS_FAST(kDeepThreads, false, false, g, r, lo, hi, 0);
+          CHOMP_KNOTS_FAST(kDeepThreadsFew, false, true, ge, r, lo, hi, 1);
+        }
+      }
+    }
   }
   // knots can only be handed on when some HOD Romberg may run beyond the node tables
-  if (hod_groups && ctx->cfg.divmax > kNodeLevel) {
+  if (deep_route) {
     const size_t shl = deep_literal_lds(L.NM, L.NK);
     // (an empty list is the rule: few blocks, each returns after one read)
     const unsigned gl = all_literal ? gd : (gd < 256u ? gd : 256u);
     if (few) CHOMP_KNOTS_LITERAL(kDeepThreadsFew, gl); else CHOMP_KNOTS_LITERAL(kDeepThreads, gl);
   }
 #undef CHOMP_KNOTS_FAST
+#undef CHOMP_KNOTS_SAMPLES
 #undef CHOMP_KNOTS_LITERAL
   HIPCHK(hipGetLastError());
   ctx->have_halo = true;

@@ -12,6 +12,8 @@
 //                   splines over ln k (halo.py:916-918, 959-961, 983-986, 1026-1029, 1072-1075)
 #pragma once
 
+#include <type_traits>
+
 #include "chomp_mass_kernels.h"
 
 namespace chomp {
@@ -29,13 +31,27 @@ constexpr double kPendingLevel = -1.0;   // levels-table marker: needs the deep 
 //       Romberg runs deepest, at the front, so that a launch ends with short knots)
 //                                                                      (k_halo_knots_fast)
 //   [4] items handed on to the literal evaluation, [5] next of those (k_halo_knots_literal)
-//   [kPendingHead ...] the items; the second list follows at pending_literal_base().
-constexpr int kPendingHead = 8;
+//   [kPendingDraw + r] next item of round r of k_halo_knots_fast (a round works off as many
+//       listed knots as the sample buffer has slots; one round unless the batch is huge)
+//   [kPendingEvCount + r], [kPendingEvDraw + r] knots of round r that the lean instance of
+//       k_halo_knots_fast handed to the one that can evaluate the integrand (see EVAL there):
+//       how many, and the next to hand out
+//   [kPendingHead ...] the items; the second list follows at pending_literal_base(), the list
+//       positions of the knots handed to the evaluating instance at pending_eval_base() (a
+//       round's at the round's first slot: it cannot hand on more knots than it has slots).
+constexpr int kPendingDraw = 8;
+constexpr int kPendingRounds = 32;
+constexpr int kPendingEvCount = kPendingDraw + kPendingRounds;
+constexpr int kPendingEvDraw = kPendingEvCount + kPendingRounds;
+constexpr int kPendingHead = kPendingEvDraw + kPendingRounds;
 __host__ __device__ inline size_t pending_literal_base(size_t n_epoch, int NK) {
   return (size_t)kPendingHead + 3 * n_epoch * (size_t)NK;
 }
-__host__ __device__ inline size_t pending_ints(size_t n_epoch, int NK) {
+__host__ __device__ inline size_t pending_eval_base(size_t n_epoch, int NK) {
   return (size_t)kPendingHead + 2 * 3 * n_epoch * (size_t)NK;
+}
+__host__ __device__ inline size_t pending_ints(size_t n_epoch, int NK) {
+  return (size_t)kPendingHead + 3 * 3 * n_epoch * (size_t)NK;
 }
 constexpr unsigned kMaskExclusion = 1u << 8;   // bit of the kernels' family mask: HaloExclusion
 constexpr unsigned kMaskDeepNodes = 1u << 9;   // ... the node tables hold level kNodeTabLevel too
@@ -355,7 +371,10 @@ __device__ __forceinline__ void halo_epoch_begin(Epoch& E, const chomp_halo_par&
   *npend_e = 1;
   // the work list of the knots: emptied once per set-up, before any knot is integrated
   // (every block of the previous set-up's k_halo_knots_fast has finished by now)
-  if (first_epoch) { pending[0] = 0; pending[1] = 0; pending[2] = 0; pending[4] = 0; pending[5] = 0; }
+  if (first_epoch) {
+    pending[0] = 0; pending[1] = 0; pending[2] = 0; pending[4] = 0; pending[5] = 0;
+    for (int r = 0; r < 3 * kPendingRounds; ++r) pending[kPendingDraw + r] = 0;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -480,21 +499,13 @@ struct NodeIntegrand {
   const double* node;     // this (epoch, group)'s table
   double ln_k;
   bool exclusion;         // HaloExclusion (halo.py:1208-1233): window on the 2-halo term
-  // (HOD groups) where the pair of every node this knot evaluates is kept, [node_index] x 2: a
-  // knot that has to be listed has evaluated half of k_halo_knots_fast's coarse samples by then
-  double* keep;
   __device__ __forceinline__ void operator()(double, double (&out)[2], int lev, long j) const {
     const int idx = node_index(lev, j);
     const double* n = node + idx;
     node_pair(*sici, ln_k, exclusion, n[0], n[kNodeCount], n[2 * kNodeCount], n[3 * kNodeCount],
               n[4 * kNodeCount], n[5 * kNodeCount], n[6 * kNodeCount], out);
-    if (keep) reinterpret_cast<double2*>(keep)[idx] = make_double2(out[0], out[1]);
   }
 };
-// The kept pairs of knot ik of epoch e in the compact slot sc of an HOD group (see NodeIntegrand).
-__host__ __device__ inline size_t kept_offset(int sc, int n_epoch, int e, int NK, int ik) {
-  return (((size_t)sc * n_epoch + e) * NK + ik) * 2 * (size_t)kNodeBase;
-}
 
 __device__ __forceinline__ int group_fa(int group) { return group == 0 ? F_HM : F_HG; }
 __device__ __forceinline__ int group_fb(int group) {
@@ -534,7 +545,7 @@ __global__ __launch_bounds__(KNW == 0 ? 64 : 256, KNW == 1 ? 3 : 1) void k_halo_
     const SiCiTab* __restrict__ sici_g, const double* __restrict__ nodes,
     const double* __restrict__ endp, int g0, int g1, int g2, unsigned mask, int want_nbar,
     int* __restrict__ pending, int* __restrict__ npend, unsigned* __restrict__ status,
-    double* __restrict__ kept, int s0, int s1, int s2) {
+    int hod_cap) {
   extern __shared__ __align__(16) double sm[];
   __shared__ SiCiTab S;
   __shared__ Epoch E;              // (the n_bar block only)
@@ -577,12 +588,15 @@ __global__ __launch_bounds__(KNW == 0 ? 64 : 256, KNW == 1 ? 3 : 1) void k_halo_
   double* t = tab + (size_t)e * L.stride;
   const double ln_k0 = log(cfg.k_min), ln_k1 = log(cfg.k_max);
   const double ln_k = linspace_at(ln_k0, ln_k1, NK, have ? ik : 0);          // halo.py:52-54
-  const int sc = bz == 0 ? s0 : (bz == 1 ? s1 : s2);
-  const bool keeps = kept != nullptr && sc >= 0;
   const bool exclusion = (mask & kMaskExclusion) != 0;
-  NodeIntegrand f{&S, node, ln_k, exclusion,
-                  keeps ? kept + kept_offset(sc, n_epoch, e, NK, have ? ik : 0) : nullptr};
-  const int dmax = cfg.divmax < kNodeLevel ? cfg.divmax : kNodeLevel;
+  NodeIntegrand f{&S, node, ln_k, exclusion};
+  // How deep a knot walks the node table here.  The HOD groups' knots that do not converge
+  // within the table are listed for k_halo_knots_fast, whose sampling launch evaluates every
+  // node of the table for them anyway: what such a knot sums here beyond level hod_cap is
+  // done twice (at the default HOD the pairs either stop at levels 8-9 or run to 11..20, so
+  // level 10 -- half the table's nodes, on one wavefront -- is evaluated for the listed only).
+  const int top = (group > 0 && (mask & kMaskDeepNodes) && hod_cap < kNodeLevel) ? hod_cap : kNodeLevel;
+  const int dmax = cfg.divmax < top ? cfg.divmax : top;
   RombergOut<2> r;
   if constexpr (kCoop) {
     // Four knots to a block, one per wavefront, up to level kCoopLevel (four fifths of the
@@ -616,8 +630,7 @@ __global__ __launch_bounds__(KNW == 0 ? 64 : 256, KNW == 1 ? 3 : 1) void k_halo_
     for (int w = 0; w < 4; ++w) {
       if (!co_need[w]) continue;                 // (block-uniform)
       const int ikw = bx + kb * w;
-      NodeIntegrand fw{&S, node, linspace_at(ln_k0, ln_k1, NK, ikw), exclusion,
-                       keeps ? kept + kept_offset(sc, n_epoch, e, NK, ikw) : nullptr};
+      NodeIntegrand fw{&S, node, linspace_at(ln_k0, ln_k1, NK, ikw), exclusion};
       RombergResume R[2];
       bool dn[2];
 #pragma unroll
@@ -682,7 +695,7 @@ __global__ __launch_bounds__(KNW == 0 ? 64 : 256, KNW == 1 ? 3 : 1) void k_halo_
   if ((KNW <= 1 ? (threadIdx.x & 63) : threadIdx.x) == 0) {
     double* lev = t + L.off_levels;
     const int fa = group_fa(group), fb_ = group_fb(group);
-    const bool more = cfg.divmax > kNodeLevel;
+    const bool more = cfg.divmax > top;
     if (group != 2 && (mask & (1u << fa))) {
       t[L.off_knot[fa] + ik] = r.value[0];
       lev[fa * NK + ik] = (!r.converged[0] && more) ? kPendingLevel : (double)r.level[0];
@@ -809,6 +822,7 @@ constexpr int kDeepMaxRough = 8;                           // break-point interv
 constexpr int kDeepMaxFine = 64;                           // node-by-node intervals
 constexpr int kDeepKinkMargin = 16;                        // extra ones above M_0 (see kernel)
 constexpr double kDeepTol = 1e-9;
+constexpr int kHodCapLevel = 9;                             // see k_halo_knots (hod_cap)
 
 // W[L - LC - 1][o][m] = sum_(r < n) l_m(o + (r + 1/2) / n), n = 2^(L - 1 - LC), with l_m the
 // Lagrange basis polynomial on the stencil nodes 0..7.  Host, once per context.
@@ -887,28 +901,29 @@ __device__ __forceinline__ int halo_state_at(int group, const HaloCtx& c, double
   return st;
 }
 
-// The degree-7 Lagrange interpolant through f[0..7] (nodes 0..7) at t, for a pair of arrays.
-// t outside [0, 7] extrapolates: one-sided continuation of a smooth branch up to a break point.
-__device__ __forceinline__ void lagrange8_pair(double t, const double* f0, const double* f1,
-                                               double* o0, double* o1) {
-  double d[kDeepStencil], pre[kDeepStencil], suf[kDeepStencil];
-#pragma unroll
-  for (int j = 0; j < kDeepStencil; ++j) d[j] = t - (double)j;
-  pre[0] = 1.0;
-#pragma unroll
-  for (int m = 1; m < kDeepStencil; ++m) pre[m] = pre[m - 1] * d[m - 1];
+// The degree-7 Lagrange interpolant through samples s0 .. s0 + 7 (stencil nodes 0..7) at t, for
+// the pair of sample arrays (positions through POS: the arrays' storage order).  t outside
+// [0, 7] extrapolates: one-sided continuation of a smooth branch up to a break point.
+// l_m(t) = c_m prod_(j < m) (t - j) prod_(j > m) (t - j): the suffix products first, the prefix
+// product and the samples as the sum goes (8 doubles live, not 40).
+template <class POS>
+__device__ __forceinline__ void lagrange8_pair(double t, const double* F0, const double* F1,
+                                               int s0, POS pos, double* o0, double* o1) {
+  double suf[kDeepStencil];
   suf[kDeepStencil - 1] = 1.0;
 #pragma unroll
-  for (int m = kDeepStencil - 2; m >= 0; --m) suf[m] = suf[m + 1] * d[m + 1];
+  for (int m = kDeepStencil - 2; m >= 0; --m) suf[m] = suf[m + 1] * (t - (double)(m + 1));
   // 1 / prod_(j != m) (m - j) = (-1)^(7 - m) / (m! (7 - m)!)
   const double cm[kDeepStencil] = {-1.0 / 5040.0, 1.0 / 720.0, -1.0 / 240.0, 1.0 / 144.0,
                                    -1.0 / 144.0, 1.0 / 240.0, -1.0 / 720.0, 1.0 / 5040.0};
-  double a0 = 0.0, a1 = 0.0;
+  double a0 = 0.0, a1 = 0.0, pre = 1.0;
 #pragma unroll
   for (int m = 0; m < kDeepStencil; ++m) {
-    const double l = cm[m] * (pre[m] * suf[m]);
-    a0 = fma(l, f0[m], a0);
-    a1 = fma(l, f1[m], a1);
+    const double l = cm[m] * (pre * suf[m]);
+    const int at = pos(s0 + m);
+    a0 = fma(l, F0[at], a0);
+    a1 = fma(l, F1[at], a1);
+    pre *= t - (double)m;
   }
   *o0 = a0;
   *o1 = a1;
@@ -947,6 +962,28 @@ struct RombergRows2 {
     }
   }
   __device__ __forceinline__ bool all_done() const { return done[0] && done[1]; }
+  // The state out of the registers across a phase that needs them (the node-by-node loop of a
+  // deep round): every lane of every wavefront holds the same state but for Tl, which is
+  // distributed over the lanes -- wavefront 0 writes, and behind a barrier everyone reads back.
+  // (Tl only lives in lanes 0..31: rows <= kMaxDivmax < 32)
+  static constexpr int kPark = 2 * 32 + 8;
+  __device__ __forceinline__ void park(double* sh) const {
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x < 32) {
+      sh[lane] = Tl[0];
+      sh[32 + lane] = Tl[1];
+      if (lane == 0) {
+        sh[64] = ordsum[0]; sh[65] = ordsum[1]; sh[66] = prev[0]; sh[67] = prev[1];
+        sh[68] = value[0]; sh[69] = value[1]; sh[70] = n;
+      }
+    }
+  }
+  __device__ __forceinline__ void unpark(const double* sh) {
+    const int lane = threadIdx.x & 63;
+    Tl[0] = lane < 32 ? sh[lane] : 0.0; Tl[1] = lane < 32 ? sh[32 + lane] : 0.0;
+    ordsum[0] = sh[64]; ordsum[1] = sh[65]; prev[0] = sh[66]; prev[1] = sh[67];
+    value[0] = sh[68]; value[1] = sh[69]; n = sh[70];
+  }
   // level i with the sums of its new nodes
   __device__ __forceinline__ void advance(int i, double s0, double s1) {
     const int lane = threadIdx.x & 63;
@@ -1014,13 +1051,147 @@ __device__ __forceinline__ double deep_coarse_x(double a, double b, int q) {
   return (a + 0.5 * h) + h * (double)j;
 }
 
-// Dynamic LDS of k_halo_knots_fast (bytes).
+// ---------------------------------------------------------------------------
+// The coarse samples of the listed knots: one slot of the context's sample buffer per listed
+// knot (list position -> slot), filled by k_halo_knots_samples -- a launch of its own over ALL
+// listed knots, so that the 2^LC + 1 NFW transforms of a knot are chip time (a thread each)
+// and not 2 x 20 us on the critical path of the block that then sums the knot's levels.
+// Layout of a slot (doubles): F0[kDeepF], F1[kDeepF], the nodes' states as bytes [kDeepF].
+// A sample array holds the even-numbered samples first and the odd ones from kDeepOdd on
+// (deep_pos): every phase of k_halo_knots_fast then reads LDS at unit stride -- the self-check
+// predicts every odd sample from the even ones (stride-2 doubles: a two-way bank conflict by
+// construction in position order), and a level's new nodes are the odd samples of the level
+// below.  kDeepOdd = 16 mod 32: the two halves of a run of consecutive samples fall into
+// different banks.
+// ---------------------------------------------------------------------------
+constexpr int kDeepOdd = 1040;
+constexpr int kDeepF = kDeepOdd + (1 << (kDeepCoarse - 1));      // 2064
+constexpr int kDeepSlot = 4400;                                  // 2 x 2064 + 2064 / 8, padded
+constexpr int kDeepPsum = 16;                                    // per (slot, part): levels 11..4 x 2
+static_assert(2 * kDeepF + kDeepF / 8 <= kDeepSlot, "slot layout");
+__host__ __device__ inline int deep_pos(int q) { return (q & 1) ? kDeepOdd + (q >> 1) : (q >> 1); }
+// LDS doubles in front of a block's sample arrays (the epoch's splines, the reductions'
+// scratch), rounded to 16 bytes: the arrays are copied as double2
+__host__ __device__ inline int deep_f_off(int NM) { return (NM + 8 * (NM - 1) + kDeepScratch + 1) & ~1; }
+
+// grid: any (blocks stride over the work items), block 256.  Work item = (listed knot, part):
+// part p of `parts` (1, 2, 4, 8) is samples [p NC / parts, (p + 1) NC / parts) in POSITION
+// order, thread t on t, t + 256, ...: the reads of the (epoch, group) node table are gathers
+// (runs of 32, 16, 8 ... consecutive nodes of a level; the table is L2-resident, shared by the
+// group's knots), the writes of a slot are contiguous.  The upper end point comes from d_endp
+// (the node-table stage evaluated it for every knot).  A thread's samples all belong to one
+// Romberg level -- LC - ctz(t), t != 0 -- so the per-level sums scipy's rows need are taken
+// here, from the registers: psum[(slot * parts + part) * 16 + 2 (LC - level) + f], levels
+// LC .. LC - 7; thread 0's samples (multiples of 256: levels <= 3 and the end points) are read
+// from the slot by the consumer.
 template <int LC>
-inline size_t deep_fast_lds(int NM) {
+__global__ __launch_bounds__(256) void k_halo_knots_samples(
+    chomp_config cfg, TabLayout L, const SiCiTab* __restrict__ sici_g, int g0, int g1, int g2,
+    unsigned mask, int n_epoch, const int* __restrict__ pending, const double* __restrict__ nodes,
+    const double* __restrict__ endp, double* __restrict__ samples, double* __restrict__ psum,
+    int parts, int slot_lo, int slot_hi) {
   constexpr int NC = 1 << LC;
-  const size_t deep = (size_t)(NM + 8 * (NM - 1) + kDeepScratch + 2 * (NC + 1) +
-                               kDeepWLevels * kDeepWStride + (kMaxDivmax + 1) * 32) *
-                          sizeof(double) + (size_t)((NC + 1 + 15) & ~15);
+  __shared__ SiCiTab S;
+  __shared__ double xs[4][2][6];
+  __shared__ double single[3][2];
+  const int NK = L.NK, tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+  const int count_front = pending[0], count = count_front + pending[2];
+  const int hi = count < slot_hi ? count : slot_hi;
+  const int n_work = (hi - slot_lo) * parts;
+  if ((int)blockIdx.x >= n_work) return;
+  copy_doubles(reinterpret_cast<double*>(&S), reinterpret_cast<const double*>(sici_g),
+               (int)(sizeof(SiCiTab) / sizeof(double)));
+  __syncthreads();
+  const bool exclusion = (mask & kMaskExclusion) != 0;
+  const int span = NC / parts;
+  for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
+    const int li = slot_lo + w / parts, part = w % parts;
+    const int item = li < count_front
+                         ? pending[kPendingHead + li]
+                         : pending[kPendingHead + 3 * n_epoch * NK - 1 - (li - count_front)];
+    const int ik = item % NK, e = (item / NK) % n_epoch, zg = item / (NK * n_epoch);
+    const int group = zg == 0 ? g0 : (zg == 1 ? g1 : g2);
+    if (group < 0 || group > 2) continue;          // (never listed)
+    const double* nd = nodes + ((size_t)e * 3 + group) * kNodeStride;
+    const double ln_k = linspace_at(log(cfg.k_min), log(cfg.k_max), NK, ik);
+    double* slot = samples + (size_t)(li - slot_lo) * kDeepSlot;
+    unsigned char* code = reinterpret_cast<unsigned char*>(slot + 2 * kDeepF);
+    double a0 = 0.0, a1 = 0.0;
+    for (int q = part * span + tid; q < (part + 1) * span; q += 256) {
+      int idx = 0;
+      if (q != 0) {                                // position -> level-major
+        const int tz = __builtin_ctz((unsigned)q);
+        idx = 1 + (1 << (LC - tz - 1)) + (q >> (tz + 1));
+      }
+      const double state = nd[6 * kNodeCount + idx];
+      double o[2];
+      node_pair(S, ln_k, exclusion, nd[idx], nd[kNodeCount + idx], nd[2 * kNodeCount + idx],
+                nd[3 * kNodeCount + idx], nd[4 * kNodeCount + idx], nd[5 * kNodeCount + idx],
+                state, o);
+      const int at = deep_pos(q);
+      slot[at] = o[0];
+      slot[kDeepF + at] = o[1];
+      code[q] = (unsigned char)(int)state;
+      a0 += o[0];
+      a1 += o[1];
+    }
+    if (part == parts - 1 && tid == 255) {         // the upper end point (node 1 of the table)
+      const double* ep = endp + ((size_t)e * 3 + group) * 2 * NK + 2 * ik;
+      slot[deep_pos(NC)] = ep[0];
+      slot[kDeepF + deep_pos(NC)] = ep[1];
+      code[NC] = (unsigned char)(int)nd[6 * kNodeCount + 1];
+    }
+    // per-level sums: lanes of class c = ctz(lane) hold level LC - c (c = 0..5); inside a row
+    // of 16 lanes by DPP, the four rows through v_readlane
+    double r0[6], r1[6];
+    {
+      const double b0 = a0 + dpp_move<0x128>(a0), b1 = a1 + dpp_move<0x128>(a1);     // {i, i + 8}
+      const double c0 = b0 + dpp_move<0x124>(b0), c1 = b1 + dpp_move<0x124>(b1);     // = mod 4
+      const double d0 = c0 + dpp_move<0x4E>(c0), d1 = c1 + dpp_move<0x4E>(c1);       // = mod 2
+      r0[0] = (readlane_d(d0, 1) + readlane_d(d0, 17)) + (readlane_d(d0, 33) + readlane_d(d0, 49));
+      r1[0] = (readlane_d(d1, 1) + readlane_d(d1, 17)) + (readlane_d(d1, 33) + readlane_d(d1, 49));
+      r0[1] = (readlane_d(c0, 2) + readlane_d(c0, 18)) + (readlane_d(c0, 34) + readlane_d(c0, 50));
+      r1[1] = (readlane_d(c1, 2) + readlane_d(c1, 18)) + (readlane_d(c1, 34) + readlane_d(c1, 50));
+      r0[2] = (readlane_d(b0, 4) + readlane_d(b0, 20)) + (readlane_d(b0, 36) + readlane_d(b0, 52));
+      r1[2] = (readlane_d(b1, 4) + readlane_d(b1, 20)) + (readlane_d(b1, 36) + readlane_d(b1, 52));
+      r0[3] = (readlane_d(a0, 8) + readlane_d(a0, 24)) + (readlane_d(a0, 40) + readlane_d(a0, 56));
+      r1[3] = (readlane_d(a1, 8) + readlane_d(a1, 24)) + (readlane_d(a1, 40) + readlane_d(a1, 56));
+      r0[4] = readlane_d(a0, 16) + readlane_d(a0, 48);
+      r1[4] = readlane_d(a1, 16) + readlane_d(a1, 48);
+      r0[5] = readlane_d(a0, 32);
+      r1[5] = readlane_d(a1, 32);
+    }
+    __syncthreads();                               // (xs, single: the previous item's were read)
+    if (ln == 0) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) { xs[wv][0][c] = r0[c]; xs[wv][1][c] = r1[c]; }
+      // threads 64, 192: level LC - 6; thread 128: level LC - 7 (thread 0: see above)
+      if (wv > 0) { single[wv - 1][0] = a0; single[wv - 1][1] = a1; }
+    }
+    __syncthreads();
+    if (tid < kDeepPsum) {
+      const int c = tid >> 1, f = tid & 1;
+      double v;
+      if (c < 6) v = (xs[0][f][c] + xs[1][f][c]) + (xs[2][f][c] + xs[3][f][c]);
+      else if (c == 6) v = single[0][f] + single[2][f];
+      else v = single[1][f];
+      psum[((size_t)(li - slot_lo) * parts + part) * kDeepPsum + tid] = v;
+    }
+  }
+}
+
+// Dynamic LDS of k_halo_knots_fast (bytes).
+// (the deep levels' weights and the Romberg rows' for the context's divmax, not for the largest
+//  one allowed: 7 KB of 59 at the default 20 -- what lets a CU hold three blocks)
+__host__ __device__ inline int deep_w_levels(int divmax, int LC) {
+  const int n = divmax - LC;
+  return n < 0 ? 0 : (n > kDeepWLevels ? kDeepWLevels : n);
+}
+template <int LC>
+inline size_t deep_fast_lds(int NM, int divmax) {
+  const size_t deep = (size_t)(deep_f_off(NM) + 2 * kDeepF +
+                               deep_w_levels(divmax, LC) * kDeepWStride + (divmax + 1) * 32) *
+                          sizeof(double) + (size_t)kDeepF;
   return deep;                     // (> finalize_lds_doubles(NK) for any NK <= 512 at LC >= 11)
 }
 // ... of k_halo_knots_literal.
@@ -1037,17 +1208,17 @@ constexpr int kStampBlocks = 2048, kStampSlots = 24;
 __device__ long long g_ks[kStampBlocks * kStampSlots];
 #define KSTAMP(k)                                                                     \
   do {                                                                                \
-    if (first_item && threadIdx.x == 0 && blockIdx.x < kStampBlocks)                  \
+    if (first_item && threadIdx.x == 0 && blockIdx.x < kStampBlocks && !from_eval)    \
       g_ks[blockIdx.x * kStampSlots + (k)] = (long long)__builtin_amdgcn_s_memtime(); \
   } while (0)
 #define KSTAMP_VALUE(k, v)                                                            \
   do {                                                                                \
-    if (first_item && threadIdx.x == 0 && blockIdx.x < kStampBlocks)                  \
+    if (first_item && threadIdx.x == 0 && blockIdx.x < kStampBlocks && !from_eval)    \
       g_ks[blockIdx.x * kStampSlots + (k)] = (long long)(v);                          \
   } while (0)
 #define KSTAMP_BLOCK(k, v)                                                            \
   do {                                                                                \
-    if (threadIdx.x == 0 && blockIdx.x < kStampBlocks)                                \
+    if (threadIdx.x == 0 && blockIdx.x < kStampBlocks && !from_eval)                  \
       g_ks[blockIdx.x * kStampSlots + (k)] = (long long)(v);                          \
   } while (0)
 #else
@@ -1102,29 +1273,44 @@ __device__ __forceinline__ void deep_arrive(const chomp_config& cfg, const TabLa
 // precision, the launch is the epochs' finalisation -- and a listed knot (tightened
 // halo_precision) can only be of the smooth group 0, which this instance evaluates literally
 // right here, so that the headline chain does not carry an always-empty hand-over launch.
-template <int LC, int NT, bool SELF>
-__global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
+// EVAL: whether the instance can evaluate the integrand at a node that is not on the coarse
+// grid -- the nodes of a break-point interval whose value cannot be read off a neighbouring
+// branch's continuation, the margin above a singular satellite onset (alpha != 1).  The
+// integrand (NFW transform, mass function, HOD moments, fully inlined) is what takes this
+// kernel to 256 VGPRs and into scratch; with the default kind of HOD (alpha = 1) a knot of a
+// thousand needs it.  The host launches the EVAL instance when some epoch's HOD has
+// alpha != 1; otherwise the lean one, which hands a knot that turns out to need an
+// evaluation (stats[6]: two break points closer than a stencil, ~7 % of configs[2]'s listed
+// knots) on to a second launch of the EVAL instance behind it (from_eval: that launch draws
+// the list positions the lean one left at pending_eval_base(); the knots' samples are still
+// in their slots).
+template <int LC, int NT, bool SELF, bool EVAL>
+__global__ __launch_bounds__(NT, (!EVAL && NT == 256) ? 3 : 512 / NT) void k_halo_knots_fast(
     chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs, double* __restrict__ tab,
     const SiCiTab* __restrict__ sici_g, int g0, int g1, int g2, unsigned mask, int n_epoch,
     int* __restrict__ pending, int* __restrict__ npend, Epoch* __restrict__ epochs_rw,
     unsigned fam_mask, unsigned* __restrict__ status, const double* __restrict__ deepw,
     int all_literal, double tol, int max_rough, int max_fine, int* __restrict__ stats,
-    const double* __restrict__ nodes, const double* __restrict__ kept, int s0, int s1, int s2) {
+    const double* __restrict__ samples, const double* __restrict__ psum, int parts,
+    int round, int slot_lo, int slot_hi, int from_eval) {
   static_assert(LC == kNodeTabLevel, "the coarse samples are the node table's grid");
   constexpr int NC = 1 << LC;
   constexpr int NWV = NT / 64;
   extern __shared__ __align__(16) double sm[];
   __shared__ Epoch E;
-  __shared__ SiCiTab S;
-  __shared__ int item_sh, n_rough_sh, n_fine_sh, n_seg_sh, last_sh;
+  // (the Si/Ci tables only where the instance evaluates the NFW transform)
+  constexpr bool kNeedsSici = SELF || EVAL;
+  __shared__ std::conditional_t<kNeedsSici, SiCiTab, double> S_store;
+  SiCiTab& S = *reinterpret_cast<SiCiTab*>(&S_store);
+  __shared__ int item_sh, n_rough_sh, n_fine_sh, n_seg_sh, last_sh, bail_sh;
   __shared__ int rough_sh[kDeepMaxRough], fine_sh[kDeepMaxFine];
   __shared__ int seg_lo[kDeepMaxRough + 1], seg_hi[kDeepMaxRough + 1];
-  __shared__ double lsum_w[NWV][2][LC + 1];        // per-wavefront sums of the coarse levels
   // per node-by-node interval: the states of its two end nodes (low / high nibble), and whether
   // its nodes may be read off the one-sided continuations of the neighbouring smooth segments
   __shared__ unsigned char fine_states[kDeepMaxFine], fine_poly[kDeepMaxFine];
   // per smooth segment [lo, hi]: the sum of the samples lo .. hi - 7 (see the deep rounds)
   __shared__ double seg_sum[2][kDeepMaxRough + 1], seg_slot[NWV][2][kDeepMaxRough + 1];
+  __shared__ double rows_park[2][RombergRows2::kPark];
   const int NK = L.NK;
   const int tid = threadIdx.x;
   const int wv = tid >> 6, ln = tid & 63;
@@ -1133,22 +1319,27 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
   // (with an empty list no block of this launch writes a knot: every value the finalisation
   //  reads comes from the previous launch, and no fence is needed)
   const bool fences = count != 0;
-  if ((int)blockIdx.x < n_epoch)
+  if (round == 0 && !from_eval && (int)blockIdx.x < n_epoch)
     deep_arrive(cfg, L, epochs_rw, tab, (int)blockIdx.x, fam_mask, status, npend, fences, &last_sh, sm);
-  if (count == 0) return;          // nothing listed: no traffic on the queue head
+  // this round's share of the list: the knots whose samples are in the buffer's slots now
+  const int item_hi = count < slot_hi ? count : slot_hi;
+  if (item_hi <= slot_lo) return;  // nothing listed (for this round): no traffic on the queue head
   int* lit_items = pending + pending_literal_base((size_t)n_epoch, NK);
+  int* ev_items = pending + pending_eval_base((size_t)n_epoch, NK) + slot_lo;
+  const int ev_count = from_eval ? pending[kPendingEvCount + round] : 0;
+  if (from_eval && ev_count == 0) return;
   // what does not depend on the knot, once per block: Si/Ci tables; the deep levels' weights
   // and the Romberg rows' weights where the finalisation of an epoch cannot reach them
-  double* const w_all = sm + L.NM + 8 * (L.NM - 1) + kDeepScratch + 2 * (NC + 1);
-  const bool w_safe = finalize_lds_doubles(NK) <= L.NM + 8 * (L.NM - 1) + kDeepScratch + 2 * (NC + 1);
+  double* const w_all = sm + deep_f_off(L.NM) + 2 * kDeepF;
+  const bool w_safe = finalize_lds_doubles(NK) <= deep_f_off(L.NM) + 2 * kDeepF;
   auto stage_weights = [&]() {
-    int nlev = cfg.divmax - LC;
-    nlev = nlev < 0 ? 0 : (nlev > kDeepWLevels ? kDeepWLevels : nlev);
+    const int nlev = deep_w_levels(cfg.divmax, LC);
     copy_doubles(w_all, deepw, nlev * kDeepWStride);
-    romberg_weights_to_lds(w_all + kDeepWLevels * kDeepWStride, cfg.divmax);   // (the rows' weights)
+    romberg_weights_to_lds(w_all + nlev * kDeepWStride, cfg.divmax);   // (the rows' weights)
   };
-  copy_doubles(reinterpret_cast<double*>(&S), reinterpret_cast<const double*>(sici_g),
-               (int)(sizeof(SiCiTab) / sizeof(double)));
+  if constexpr (kNeedsSici)
+    copy_doubles(reinterpret_cast<double*>(&S), reinterpret_cast<const double*>(sici_g),
+                 (int)(sizeof(SiCiTab) / sizeof(double)));
   stage_weights();
 #ifdef CHOMP_STAMPS
   bool first_item = true;
@@ -1159,9 +1350,16 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
     first_item = (n_items++ == 0);
 #endif
     __syncthreads();               // (previous item done with E, sm)
-    if (tid == 0) item_sh = atomicAdd(&pending[1], 1);
+    if (tid == 0) {
+      if (from_eval) {
+        const int d = atomicAdd(&pending[kPendingEvDraw + round], 1);
+        item_sh = d < ev_count ? ev_items[d] : item_hi;
+      } else {
+        item_sh = slot_lo + atomicAdd(&pending[kPendingDraw + round], 1);
+      }
+    }
     __syncthreads();
-    if (item_sh >= count) {        // block-uniform
+    if (item_sh >= item_hi) {      // block-uniform
       KSTAMP_BLOCK(19, __builtin_amdgcn_s_memtime());
 #ifdef CHOMP_STAMPS
       KSTAMP_BLOCK(20, n_items - 1);
@@ -1225,77 +1423,35 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
                  kEpochDoubles);
     copy_doubles(nu_knots, t + L.off_nu, L.NM);
     copy_doubles(lnm_pp, t + L.off_lnm_pp, 4 * (L.NM - 1));
-    if (tid == 0) { n_rough_sh = 0; n_fine_sh = 0; n_seg_sh = 0; }
-    if (ln <= LC) { lsum_w[wv][0][ln] = 0.0; lsum_w[wv][1][ln] = 0.0; }
+    if (tid == 0) { n_rough_sh = 0; n_fine_sh = 0; n_seg_sh = 0; bail_sh = 0; }
     __syncthreads();
     KSTAMP(1);
     double* red = sm + L.NM + 8 * (L.NM - 1);
-    double* F0 = red + kDeepScratch;
-    double* F1 = F0 + (NC + 1);
-    double* W = F1 + (NC + 1);                             // [divmax - LC][kDeepWStride]
-    const double* Ctab = W + kDeepWLevels * kDeepWStride;  // [divmax + 1][32]
-    unsigned char* code = reinterpret_cast<unsigned char*>(W + kDeepWLevels * kDeepWStride +
-                                                           (kMaxDivmax + 1) * 32);
+    double* F0 = sm + deep_f_off(L.NM);
+    double* F1 = F0 + kDeepF;                              // (both in deep_pos order)
+    double* W = F1 + kDeepF;                               // [divmax - LC][kDeepWStride]
+    const double* Ctab = W + deep_w_levels(cfg.divmax, LC) * kDeepWStride;   // [divmax + 1][32]
+    unsigned char* code = reinterpret_cast<unsigned char*>(
+        W + deep_w_levels(cfg.divmax, LC) * kDeepWStride + (cfg.divmax + 1) * 32);
     const double a = group_lower(E, group), b = log(E.nu_max);
     HaloCtx c{&E, &S, nu_knots, lnm_pp, L.NM,
               linspace_at(log(cfg.k_min), log(cfg.k_max), NK, ik), (mask & kMaskExclusion) != 0};
-    bool literal = false;
+    bool literal = false, to_eval = false;
     int flip = 0;
     RombergRows2 R;
     R.ctab = Ctab;
     {
-      // ---- coarse samples from the (epoch, group) node table (what does not depend on k is
-      // already there -- the lower levels are the very nodes k_halo_knots summed); the table
-      // is level-major, so a wavefront's 64 samples of one pass belong to one or two levels
-      // (the first pass: levels 0..6): their sums are taken here, from the registers, one
-      // butterfly per level present -- a separate pass over the samples in position order
-      // would read LDS at power-of-two strides (2.8 M bank conflicts per C3 launch)
-      const double* nd = nodes + ((size_t)e * 3 + group) * kNodeStride;
-      // (the levels <= kNodeLevel of an HOD knot are the very values k_halo_knots summed and
-      //  kept -- all but the upper end point, which it takes from d_endp: read, not re-evaluated)
-      const int sc = zg == 0 ? s0 : (zg == 1 ? s1 : s2);
-      const double2* kp = (kept != nullptr && sc >= 0)
-                              ? reinterpret_cast<const double2*>(kept + kept_offset(sc, n_epoch, e, NK, ik))
-                              : nullptr;
-      for (int base = 0; base <= NC; base += NT) {
-        const int idx = base + tid;
-        const bool live = idx <= NC;
-        double o[2] = {0.0, 0.0};
-        int lv = 0;
-        if (live) {
-          int q;
-          if (idx < 2) {
-            q = idx == 0 ? 0 : NC;
-          } else {                                             // level-major -> position
-            const int m = idx - 1;
-            lv = 32 - __builtin_clz((unsigned)m);
-            q = (2 * (m - (1 << (lv - 1))) + 1) << (LC - lv);
-          }
-          const double state = nd[6 * kNodeCount + idx];
-          if (kp != nullptr && idx < kNodeBase && idx != 1) {
-            const double2 v = kp[idx];
-            o[0] = v.x; o[1] = v.y;
-          } else {
-            node_pair(S, c.ln_k, c.exclusion, nd[idx], nd[kNodeCount + idx], nd[2 * kNodeCount + idx],
-                      nd[3 * kNodeCount + idx], nd[4 * kNodeCount + idx], nd[5 * kNodeCount + idx],
-                      state, o);
-          }
-          F0[q] = o[0];
-          F1[q] = o[1];
-          code[q] = (unsigned char)(int)state;
-        }
-        const int i0 = base + 64 * wv;                         // this wavefront's first sample
-        if (i0 <= NC) {                                        // wave-uniform
-          const int i1 = i0 + 63 < NC ? i0 + 63 : NC;
-          int l0 = i0 < 2 ? 1 : 32 - __builtin_clz((unsigned)(i0 - 1));
-          const int l1 = i1 < 2 ? 0 : 32 - __builtin_clz((unsigned)(i1 - 1));
-          if (l0 < 1) l0 = 1;
-          for (int l = l0; l <= l1; ++l) {
-            const bool mine = live && idx >= 2 && lv == l;
-            const double x0 = wave_sum(mine ? o[0] : 0.0), x1 = wave_sum(mine ? o[1] : 0.0);
-            if (ln == 0) { lsum_w[wv][0][l] += x0; lsum_w[wv][1][l] += x1; }
-          }
-        }
+      // ---- the knot's coarse samples: k_halo_knots_samples left them in slot (list position)
+      // of the sample buffer, already in deep_pos order, with the states of the nodes behind
+      // them and the sums of levels LC - 7 .. LC beside them: a contiguous copy into LDS
+      {
+        const double* slot = samples + (size_t)(item_sh - slot_lo) * kDeepSlot;
+        const double2* src = reinterpret_cast<const double2*>(slot);
+        double2* dst = reinterpret_cast<double2*>(F0);
+        for (int i = tid; i < kDeepF; i += NT) dst[i] = src[i];              // F0 and F1
+        const unsigned* csrc = reinterpret_cast<const unsigned*>(slot + 2 * kDeepF);
+        unsigned* cdst = reinterpret_cast<unsigned*>(code);
+        for (int i = tid; i < kDeepF / 4; i += NT) cdst[i] = csrc[i];
       }
       __syncthreads();
       KSTAMP(2);
@@ -1304,14 +1460,20 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
         double* lsum = red + 2 * NWV;                          // [2][LC + 1] (behind group_sum's slots)
         if (tid < 2 * (LC + 1)) {
           const int f = tid / (LC + 1), l = tid % (LC + 1);
+          const double* Ff = f ? F1 : F0;
           double v = 0.0;
-#pragma unroll
-          for (int w = 0; w < NWV; ++w) v += lsum_w[w][f][l];
+          if (l >= LC - 7) {                                   // the sampling launch's parts, in order
+            const double* ps = psum + (size_t)(item_sh - slot_lo) * parts * kDeepPsum + 2 * (LC - l) + f;
+            for (int pt = 0; pt < parts; ++pt) v += ps[pt * kDeepPsum];
+          } else if (l >= 1) {                                 // samples 256 m, m odd multiples of 2^(3 - l)
+            const int step = 1 << (LC - l);
+            for (int q = step; q < NC; q += 2 * step) v += Ff[deep_pos(q)];
+          }
           lsum[f * (LC + 1) + l] = v;
         }
         __syncthreads();
-        R.start(b - a, cfg.global_precision, cfg.halo_precision, 0.5 * (F0[0] + F0[NC]),
-                0.5 * (F1[0] + F1[NC]), pa, pb);
+        R.start(b - a, cfg.global_precision, cfg.halo_precision,
+                0.5 * (F0[0] + F0[deep_pos(NC)]), 0.5 * (F1[0] + F1[deep_pos(NC)]), pa, pb);
         for (int l = 1; l <= LC && !R.all_done(); ++l) R.advance(l, lsum[l], lsum[LC + 1 + l]);
       }
       KSTAMP(3);
@@ -1417,14 +1579,18 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
                 double dl0 = 0.0, dl1 = 0.0, dr0 = 0.0, dr1 = 0.0, sc0 = 0.0, sc1 = 0.0;
 #pragma unroll
                 for (int m = 0; m < 9; ++m) {
-                  dl0 = fma(w8[m], F0[i - 8 + m], dl0);
-                  dl1 = fma(w8[m], F1[i - 8 + m], dl1);
-                  dr0 = fma(w8[m], F0[i + 1 + m], dr0);
-                  dr1 = fma(w8[m], F1[i + 1 + m], dr1);
-                  sc0 += fabs(F0[i - 8 + m]) + fabs(F0[i + 1 + m]);
-                  sc1 += fabs(F1[i - 8 + m]) + fabs(F1[i + 1 + m]);
+                  const int pl = deep_pos(i - 8 + m), pr = deep_pos(i + 1 + m);
+                  dl0 = fma(w8[m], F0[pl], dl0);
+                  dl1 = fma(w8[m], F1[pl], dl1);
+                  dr0 = fma(w8[m], F0[pr], dr0);
+                  dr1 = fma(w8[m], F1[pr], dr1);
+                  sc0 += fabs(F0[pl]) + fabs(F0[pr]);
+                  sc1 += fabs(F1[pl]) + fabs(F1[pr]);
                 }
-                const double lim = 1e-7 / 18.0;
+                // (budget: the nodes of a break-point interval are 1 / NC of a level's; with up to
+                //  four such intervals an error of tol NC / 4 of the samples' size per node keeps
+                //  the level sum within tol -- 5e-7 at the defaults; sc sums 18 samples)
+                const double lim = tol * (double)NC / (4.0 * 18.0);
                 ok = fabs(dl0) <= lim * sc0 && fabs(dr0) <= lim * sc0 &&
                      fabs(dl1) <= lim * sc1 && fabs(dr1) <= lim * sc1;
               }
@@ -1438,7 +1604,11 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
                 double a0 = 0.0, a1 = 0.0;
                 if (sgi < ns) {                                  // block-uniform
                   const int hi7 = seg_hi[sgi] - 7;
-                  for (int q = seg_lo[sgi] + tid; q <= hi7; q += NT) { a0 += F0[q]; a1 += F1[q]; }
+                  for (int q = seg_lo[sgi] + tid; q <= hi7; q += NT) {
+                    const int at = deep_pos(q);
+                    a0 += F0[at];
+                    a1 += F1[at];
+                  }
                   a0 = wave_sum(a0);
                   a1 = wave_sum(a1);
                   if (ln == 0) { seg_slot[wv][0][sgi] = a0; seg_slot[wv][1][sgi] = a1; }
@@ -1473,13 +1643,14 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
               double p0 = 0.0, p1 = 0.0;
 #pragma unroll
               for (int m = 0; m < kDeepStencil; ++m) {
-                p0 = fma(w[m], F0[2 * (st + m)], p0);
-                p1 = fma(w[m], F1[2 * (st + m)], p1);
+                p0 = fma(w[m], F0[st + m], p0);                // (even sample 2 (st + m))
+                p1 = fma(w[m], F1[st + m], p1);
               }
-              e0 += fabs(p0 - F0[2 * ep + 1]);
-              e1 += fabs(p1 - F1[2 * ep + 1]);
+              e0 += fabs(p0 - F0[kDeepOdd + ep]);              // (odd sample 2 ep + 1)
+              e1 += fabs(p1 - F1[kDeepOdd + ep]);
             }
-            for (int q = tid; q <= NC; q += NT) { m0 += F0[q]; m1 += F1[q]; }
+            for (int q = tid; q <= NC / 2; q += NT) { m0 += F0[q]; m1 += F1[q]; }
+            for (int q = tid; q < NC / 2; q += NT) { m0 += F0[kDeepOdd + q]; m1 += F1[kDeepOdd + q]; }
             e0 = group_sum<NWV>(e0, red, flip);
             e1 = group_sum<NWV>(e1, red, flip);
             m0 = group_sum<NWV>(m0, red, flip);
@@ -1487,17 +1658,27 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
             const bool bad0 = !R.done[0] && !(e0 * (1.0 / 256.0) <= tol * fabs(m0));
             const bool bad1 = !R.done[1] && !(e1 * (1.0 / 256.0) <= tol * fabs(m1));
             if (bad0 || bad1) literal = true;
+            bool need_eval = false;
+            if constexpr (!EVAL) {   // an interval that has to be evaluated node by node
+              for (int x = 0; x < nf_all; ++x) need_eval = need_eval || fine_poly[x] == 0;
+            }
             if (stats && tid == 0) {
+              if (!literal && need_eval) atomicAdd(&stats[6], 1);
               if (literal) atomicAdd(&stats[4], 1);
               const float r0 = R.done[0] ? 0.0f : (float)(e0 * (1.0 / 256.0) / fabs(m0));
               const float r1 = R.done[1] ? 0.0f : (float)(e1 * (1.0 / 256.0) / fabs(m1));
               atomicMax(&stats[5], __float_as_int(fmaxf(r0, r1)));   // (positive floats order as ints)
             }
+            if (need_eval && !literal) to_eval = true;
           }
         }
       }
       if (literal) {               // block-uniform: on to k_halo_knots_literal, still counted
         if (tid == 0) lit_items[atomicAdd(&pending[4], 1)] = item;
+        continue;
+      }
+      if (to_eval) {               // ... to the evaluating instance behind this launch
+        if (tid == 0) ev_items[atomicAdd(&pending[kPendingEvCount + round], 1)] = item_sh;
         continue;
       }
       KSTAMP(5);
@@ -1511,6 +1692,10 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
         const int nf = n_fine_sh;
         for (int lv0 = LC + 1; lv0 <= cfg.divmax && !R.all_done(); lv0 += kDeepRound) {
           const int ng = cfg.divmax - lv0 + 1 < kDeepRound ? cfg.divmax - lv0 + 1 : kDeepRound;
+          // (read back behind the round's exchange; two buffers in turn: a wavefront may still
+          //  be reading the last round's while wavefront 0 writes this one's)
+          double* const park = rows_park[((lv0 - LC - 1) / kDeepRound) & 1];
+          R.park(park);
           double s0[kDeepRound], s1[kDeepRound];
 #pragma unroll
           for (int g = 0; g < kDeepRound; ++g) { s0[g] = 0.0; s1[g] = 0.0; }
@@ -1534,8 +1719,9 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
                 const int st = part < 3 ? lo : hi - 7;
 #pragma unroll
                 for (int m = 0; m < kDeepStencil; ++m) {
-                  v0 = fma(w[m], F0[st + m], v0);
-                  v1 = fma(w[m], F1[st + m], v1);
+                  const int at = deep_pos(st + m);
+                  v0 = fma(w[m], F0[at], v0);
+                  v1 = fma(w[m], F1[at], v1);
                 }
               } else {
                 double d0 = seg_sum[0][sgi], d1 = seg_sum[1][sgi];
@@ -1544,8 +1730,9 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
                   v0 = fma(w[m], d0, v0);
                   v1 = fma(w[m], d1, v1);
                   if (m < kDeepStencil - 1) {
-                    d0 += F0[hi - 6 + m] - F0[lo + m];
-                    d1 += F1[hi - 6 + m] - F1[lo + m];
+                    const int ah = deep_pos(hi - 6 + m), al = deep_pos(lo + m);
+                    d0 += F0[ah] - F0[al];
+                    d1 += F1[ah] - F1[al];
                   }
                 }
               }
@@ -1576,13 +1763,18 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
                 const bool left = st == sl;
                 const int s0i = left ? iv - 7 : iv + 1;
                 const double t = (left ? 7.0 : -1.0) + ((double)rr + 0.5) / (double)n;
-                lagrange8_pair(t, F0 + s0i, F1 + s0i, &o[0], &o[1]);
+                lagrange8_pair(t, F0, F1, s0i, [](int q) { return deep_pos(q); }, &o[0], &o[1]);
                 done = true;
               }
             }
             if (!done) {
-              int st;
-              halo_eval_coded(group, c, x, o, &st);
+              if constexpr (EVAL) {
+                int st;
+                halo_eval_coded(group, c, x, o, &st);
+              } else {             // (this instance carries no integrand: see EVAL)
+                o[0] = o[1] = 0.0;
+                bail_sh = 1;
+              }
             }
 #pragma unroll
             for (int gg = 0; gg < kDeepRound; ++gg)
@@ -1614,11 +1806,24 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_halo_knots_fast(
             flip ^= 1;
           }
           if (lv0 == LC + 1) KSTAMP(12);
+          if constexpr (!EVAL) {
+            // (a node of a break-point interval whose state is neither neighbour's; read behind
+            //  the exchange's barrier: block-uniform)
+            if (bail_sh) { to_eval = true; break; }
+          }
+          R.unpark(park);
 #pragma unroll
           for (int g = 0; g < kDeepRound; ++g)
             if (g < ng && !R.all_done()) R.advance(lv0 + g, s0[g], s1[g]);
           KSTAMP(5 + (lv0 - LC - 1) / kDeepRound + 1);
         }
+      }
+      if (to_eval) {               // (!EVAL only) still counted in npend[e]
+        if (tid == 0) {
+          ev_items[atomicAdd(&pending[kPendingEvCount + round], 1)] = item_sh;
+          if (stats) atomicAdd(&stats[6], 1);
+        }
+        continue;
       }
     }
     KSTAMP(16);

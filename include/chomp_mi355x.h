@@ -319,6 +319,9 @@ int chomp_status_wait(chomp_ctx* ctx, size_t epoch0, size_t n, unsigned* out);
  *                            the margin above a singular satellite onset, segments shorter
  *                            than a stencil) and still take the fast sums (default and
  *                            maximum 64)
+ *   CHOMP_TUNE_HOD_CAP       Romberg level (6..10, default 9) up to which a knot of the HOD
+ *                            integrands walks the node table before it is listed for the fast
+ *                            deep-level sums (10: the whole table, as for the smooth pair)
  *   CHOMP_TUNE_WTHETA_DIRECT 1: w(theta) by evaluating the kernel spline at every Romberg node
  *                            (the checker of the moment route of chomp_wtheta)
  *   CHOMP_TUNE_CELL_ONE_KERNEL 1: C_l with every Romberg level in the per-multipole kernel (the
@@ -337,12 +340,15 @@ int chomp_status_wait(chomp_ctx* ctx, size_t epoch0, size_t n, unsigned* out);
 #define CHOMP_TUNE_DEEP_TOL 6
 #define CHOMP_TUNE_DEEP_MAX_BREAKS 7
 #define CHOMP_TUNE_DEEP_MAX_FINE 8
-#define CHOMP_TUNE_COUNT 9
+#define CHOMP_TUNE_HOD_CAP 9
+#define CHOMP_TUNE_COUNT 10
 int chomp_set_tuning(chomp_ctx* ctx, int what, long long value);
-/* Measurement aid: out[6] <- knots beyond the node tables done so far (since the context was
+/* Measurement aid: out[7] <- knots beyond the node tables done so far (since the context was
  * created) by [0] the fast deep-level sums, [1] literal evaluation of every node; why literal:
  * [2] too many break points, [3] too many node-by-node intervals, [4] the self-check of the
- * interpolation; [5] the largest self-check error estimate seen, in units of 1e-15. */
+ * interpolation; [5] the largest self-check error estimate seen, in units of 1e-15; [6] why
+ * literal, continued: the knot needed the integrand at a node off the coarse grid in a set-up
+ * whose kernel instance carries none (every HOD with alpha = 1). */
 int chomp_get_deep_stats(chomp_ctx* ctx, long long* out);
 
 #define CHOMP_TAB_LN_MASS 0 /* MassFunction._ln_mass_array  [mass_npoints] */
