@@ -18,11 +18,17 @@ prints ONE JSON line (contract in the task description) carrying
   cpu_baseline      the NumPy oracle = a port of the reference's algorithm, timed on
                     this box's host cores on a bounded sample of the same workload
   other_configs     configs[2..4] (c3, c4, c5) timed in the same process, GPU side
+  dropin            the reference-shaped loop over one Halo object (ms per z, samples/s)
 
-N > 1 (torch.distributed.run, one rank per GPU, RCCL): the headline is WEAK scaling
-(every GPU carries configs[1]'s 64 redshift rows; at N = 1 exactly configs[1]); the
-same run then times the STRONG split of SURVEY 8(e) (the 64 rows dealt over the ranks)
-and reports it under `strong_scaling`.
+N > 1 (torch.distributed.run, one rank per GPU, RCCL): the headline is the STRONG split
+of north_star / SURVEY 8(e) -- configs[1]'s 64 redshift rows dealt over the ranks, one
+all-gather per step; the same run then times the WEAK split (64 rows per GPU) and reports
+it under `weak_scaling` (`--scaling weak` swaps the two).  Rank 0 times the CPU baseline
+before it touches the GPU at every N.
+
+Every leg reports ms_per_step_median / _p95 / _max beside its mean (HIP events behind
+every step, a pass of its own), and `dropin` is the reference-shaped call pattern: one
+Halo, set_redshift(z) + power_mm(k) per redshift, host arrays in and out.
 
 --workload c3 | c4 | c5 runs one of the other configs as the headline instead.
 """
@@ -43,7 +49,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 measur
 FP64_VALU_PEAK_TFLOPS = 78.6   # vector fp64: half the 157.3 TFLOP/s fp32 vector peak
 N_THETA, N_ELL = 1024, 2048
 # SQ counter summaries of Stage K (tools/prof.sh sq -> tools/collect_profiles.py), newest first
-STAGE_K_COUNTER_FILES = ("round3_stage_k_counters.json", "round2_stage_k_counters.json")
+STAGE_K_COUNTER_FILES = ("round4_stage_k_counters.json", "round3_stage_k_counters.json",
+                         "round2_stage_k_counters.json")
+PROFILE_ROUND = "round4"
 
 
 # ---------------------------------------------------------------------------
@@ -176,6 +184,59 @@ def rehearsal_gathers():
     grid.gather_samples = gather_samples
 
 
+def step_distribution(step, n, stream, dev):
+    """Per-step durations of n further steps (HIP events on the stream the steps are queued on,
+    one behind every step; run AFTER a leg's timed region so that the headline's K steps carry
+    no event packets): median / p95 / max beside the leg's mean, and where the slowest step
+    was -- a transient is reported, not averaged away."""
+    import torch
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+    torch.cuda.synchronize(dev)
+    ev[0].record(stream)
+    for i in range(n):
+        step()
+        ev[i + 1].record(stream)
+    torch.cuda.synchronize(dev)
+    d = numpy.array([ev[i].elapsed_time(ev[i + 1]) for i in range(n)])
+    return {"ms_per_step_median": float(numpy.median(d)),
+            "ms_per_step_p95": float(numpy.percentile(d, 95)),
+            "ms_per_step_max": float(d.max()), "ms_per_step_min": float(d.min()),
+            "slowest_step_index": int(d.argmax()), "steps_in_distribution": int(n),
+            "clock": "HIP events behind every step, a pass of its own after the timed region"}
+
+
+def dropin_leg(D, passes=3):
+    """The reference-shaped call pattern (halo.py:255-264, 277-320): ONE Halo
+    object, `set_redshift(z)` + `power_mm(k)` per redshift with host arrays in and out -- what
+    an existing script does, unchanged.  Every z is a full single-epoch Stage K (a latency
+    chain: each launch lasts as long as its slowest unit) + Stage E + the result's copy to the
+    host; the headline batches the 64 redshifts into one set-up instead."""
+    import warnings
+    from chomp_amd import halo
+    k = numpy.logspace(-3, 2, NK)
+    z = numpy.linspace(0.0, Z_MAX, NZ)
+    h = halo.Halo(float(z[-1]))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for zz in z[:8]:
+            h.set_redshift(float(zz))
+            out = h.power_mm(k)
+        per = []
+        for _ in range(passes):
+            t0 = time.perf_counter()
+            for zz in z:
+                h.set_redshift(float(zz))
+                out = h.power_mm(k)
+            per.append(time.perf_counter() - t0)
+    assert out.shape == (NK,) and bool(numpy.isfinite(out).all())
+    best = min(per)
+    return {"workload": "one Halo: %d x (set_redshift(z) + power_mm(k[%d])), host arrays in and out"
+                        % (NZ, NK),
+            "ms_per_z": 1e3 * best / NZ, "ms_per_pass": 1e3 * best,
+            "samples_per_s": NZ * NK / best, "passes": passes,
+            "ms_per_pass_all": [1e3 * t for t in per], "clock": "host wall clock, best pass"}
+
+
 def grid_leg(D, which, mf, nz, steps, warmup, stream):
     """`steps` timed steps of the (k, z) grid workload with nz redshift rows in all, dealt
     over the ranks (interleaved).  Steps are software-pipelined for N > 1: the all-gather of
@@ -207,6 +268,7 @@ def grid_leg(D, which, mf, nz, steps, warmup, stream):
     D.fence()
     elapsed = D.max_over_ranks(time.perf_counter() - t0)
     assert out.shape == (nz, NK) and bool(torch.isfinite(out).all())
+    hg.bench_step = lambda: run(1)          # (step_distribution: one whole step, gather included)
     return elapsed, hg, k, out
 
 
@@ -367,10 +429,13 @@ def projection_leg(D, ggl, steps, warmup):
         for _ in range(steps):
             w, c = step()
         D.fence()
-    elapsed = D.max_over_ranks(time.perf_counter() - t0)
-    assert w.numel() == N_THETA and c.numel() == N_ELL
-    assert bool(torch.isfinite(w).all()) and bool((c > 0).all())
-    return elapsed
+        elapsed = D.max_over_ranks(time.perf_counter() - t0)
+        assert w.numel() == N_THETA and c.numel() == N_ELL
+        assert bool(torch.isfinite(w).all()) and bool((c > 0).all())
+        dist = None
+        if D.world == 1:
+            dist = step_distribution(step, steps, torch.cuda.current_stream(D.dev), D.dev)
+    return elapsed, dist
 
 
 def stage_k_roofline(stage_k_seconds, workload):
@@ -404,15 +469,13 @@ def launch_ranks(n):
     with torch.distributed.run as CHILDREN of this process -- which never initialises the GPU
     and is never replaced by another program -- relay rank 0's JSON line and return the
     launcher's exit code."""
-    import socket
     import subprocess
-    with socket.socket() as sk:                      # a free rendezvous port on the loop-back
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get(
         "HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
-           "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+    # --standalone: the launcher picks the rendezvous port itself (a port found here by binding
+    # and closing a socket could be taken by someone else before the ranks get to it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr",
+           "127.0.0.1", "--nnodes=1", "--nproc-per-node", str(n),
            os.path.abspath(__file__)] + sys.argv[1:]
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
     line = None
@@ -442,9 +505,10 @@ def main():
                     help="--workload batch: 1 = a cosmology per epoch, redrawn every step; "
                          "0 = one cosmology")
     ap.add_argument("--no-batch-scaling", action="store_true")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
                     help="N > 1, c2 / c3: which split is the headline (the other one is timed "
-                         "too and reported beside it)")
+                         "too and reported beside it).  Default: strong -- configs[1]'s 64 "
+                         "redshift rows dealt over the ranks, as north_star shards it")
     ap.add_argument("--roofline-nk", type=int, default=1 << 20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true",
@@ -471,8 +535,9 @@ def main():
     which = "power_mm" if args.workload == "c2" else "power_gm"
     mf = "st" if args.workload == "c2" else "tinker"
     baseline = None
-    if world == 1 and not args.no_cpu_baseline and args.workload != "batch":
-        # before the GPU is initialised: the pool forks
+    if rank == 0 and not args.no_cpu_baseline and args.workload != "batch":
+        # rank 0 only, at every N; before this process initialises the GPU or joins the process
+        # group: the pool forks (the other ranks wait for it in init_process_group)
         if proj:
             baseline = projection_baseline(args.workload == "c5")
         else:
@@ -503,10 +568,9 @@ def main():
     # image serialises against the whole device (+0.1 ms per step, measured).
     stream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)
-    # rccl_world_size: ranks that talk RCCL (1 without a process group; None when the group is
-    # the gloo rehearsal, which proves nothing about RCCL)
-    job = {"rccl_world_size": (1 if world == 1 else dist.get_world_size() if backend == "nccl"
-                               else None),
+    # rccl_world_size: ranks that talk RCCL -- None when no nccl group exists (one rank without
+    # a process group, or the gloo rehearsal: neither says anything about RCCL)
+    job = {"rccl_world_size": dist.get_world_size() if backend == "nccl" else None,
            "world_size": world, "backend": backend or "none"}
     if args.rehearse and world > 1:
         rehearsal_gathers()
@@ -535,7 +599,7 @@ def main():
     # ---- projection workloads as the headline
     if proj:
         ggl = args.workload == "c5"
-        elapsed = projection_leg(D, ggl, args.steps, args.warmup)
+        elapsed, pdist = projection_leg(D, ggl, args.steps, args.warmup)
         res = {"metric": "Limber w(theta) + C_l samples/sec (projection and halo set-up included)",
                "value": (N_THETA + N_ELL) * args.steps / elapsed, "unit": "samples/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -553,6 +617,8 @@ def main():
                           "sharding": "theta and l interleaved over %d rank(s), set-up "
                                       "replicated, one all-gather each" % world},
                "job": job, "roofline": None}
+        if pdist is not None:
+            res.update(pdist)
         if baseline is not None:
             res["cpu_baseline"] = baseline
         return finish(res)
@@ -561,8 +627,11 @@ def main():
     # weak: every GPU carries configs[1]'s 64 redshift rows (global grid 4096 k x 64 N z; at
     # N = 1 exactly configs[1]); strong: configs[1]'s 64 rows dealt over the ranks.
     nz_of = {"weak": NZ * world, "strong": NZ}
-    head = args.scaling
+    # (one rank: both splits are configs[1] itself; the label stays "weak" -- per-GPU work fixed
+    #  -- so that a scaling run's N = 1 line equals the plain bench line)
+    head = args.scaling or ("weak" if world == 1 else "strong")
     elapsed, hg, k, out = grid_leg(D, which, mf, nz_of[head], args.steps, args.warmup, stream)
+    head_dist = step_distribution(hg.bench_step, args.steps, stream, dev)
     nz = nz_of[head]
     ms_per_step = 1e3 * elapsed / args.steps
     value = nz * NK * args.steps / elapsed
@@ -583,10 +652,11 @@ def main():
                        "rows_per_rank": [len(range(r, nz_of[alt], world)) for r in range(world)]}
 
     if args.no_roofline:
-        return finish({"metric": "halo-model P(k,z) samples/sec (development run)",
-                       "value": value, "unit": "samples/s", "n_gpus": world,
-                       "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-                       "scaling": head, "job": job})
+        return finish(dict({"metric": "halo-model P(k,z) samples/sec (development run)",
+                            "value": value, "unit": "samples/s", "n_gpus": world,
+                            "steps": args.steps, "warmup": args.warmup,
+                            "ms_per_step": ms_per_step, "scaling": head, "job": job},
+                           **head_dist))
 
     # ---- stage split and rooflines (rank 0's shard; HIP events on the kernel stream)
     def timed(fn, reps):
@@ -720,6 +790,7 @@ def main():
                               "n_local_z": n_local},
         "roofline": roof,
     }
+    res.update(head_dist)
     if n_local == NZ:
         rk = stage_k_roofline(t_setup, args.workload)
         if rk is not None:
@@ -735,6 +806,7 @@ def main():
         del hg
         n_o = 30                                     # (timed steps of each of these legs)
         e3, hg3, k3, _ = grid_leg(D, "power_gm", "tinker", NZ, n_o, 3, stream)
+        d3 = step_distribution(hg3.bench_step, n_o, stream, dev)
         ts3 = timed(lambda: hg3.setup("power_gm"), 5)
         f3 = stage_k_roofline(ts3, "c3")
         other["c3"] = {"workload": "configs[2]: power_gm, Tinker10 + Zheng07, 4096 k x 64 z",
@@ -747,9 +819,10 @@ def main():
                        "frac_of": "vector-fp64 peak, Stage K (FLOP per step: profiles/%s)"
                                   % STAGE_K_COUNTER_FILES[0],
                        "deep_knots_fast_literal_cumulative": list(hg3.ctx.deep_stats())}
+        other["c3"].update(d3)
         del hg3
         for name, ggl in (("c4", False), ("c5", True)):
-            ep = projection_leg(D, ggl, n_o, 3)
+            ep, pd = projection_leg(D, ggl, n_o, 3)
             other[name] = {"workload": "configs[%d]: %s, 1024 theta + 2048 l" % (
                                4 if ggl else 3, "GGL J2 kernel + HaloFit power_gm" if ggl
                                else "clustering J0 kernel + power_gg"),
@@ -760,8 +833,14 @@ def main():
                                               "k_wtheta_nodes / _moments / _fast (level sums from "
                                               "prefix moments)",
                            "frac": None,
-                           "profile": "profiles/round3_kernel_stats_%s.csv" % name}
+                           "profile": "profiles/%s_kernel_stats_%s.csv" % (PROFILE_ROUND, name)}
+            if pd is not None:
+                other[name].update(pd)
         res["other_configs"] = other
+        # ---- the reference-shaped call pattern (one Halo, set_redshift + power_mm per z, host
+        # arrays): what a drop-in script sees, beside the batched headline
+        res["dropin"] = dropin_leg(D)
+        res["dropin"]["vs_headline"] = res["dropin"]["samples_per_s"] / value
     # ---- the batch-over-parameters axis: where Stage K fills the chip
     if world == 1 and not args.no_batch_scaling and args.workload == "c2":
         try:

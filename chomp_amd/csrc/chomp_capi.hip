@@ -133,7 +133,8 @@ struct chomp_ctx {
   size_t cap_cnodes = 0;
   double* d_samples = nullptr;     // coarse samples of the listed knots, a slot each (k_halo_knots_samples -> _fast)
   double* d_psum = nullptr;        // ... and their per-level sums
-  size_t cap_samples = 0, cap_psum = 0;
+  size_t cap_samples = 0, cap_psum = 0, cap_plan = 0;
+  char* d_plan = nullptr;          // per (epoch, group): the break-point plan (DeepPlan; k_halo_knots -> _fast)
   double* d_deepw = nullptr;       // k_halo_knots_fast: level weights (deep_weights_host)
   int* d_deepstat = nullptr;       // k_halo_knots_fast: knots done by the fast / literal path
   size_t cap_slow = 0, cap_winfo = 0, cap_ktab = 0, cap_wnodes = 0;
@@ -513,7 +514,7 @@ void chomp_ctx_destroy(chomp_ctx* ctx) {
                   ctx->d_cand, ctx->d_cosmo, ctx->d_z, ctx->d_epochs, ctx->d_search, ctx->d_probe, ctx->d_count, ctx->d_pending,
                   ctx->d_tab, ctx->d_mass_par, ctx->d_profile, ctx->d_hod, ctx->d_nodes, ctx->d_snodes, ctx->d_slot, ctx->d_first, ctx->d_status, ctx->d_endp, ctx->d_npend,
                   ctx->d_stage_in, ctx->d_stage_in2, ctx->d_stage_out, ctx->d_slow, ctx->d_wnodes, ctx->d_cnodes, ctx->d_deepw, ctx->d_deepstat,
-                  ctx->d_winfo, ctx->d_ktab, ctx->d_samples, ctx->d_psum};
+                  ctx->d_winfo, ctx->d_ktab, ctx->d_samples, ctx->d_psum, ctx->d_plan};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (void* p : ctx->graveyard) (void)hipFree(p);
@@ -831,6 +832,8 @@ static int launch_nu_mass(chomp_ctx* ctx, int mf_kind, const HaloPlan* plan) {
   const int ng = plan && plan->ng > 0 ? plan->ng : 1;
   // (node-table chunks: as many blocks per (epoch, group) as keep the launch under ~2 blocks
   //  per CU -- below that the chip is idle anyway and each block's node loop gets shorter)
+  //  (measured: twice the chunks for the tables that are one level deeper -- 1024 blocks, each
+  //   repeating the mass function part, for 768 resident -- 58 against 37 us on configs[2])
   unsigned chunks = plan ? (unsigned)(512 / (n * ng)) : 1u;
   chunks = chunks < 1 ? 1 : (chunks > 12 ? 12 : chunks);
   hipLaunchKernelGGL(k_mass_nodes, dim3((unsigned)n, (unsigned)ng, chunks), dim3(256), sh, ctx->stream,
@@ -874,17 +877,35 @@ static int launch_halo_knots(chomp_ctx* ctx, const HaloPlan& P) {
     rounds = (int)((worst + slots - 1) / slots);
     int rck = ensure(ctx, &ctx->d_samples, &ctx->cap_samples, slots * (size_t)kDeepSlot);
     if (rck) return rck;
-    rck = ensure(ctx, &ctx->d_psum, &ctx->cap_psum, slots * (size_t)(8 * kDeepPsum));
+    rck = ensure(ctx, &ctx->d_psum, &ctx->cap_psum, slots * (size_t)(kDeepChunks * kDeepPsum));
     if (rck) return rck;
   }
   int hod_cap = ctx->tune[CHOMP_TUNE_HOD_CAP] >= 0 ? (int)ctx->tune[CHOMP_TUNE_HOD_CAP] : kHodCapLevel;
   if (hod_cap < 6) hod_cap = 6;
+  // chomp_set_tuning: the checker (every listed knot by literal evaluation) and the two
+  // thresholds at which a knot leaves the fast path by itself
+  const int all_literal = ctx->tune[CHOMP_TUNE_DEEP_LITERAL] > 0 ? 1 : 0;
+  const double deep_tol = ctx->tune[CHOMP_TUNE_DEEP_TOL] >= 0
+                              ? (double)ctx->tune[CHOMP_TUNE_DEEP_TOL] * 1e-15 : kDeepTol;
+  int max_rough = ctx->tune[CHOMP_TUNE_DEEP_MAX_BREAKS] >= 0 ? (int)ctx->tune[CHOMP_TUNE_DEEP_MAX_BREAKS]
+                                                             : kDeepMaxRough;
+  if (max_rough > kDeepMaxRough) max_rough = kDeepMaxRough;
+  int max_fine = ctx->tune[CHOMP_TUNE_DEEP_MAX_FINE] >= 0 ? (int)ctx->tune[CHOMP_TUNE_DEEP_MAX_FINE]
+                                                          : kDeepMaxFine;
+  if (max_fine > kDeepMaxFine) max_fine = kDeepMaxFine;
+  // (the break-point plans of the (epoch, group)s: an extra block row of k_halo_knots)
+  const int want_plan = deep_route ? 1 : 0;
+  if (want_plan) {
+    const int rcp = ensure(ctx, &ctx->d_plan, &ctx->cap_plan, n * 3 * sizeof(DeepPlan));
+    if (rcp) return rcp;
+  }
 #define CHOMP_KNOTS(KNW)                                                                          \
-  hipLaunchKernelGGL((k_halo_knots<KNW>), dim3((unsigned)n, kb + (P.want_nbar ? 1u : 0u), (unsigned)ng), \
+  hipLaunchKernelGGL((k_halo_knots<KNW>), dim3((unsigned)n, kb + (P.want_nbar ? 1u : 0u) + (unsigned)want_plan, (unsigned)ng), \
                      dim3(KNW == 0 ? 64 : 256), shk, ctx->stream, ctx->cfg, L, ctx->d_epochs, ctx->d_tab,        \
                      ctx->d_profile, ctx->d_hod, ctx->d_sici, ctx->d_nodes, ctx->d_endp,          \
                      P.groups[0], P.groups[1], P.groups[2], P.kmask, P.want_nbar, ctx->d_pending, \
-                     ctx->d_npend, ctx->d_status, hod_cap)
+                     ctx->d_npend, ctx->d_status, hod_cap, want_plan, max_rough, max_fine,           \
+                     reinterpret_cast<DeepPlan*>(ctx->d_plan))
   if (wide) CHOMP_KNOTS(4); else if (lone) CHOMP_KNOTS(0); else CHOMP_KNOTS(1);
 #undef CHOMP_KNOTS
   // blocks 0..n-1 take the epochs' tokens; with integrands that can run beyond the node
@@ -903,23 +924,13 @@ static int launch_halo_knots(chomp_ctx* ctx, const HaloPlan& P) {
   size_t shf = deep_fast_lds<kDeepCoarse>(L.NM, ctx->cfg.divmax);
   if (shf < (size_t)finalize_lds_doubles(L.NK) * sizeof(double))
     shf = (size_t)finalize_lds_doubles(L.NK) * sizeof(double);
-  // chomp_set_tuning: the checker (every listed knot by literal evaluation) and the two
-  // thresholds at which a knot leaves the fast path by itself
-  const int all_literal = ctx->tune[CHOMP_TUNE_DEEP_LITERAL] > 0 ? 1 : 0;
-  const double deep_tol = ctx->tune[CHOMP_TUNE_DEEP_TOL] >= 0
-                              ? (double)ctx->tune[CHOMP_TUNE_DEEP_TOL] * 1e-15 : kDeepTol;
-  int max_rough = ctx->tune[CHOMP_TUNE_DEEP_MAX_BREAKS] >= 0 ? (int)ctx->tune[CHOMP_TUNE_DEEP_MAX_BREAKS]
-                                                             : kDeepMaxRough;
-  if (max_rough > kDeepMaxRough) max_rough = kDeepMaxRough;
-  int max_fine = ctx->tune[CHOMP_TUNE_DEEP_MAX_FINE] >= 0 ? (int)ctx->tune[CHOMP_TUNE_DEEP_MAX_FINE]
-                                                          : kDeepMaxFine;
-  if (max_fine > kDeepMaxFine) max_fine = kDeepMaxFine;
 #define CHOMP_KNOTS_FAST(NT, SELF, EVAL, GRID, ROUND, LO, HI, FROM)                                         \
   hipLaunchKernelGGL((k_halo_knots_fast<kDeepCoarse, NT, SELF, EVAL>), dim3(GRID), dim3(NT), shf, ctx->stream, \
                      ctx->cfg, L, ctx->d_epochs, ctx->d_tab, ctx->d_sici, P.groups[0], P.groups[1], \
                      P.groups[2], P.kmask, (int)n, ctx->d_pending, ctx->d_npend, ctx->d_epochs,     \
                      P.fam, ctx->d_status, ctx->d_deepw, all_literal, deep_tol, max_rough, max_fine, \
-                     ctx->d_deepstat, ctx->d_samples, ctx->d_psum, parts, ROUND, LO, HI, FROM)
+                     ctx->d_deepstat, ctx->d_samples, ctx->d_psum, parts, ROUND, LO, HI, FROM,      \
+                     reinterpret_cast<const DeepPlan*>(ctx->d_plan))
 #define CHOMP_KNOTS_SAMPLES(GRID, LO, HI)                                                        \
   hipLaunchKernelGGL((k_halo_knots_samples<kDeepCoarse>), dim3(GRID), dim3(256), 0, ctx->stream,   \
                      ctx->cfg, L, ctx->d_sici, P.groups[0], P.groups[1], P.groups[2], P.kmask,      \

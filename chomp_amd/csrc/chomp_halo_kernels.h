@@ -290,16 +290,32 @@ __device__ __forceinline__ void halo_node_fields(const Epoch& E, const double* n
   }
   f[0] = wA; f[1] = wB; f[2] = ln_rv - ln_c; f[3] = con; f[4] = ln_cp;
   f[5] = 1.0 / (ln_cp - con / cp); f[6] = (double)state;
+  const double rs = exp(f[2]);
+  f[7] = rs; f[8] = 1.0 / (cp * rs);
 }
 
 // The integrand pair of a knot at one node, from the node's fields (out[0] = wA y,
 // out[1] = wB (flag ? y : y^2), flag = bit 0 of the state; group 2 uses only out[1]).
-__device__ __forceinline__ void node_pair(const SiCiTab& S, double ln_k, bool exclusion,
+// kk: the knot's ln k, k, 1 / k.
+struct KnotK {
+  double ln_k, k, inv_k;
+  __device__ __forceinline__ explicit KnotK(double ln_k_) : ln_k(ln_k_), k(exp(ln_k_)) { inv_k = 1.0 / k; }
+  // the same for a knot that is the whole wavefront's: the three numbers in scalar registers
+  __device__ __forceinline__ static KnotK uniform(double ln_k_) {
+    KnotK r(ln_k_);
+    r.ln_k = readlane_d(r.ln_k, 0);      // (v_readfirstlane-like: every lane holds the same value)
+    r.k = readlane_d(r.k, 0);
+    r.inv_k = readlane_d(r.inv_k, 0);
+    return r;
+  }
+};
+__device__ __forceinline__ void node_pair(const SiCiTab& S, const KnotK& kk, bool exclusion,
                                           double wA, double wB, double ln_rs, double con,
                                           double ln_cp, double inv_mass_k, double state,
-                                          double (&out)[2]) {
+                                          double rs, double inv_cprs, double (&out)[2]) {
   double z;             // k r_s; k * 2 r_v = 2 c z
-  const double y = y_nfw_core(S, ln_k, ln_rs, con, ln_cp, inv_mass_k, &z);
+  const double y = y_nfw_core_tab(S, kk.ln_k, kk.k, kk.inv_k, ln_rs, con, ln_cp, inv_mass_k, rs,
+                                  inv_cprs, &z);
   out[0] = wA * y;
   if (exclusion) out[0] *= exclusion_window(S, 2.0 * con * z);
   out[1] = wB * (((int)state & 1) ? y : y * y);
@@ -349,9 +365,9 @@ __device__ __forceinline__ void halo_nodes_block(const chomp_config& cfg, const 
   double fb[kNodeFields];
   halo_node_fields(E, nu_knots, lnm_pp, L.NM, group, b, fb);   // (every thread: no exchange)
   for (int ik = chunk + n_chunks * rt; ik < L.NK; ik += n_chunks * (int)blockDim.x) {
-    const double ln_k = linspace_at(log(cfg.k_min), log(cfg.k_max), L.NK, ik);
+    const KnotK kk(linspace_at(log(cfg.k_min), log(cfg.k_max), L.NK, ik));
     double o[2];
-    node_pair(S, ln_k, exclusion, fb[0], fb[1], fb[2], fb[3], fb[4], fb[5], fb[6], o);
+    node_pair(S, kk, exclusion, fb[0], fb[1], fb[2], fb[3], fb[4], fb[5], fb[6], fb[7], fb[8], o);
     endp[2 * ik] = o[0];
     endp[2 * ik + 1] = o[1];
   }
@@ -497,233 +513,20 @@ __global__ __launch_bounds__(256) void k_hod_stats(
 struct NodeIntegrand {
   const SiCiTab* sici;
   const double* node;     // this (epoch, group)'s table
-  double ln_k;
+  KnotK kk;
   bool exclusion;         // HaloExclusion (halo.py:1208-1233): window on the 2-halo term
   __device__ __forceinline__ void operator()(double, double (&out)[2], int lev, long j) const {
     const int idx = node_index(lev, j);
     const double* n = node + idx;
-    node_pair(*sici, ln_k, exclusion, n[0], n[kNodeCount], n[2 * kNodeCount], n[3 * kNodeCount],
-              n[4 * kNodeCount], n[5 * kNodeCount], n[6 * kNodeCount], out);
+    node_pair(*sici, kk, exclusion, n[0], n[kNodeCount], n[2 * kNodeCount], n[3 * kNodeCount],
+              n[4 * kNodeCount], n[5 * kNodeCount], n[6 * kNodeCount], n[7 * kNodeCount],
+              n[8 * kNodeCount], out);
   }
 };
 
 __device__ __forceinline__ int group_fa(int group) { return group == 0 ? F_HM : F_HG; }
 __device__ __forceinline__ int group_fb(int group) {
   return group == 0 ? F_PPMM : (group == 1 ? F_PPGM : F_PPGG);
-}
-
-// ---------------------------------------------------------------------------
-// k_halo_knots: grid (n_epoch, ceil(NK / 4) [+ 1], n_groups), block 256 = four wavefronts,
-// each with one knot ln k_i of group groups[blockIdx.z] (0: h_m + pp_mm, 1: h_g + pp_gm,
-// 2: pp_gg): the pair's Romberg on the node table, levels <= kNodeLevel.  The first round
-// fills the wavefront exactly (romberg_wave6: lane p on node p of the level-6 grid, the
-// upper end point from the table halo_nodes_block left), so the four fifths of the knots
-// that scipy stops at level 6 or 7 cost one or two evaluations per lane.  Integrals not
-// converged at the depth of the node table are listed for k_halo_knots_fast (pending[];
-// npend[e] counts an epoch's listed knots on top of its token).  A block only stages the
-// Si/Ci tables: everything else it needs is in the (epoch, group) node table.
-// With want_nbar the extra y-block of z == 0 does the epoch's n_bar integral
-// (halo.py:674-700) beside the knots.
-// The epochs are the FASTEST grid axis: blocks are dispatched in linear order, a (k, z) grid's
-// launch is 900 blocks for 512-768 resident ones, and with the epochs slowest the last epochs'
-// deepest knots entered the chip 11-15 us into the launch (tools/dev_knots_stamps2.py).
-// KNW = 1 (a batch of a few dozen epochs): four knots to a block up to level 7, then the
-// block's knots that go on are walked by all four wavefronts together (below), capped at three
-// wavefronts per SIMD (168 registers, 4 spills: every block of a 64-epoch launch but the last
-// 128 is resident at once).  37.9 -> 29.6 us per configs[1] launch.
-// KNW = 4 (a whole block per knot pair, grid y = NK [+ 1]): for a set-up of one or a few epochs,
-// whose launch lasts as long as its slowest knot -- 1, 1, 2, 4, 8 NFW transforms per lane at
-// levels 6..10 on one wavefront, 1, 1, 1, 1, 2 on four.
-// ---------------------------------------------------------------------------
-// KNW = 0: one wavefront per knot pair AND per block (64 threads): a finished knot frees its
-// slot for the next block at once, instead of idling beside the one slow knot of its four
-// (from ~80 epochs x 50 knots on, and for the two-group HOD set-ups).
-template <int KNW>
-__global__ __launch_bounds__(KNW == 0 ? 64 : 256, KNW == 1 ? 3 : 1) void k_halo_knots(
-    chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs, double* __restrict__ tab,
-    const chomp_halo_par* __restrict__ profile, const HodDev* __restrict__ hod,
-    const SiCiTab* __restrict__ sici_g, const double* __restrict__ nodes,
-    const double* __restrict__ endp, int g0, int g1, int g2, unsigned mask, int want_nbar,
-    int* __restrict__ pending, int* __restrict__ npend, unsigned* __restrict__ status,
-    int hod_cap) {
-  extern __shared__ __align__(16) double sm[];
-  __shared__ SiCiTab S;
-  __shared__ Epoch E;              // (the n_bar block only)
-  const int NK = L.NK;
-  const int e = blockIdx.x, n_epoch = (int)gridDim.x;
-  const int kb = KNW == 1 ? (NK + 3) / 4 : NK;     // knot blocks
-  KNSTAMP(0, __builtin_amdgcn_s_memrealtime());
-  // Blocks are dispatched x (the epochs) fastest, z slowest: the long units of EVERY epoch first
-  // -- the n_bar integrals, the highest k (the deepest Romberg), the HOD groups (plan slots 1, 2)
-  // before the smooth one -- so that the launch ends with the knots that stop at level 6.
-  const int bx = (int)gridDim.y - 1 - (int)blockIdx.y, bz = (int)gridDim.z - 1 - (int)blockIdx.z;
-  if (bx >= kb) {                  // ---- n_bar
-    if (!want_nbar || bz != 0) return;
-    HaloLds H;
-    H.stage(L, E, S, epochs, e, tab + (size_t)e * L.stride, profile, hod, sici_g, sm);
-    HaloCtx c{&E, &S, H.nu_knots, H.lnm_pp, L.NM, 0.0, false};
-    IntegrandNbar f{c};
-    const double v = romberg1<(KNW == 0 ? 1 : 4)>(f, E.ln_nu_lo_first, log(E.nu_max),
-                                                  cfg.global_precision, cfg.halo_precision,
-                                                  cfg.divmax, H.rest);
-    if (threadIdx.x == 0) tab[(size_t)e * L.stride + L.off_misc] = v;
-    return;
-  }
-  const int group = bz == 0 ? g0 : (bz == 1 ? g1 : g2);
-  if (group < 0 || group > 2) return;
-  copy_doubles(reinterpret_cast<double*>(&S), reinterpret_cast<const double*>(sici_g),
-               (int)(sizeof(SiCiTab) / sizeof(double)));
-  __syncthreads();
-  constexpr bool kCoop = KNW == 1;
-  // KNW = 1 with the cooperative tail (below): wavefront w of block bx takes knot bx + kb w --
-  // the knots that run deep are the highest k, and this way a block holds one of them at most
-  const int ik = KNW == 1 ? (kCoop ? bx + kb * (int)(threadIdx.x >> 6) : bx * 4 + (int)(threadIdx.x >> 6)) : bx;
-  KNSTAMP(1, __builtin_amdgcn_s_memrealtime());
-  const bool have = ik < NK;
-  if (!kCoop && !have) return;     // (no barrier below unless kCoop: the wavefronts are independent)
-  const double* node = nodes + ((size_t)e * 3 + group) * kNodeStride;
-  const double a = node[kNodeFields * kNodeCount], b = node[kNodeFields * kNodeCount + 1];
-  const double* ep = endp + ((size_t)e * 3 + group) * 2 * NK + 2 * (have ? ik : 0);
-  const double fb[2] = {ep[0], ep[1]};
-  double* t = tab + (size_t)e * L.stride;
-  const double ln_k0 = log(cfg.k_min), ln_k1 = log(cfg.k_max);
-  const double ln_k = linspace_at(ln_k0, ln_k1, NK, have ? ik : 0);          // halo.py:52-54
-  const bool exclusion = (mask & kMaskExclusion) != 0;
-  NodeIntegrand f{&S, node, ln_k, exclusion};
-  // How deep a knot walks the node table here.  The HOD groups' knots that do not converge
-  // within the table are listed for k_halo_knots_fast, whose sampling launch evaluates every
-  // node of the table for them anyway: what such a knot sums here beyond level hod_cap is
-  // done twice (at the default HOD the pairs either stop at levels 8-9 or run to 11..20, so
-  // level 10 -- half the table's nodes, on one wavefront -- is evaluated for the listed only).
-  const int top = (group > 0 && (mask & kMaskDeepNodes) && hod_cap < kNodeLevel) ? hod_cap : kNodeLevel;
-  const int dmax = cfg.divmax < top ? cfg.divmax : top;
-  RombergOut<2> r;
-  if constexpr (kCoop) {
-    // Four knots to a block, one per wavefront, up to level kCoopLevel (four fifths of the
-    // knots stop there: one or two NFW transforms per lane).  The tail -- the one knot in ten
-    // that goes on to levels 8..10, another 2 + 4 + 8 transforms per lane on its own wavefront,
-    // which is what the launch lasted -- is then walked by the WHOLE block, knot after knot
-    // (RombergResume from the state the wavefront left: 1 + 1 + 2 transforms per thread).
-    constexpr int kCoopLevel = 7;
-    __shared__ double co_dump[4][2 * kRombergDump];
-    __shared__ double co_val[4][2];
-    __shared__ int co_lev[4][2], co_conv[4][2], co_need[4];
-    const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
-    const bool coop = dmax > kCoopLevel;
-    r.value[0] = r.value[1] = 0.0;
-    r.level[0] = r.level[1] = 0;
-    r.converged[0] = r.converged[1] = true;
-    if (have) {
-      if (dmax >= 6)
-        r = romberg_wave6<2>(f, a, b, fb, cfg.global_precision, cfg.halo_precision,
-                             coop ? kCoopLevel : dmax, co_dump[wave]);
-      else
-        r = romberg_group<1, 2>(f, a, b, cfg.global_precision, cfg.halo_precision, dmax, nullptr);
-    }
-    if (lane == 0) {
-      co_need[wave] = (have && coop && !(r.converged[0] && r.converged[1])) ? 1 : 0;
-      co_val[wave][0] = r.value[0]; co_val[wave][1] = r.value[1];
-      co_lev[wave][0] = r.level[0]; co_lev[wave][1] = r.level[1];
-      co_conv[wave][0] = r.converged[0] ? 1 : 0; co_conv[wave][1] = r.converged[1] ? 1 : 0;
-    }
-    __syncthreads();
-    for (int w = 0; w < 4; ++w) {
-      if (!co_need[w]) continue;                 // (block-uniform)
-      const int ikw = bx + kb * w;
-      NodeIntegrand fw{&S, node, linspace_at(ln_k0, ln_k1, NK, ikw), exclusion};
-      RombergResume R[2];
-      bool dn[2];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        R[q].load(co_dump[w] + q * kRombergDump, kCoopLevel, b - a, cfg.global_precision,
-                  cfg.halo_precision);
-        R[q].value = co_val[w][q];
-        R[q].level = co_lev[w][q];
-        dn[q] = co_conv[w][q] != 0;
-      }
-      bool all = dn[0] && dn[1];
-      int flip = 0;
-      for (int i = kCoopLevel + 1; i <= dmax && !all; ++i) {
-        const double c_il = CHOMP_ROMBERG_C[i][lane & 31];
-        const long numtosum = 1L << (i - 1);
-        const double h = (b - a) / (double)numtosum;
-        const double lox = a + 0.5 * h;
-        double part[2] = {0.0, 0.0};
-        for (long j = threadIdx.x; j < numtosum; j += 256) {
-          double v[2];
-          fw(lox + h * (double)j, v, i, j);
-          part[0] += v[0];
-          part[1] += v[1];
-        }
-        all = true;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const double Sq = group_sum<4>(part[q], sm, flip);
-          if (!dn[q]) {
-            R[q].advance(i, Sq, c_il);
-            dn[q] = R[q].done;
-          }
-          all = all && dn[q];
-        }
-      }
-      __syncthreads();                            // (sm: the last sums have been read)
-      if (threadIdx.x == 0) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          co_val[w][q] = R[q].value;
-          co_lev[w][q] = R[q].level;
-          co_conv[w][q] = dn[q] ? 1 : 0;
-        }
-      }
-    }
-    __syncthreads();
-    if (!have) return;
-    r.value[0] = co_val[wave][0]; r.value[1] = co_val[wave][1];
-    r.level[0] = co_lev[wave][0]; r.level[1] = co_lev[wave][1];
-    r.converged[0] = co_conv[wave][0] != 0; r.converged[1] = co_conv[wave][1] != 0;
-  } else if constexpr (KNW <= 1) {
-    if (dmax >= 6)
-      r = romberg_wave6<2>(f, a, b, fb, cfg.global_precision, cfg.halo_precision, dmax);
-    else
-      r = romberg_group<1, 2>(f, a, b, cfg.global_precision, cfg.halo_precision, dmax, nullptr);
-  } else {
-    (void)fb;
-    r = romberg_group<KNW, 2>(f, a, b, cfg.global_precision, cfg.halo_precision, dmax, sm);
-  }
-  KNSTAMP(2, __builtin_amdgcn_s_memrealtime());
-  KNSTAMP(3, (r.level[0] > r.level[1] ? r.level[0] : r.level[1]) + 100 * ik);
-  if ((KNW <= 1 ? (threadIdx.x & 63) : threadIdx.x) == 0) {
-    double* lev = t + L.off_levels;
-    const int fa = group_fa(group), fb_ = group_fb(group);
-    const bool more = cfg.divmax > top;
-    if (group != 2 && (mask & (1u << fa))) {
-      t[L.off_knot[fa] + ik] = r.value[0];
-      lev[fa * NK + ik] = (!r.converged[0] && more) ? kPendingLevel : (double)r.level[0];
-    }
-    bool any = false;
-    if (group != 2 && (mask & (1u << fa))) any = any || (!r.converged[0] && more);
-    if (mask & (1u << fb_)) {
-      t[L.off_knot[fb_] + ik] = r.value[1];
-      lev[fb_ * NK + ik] = (!r.converged[1] && more) ? kPendingLevel : (double)r.level[1];
-      any = any || (!r.converged[1] && more);
-    }
-    // divmax within the node tables: scipy returns the last row with an AccuracyWarning
-    if (!more) {
-      unsigned st = 0u;
-      if (group != 2 && (mask & (1u << fa)) && !r.converged[0]) st |= kStHaloDivmax0 << fa;
-      if ((mask & (1u << fb_)) && !r.converged[1]) st |= kStHaloDivmax0 << fb_;
-      if (st) atomicOr(&status[e], st);
-    }
-    // work list of k_halo_knots_fast (layout at kPendingHead): the deepest-running knots --
-    // the highest k -- at the front, the rest from the back of the buffer downwards
-    if (any) {
-      atomicAdd(&npend[e], 1);
-      const int item = (int)((bz * n_epoch + e) * NK + ik);
-      const int cap = 3 * n_epoch * NK;
-      if (4 * ik >= 3 * NK) pending[kPendingHead + atomicAdd(&pending[0], 1)] = item;
-      else pending[kPendingHead + cap - 1 - atomicAdd(&pending[2], 1)] = item;
-    }
-  }
 }
 
 // ---------------------------------------------------------------------------
@@ -962,6 +765,64 @@ struct RombergRows2 {
     }
   }
   __device__ __forceinline__ bool all_done() const { return done[0] && done[1]; }
+  // start() and advance(1 .. LC) in one go, from the sums of levels 1..LC (ls0 / ls1[l], LDS):
+  // lane l forms T_l from the running sum, the LC extrapolations R[i][i] are taken back to
+  // back (they do not depend on each other -- advance()'s loop waits for a butterfly per
+  // level), and only the stopping test walks through them in order.  Same operations on the
+  // same operands as the loop: identical values, levels and flags.
+  template <int LC>
+  __device__ __forceinline__ void start_levels(double range_, double tol_, double rtol_, double e0,
+                                               double e1, const double* ls0, const double* ls1,
+                                               bool want0, bool want1) {
+    range = range_; tol = tol_; rtol = rtol_;
+    const int lane = threadIdx.x & 63;
+    const double* ls[2] = {ls0, ls1};
+    const double send[2] = {e0, e1};
+    const bool want[2] = {want0, want1};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      double os = send[q], mine = send[q], pw = 1.0, mypw = 1.0;
+#pragma unroll
+      for (int l = 1; l <= LC; ++l) {
+        os += ls[q][l];
+        pw *= 2.0;
+        if (l <= lane) { mine = os; mypw = pw; }
+      }
+      const double T = lane <= LC ? range * mine / mypw : 0.0;
+      double cur[LC + 1];
+      cur[0] = range * send[q];
+#pragma unroll
+      for (int i = 1; i <= LC; ++i) {
+        const double c_il = ctab != nullptr ? ctab[i * 32 + (lane & 31)] : CHOMP_ROMBERG_C[i][lane & 31];
+        cur[i] = wave_sum(lane <= i ? c_il * T : 0.0);
+      }
+      done[q] = !want[q];
+      level[q] = 0;
+      value[q] = cur[0];
+      prev[q] = cur[0];
+      int stop = LC;
+      if (!done[q]) {
+#pragma unroll
+        for (int i = 1; i <= LC; ++i) {
+          if (!done[q]) {
+            const double err = fabs(cur[i] - prev[q]);
+            prev[q] = cur[i];
+            value[q] = cur[i];
+            level[q] = i;
+            if (err < tol || err < rtol * fabs(cur[i])) { done[q] = true; stop = i; }
+          }
+        }
+      }
+      // (the state advance() would have left: the sums and T_l up to the level reached)
+      double upto = send[q];
+#pragma unroll
+      for (int l = 1; l <= LC; ++l)
+        if (l <= stop) upto += ls[q][l];
+      ordsum[q] = upto;
+      Tl[q] = lane <= stop ? T : 0.0;
+    }
+    n = (double)(1 << LC);
+  }
   // The state out of the registers across a phase that needs them (the node-by-node loop of a
   // deep round): every lane of every wavefront holds the same state but for Tl, which is
   // distributed over the lanes -- wavefront 0 writes, and behind a barrier everyone reads back.
@@ -1052,11 +913,442 @@ __device__ __forceinline__ double deep_coarse_x(double a, double b, int q) {
 }
 
 // ---------------------------------------------------------------------------
+// The break-point structure of an (epoch, group)'s integrands along ln nu: NOTHING of it depends
+// on k -- where the discrete state changes between coarse nodes, which intervals are therefore
+// evaluated node by node, the smooth segments between them, and, inside a break-point interval,
+// the exact abscissa at which the state changes.  It is built once per (epoch, group) by an
+// extra block of k_halo_knots (deep_plan_block), beside the knots' Romberg, and the ~15 listed
+// knots of the group read it instead of each deriving it again (7.5 of a knot's 33 us), and
+// instead of deciding the state of every node of a break-point interval by evaluating the HOD
+// there (half of a deep round's time, and the reason the kernel carried the mass spline).
+//   tstar: the nodes of ALL Romberg levels LC + 1 .. divmax inside a coarse interval are the
+//   interior points t = 1 .. 2^D - 1 (D = divmax - LC) of its uniform grid of 2^D parts -- level
+//   LC + d holds the odd multiples of 2^(D - d).  The state is the interval's left one for
+//   t < tstar and its right one from tstar on.  Found by section search with the device's own
+//   halo_state_at AT THOSE NODES' ABSCISSAE (scipy's node formula of the node's level): every
+//   node the search probed is classified exactly as evaluating it would; between probes
+//   monotonicity is assumed (the states are thresholds of monotone functions of the mass:
+//   N < 1, M > M_0), which the search verifies at every round (a probe out of order, or in a
+//   third state -- two breaks in one interval -- marks the interval "evaluate node by node").
+// ---------------------------------------------------------------------------
+struct DeepPlan {
+  double a, b;                         // the integration range (as the node table has it)
+  int tstar[kDeepMaxFine];             // per node-by-node interval (where geom says so)
+  int flag;                            // 0: fine; 1: too many break points; 2: too many intervals
+  int n_fine, n_seg, n_rough;
+  int fine[kDeepMaxFine];              // node-by-node intervals, ascending
+  int seg_lo[kDeepMaxRough + 1], seg_hi[kDeepMaxRough + 1];   // smooth segments (node ranges)
+  unsigned char states[kDeepMaxFine];  // states of an interval's end nodes (low / high nibble)
+  unsigned char geom[kDeepMaxFine];    // 1: both neighbours are smooth segments of >= 8 intervals,
+                                       //    the states differ and tstar is valid
+};
+static_assert(sizeof(DeepPlan) % sizeof(double) == 0, "DeepPlan is copied as doubles");
+constexpr int kDeepPlanDoubles = (int)(sizeof(DeepPlan) / sizeof(double));
+
+// LDS of the builder (static, in k_halo_knots).
+template <int LC>
+struct DeepPlanLds {
+  DeepPlan P;
+  unsigned char code[((1 << LC) + 1 + 15) & ~15];
+  int rough[kDeepMaxRough];
+  int n_rough;
+  unsigned long long m0[4], m1[4], m2[4];    // per wavefront: probes in the left / right / a third state
+};
+
+// Whole block (64 or 256 threads).  E, nu_knots, lnm_pp: the epoch's record and ln M(nu) spline
+// in LDS; nd: the (epoch, group) node table, complete (the previous launch wrote it).
+template <int LC>
+__device__ __forceinline__ void deep_plan_block(const Epoch& E, const double* nu_knots,
+                                                const double* lnm_pp, int NM, int group,
+                                                const double* __restrict__ nd, int max_rough,
+                                                int max_fine, int divmax, DeepPlanLds<LC>& W,
+                                                DeepPlan* __restrict__ out) {
+  constexpr int NC = 1 << LC;
+  const int tid = threadIdx.x, NT = blockDim.x, wv = tid >> 6, nwv = NT >> 6;
+  DeepPlan& P = W.P;
+  unsigned char* code = W.code;
+  const double a = nd[kNodeFields * kNodeCount], b = nd[kNodeFields * kNodeCount + 1];
+  // ---- the states of the coarse nodes, in position order
+  for (int q = tid; q <= NC; q += NT) {
+    int idx = q == NC ? 1 : 0;
+    if (q != 0 && q != NC) {
+      const int tz = __builtin_ctz((unsigned)q);
+      idx = 1 + (1 << (LC - tz - 1)) + (q >> (tz + 1));
+    }
+    code[q] = (unsigned char)(int)nd[6 * kNodeCount + idx];
+  }
+  if (tid == 0) { W.n_rough = 0; P.a = a; P.b = b; P.flag = 0; P.n_fine = 0; P.n_seg = 0; }
+  __syncthreads();
+  // ---- break points: coarse intervals whose ends are in different states
+  for (int i = tid; i < NC; i += NT)
+    if (code[i] != code[i + 1]) {
+      const int at = atomicAdd(&W.n_rough, 1);
+      if (at < kDeepMaxRough) W.rough[at] = i;
+    }
+  __syncthreads();
+  const int nr = W.n_rough;
+  if (nr > max_rough) {                                        // block-uniform
+    if (tid == 0) { P.flag = 1; P.n_rough = nr; }
+    __syncthreads();
+    copy_doubles(reinterpret_cast<double*>(out), reinterpret_cast<const double*>(&P), kDeepPlanDoubles);
+    return;
+  }
+  if (tid == 0) {
+    // node-by-node intervals: the break points, and above one where the satellites switch on
+    // a margin in which (M - M_0)^alpha is still too singular to interpolate
+    int nf = 0;
+    bool over = false;
+    // (pp_gg starts AT M_0 when that lies inside the mass range, halo.py:1002-1006: the same
+    //  singular onset, with no change of state to announce it)
+    // (alpha = 1: N_sat is linear in M - M_0 -- a kink, smooth on either side: no margin)
+    const bool singular_onset = E.hod_alpha != 1.0;
+    if (singular_onset && group == 2 && E.ln_nu_lo_second > log(E.nu_min))
+      for (int d = 0; d <= kDeepKinkMargin; ++d) P.fine[nf++] = d;
+    for (int x = 0; x < nr; ++x) {
+      const int i = W.rough[x];
+      const int span = (((code[i] ^ code[i + 1]) & 2) && singular_onset) ? kDeepKinkMargin : 0;
+      for (int d = 0; d <= span && i + d < NC; ++d) {
+        if (nf < kDeepMaxFine) P.fine[nf++] = i + d; else over = true;
+      }
+    }
+    for (int x = 1; x < nf; ++x) {                             // insertion sort
+      const int v = P.fine[x];
+      int y = x - 1;
+      while (y >= 0 && P.fine[y] > v) { P.fine[y + 1] = P.fine[y]; --y; }
+      P.fine[y + 1] = v;
+    }
+    int nu = 0;                                                // unique
+    for (int x = 0; x < nf; ++x)
+      if (x == 0 || P.fine[x] != P.fine[x - 1]) P.fine[nu++] = P.fine[x];
+    // smooth segments between them (node ranges); one shorter than a stencil is evaluated
+    // node by node as well
+    int ns = 0, lo = 0, extra = nu;
+    for (int x = 0; x <= nu; ++x) {
+      const int hi = x < nu ? P.fine[x] : NC;                  // last node of the segment
+      if (hi - lo + 1 >= kDeepStencil) {
+        if (ns <= kDeepMaxRough) { P.seg_lo[ns] = lo; P.seg_hi[ns] = hi; ++ns; } else over = true;
+      } else {
+        for (int i = lo; i < hi; ++i) {
+          if (extra < kDeepMaxFine) P.fine[extra++] = i; else over = true;
+        }
+      }
+      lo = hi + 1;
+    }
+    P.n_rough = nr;
+    P.n_seg = ns;
+    if (over || extra > max_fine) { P.flag = 2; P.n_fine = 0; } else P.n_fine = extra;
+  }
+  __syncthreads();
+  if (P.flag) {                                                // block-uniform
+    copy_doubles(reinterpret_cast<double*>(out), reinterpret_cast<const double*>(&P), kDeepPlanDoubles);
+    return;
+  }
+  const int nf = P.n_fine, ns = P.n_seg;
+  if (tid < nf) {
+    const int i = P.fine[tid];
+    const int sl = code[i] & 15, sr = code[i + 1] & 15;
+    P.states[tid] = (unsigned char)(sl | (sr << 4));
+    // the geometry a continuation needs: a smooth segment of >= 8 intervals ends at i, another
+    // begins at i + 1, and the two end states differ
+    int seg_l = -1, seg_r = -1;
+    for (int x = 0; x < ns; ++x) {
+      if (P.seg_hi[x] == i) seg_l = x;
+      if (P.seg_lo[x] == i + 1) seg_r = x;
+    }
+    bool ok = i > 0 && i < NC - 1 && seg_l >= 0 && seg_r >= 0 && sl != sr;
+    if (ok) ok = i - P.seg_lo[seg_l] >= 8 && P.seg_hi[seg_r] - (i + 1) >= 8;
+    P.geom[tid] = ok ? 1 : 0;
+    P.tstar[tid] = 0;
+  }
+  __syncthreads();
+  // ---- where inside such an interval the state changes: NT-way section search over the
+  // interval's 2^D - 1 interior nodes (see DeepPlan), one interval after the other
+  HaloCtx c{&E, nullptr, nu_knots, lnm_pp, NM, 0.0, false};
+  const int D = divmax - LC;                                   // (1 .. kMaxDivmax - LC)
+  for (int x = 0; x < nf; ++x) {
+    if (!P.geom[x]) continue;                                  // block-uniform
+    const int iv = P.fine[x];
+    const int sl = P.states[x] & 15, sr = P.states[x] >> 4;
+    int lo = 0, hi = 1 << D;                                   // state(lo) = sl, state(hi) = sr
+    bool bad = false;
+    while (hi - lo > 1) {
+      // probes lo + step, lo + 2 step, ... < hi
+      const int span = hi - lo;
+      int step = (span + NT) / (NT + 1);
+      if (step < 1) step = 1;
+      const int tp = lo + step * (tid + 1);
+      const bool valid = tp < hi;
+      int cls = -1;
+      if (valid) {
+        // node tp of the interval: level LC + d with 2^(D - d) the largest power of two in tp
+        const int tz = __builtin_ctz((unsigned)tp);
+        const int lev = LC + D - tz;                           // (tz < D: tp is interior)
+        const long j = ((long)iv << (lev - 1 - LC)) + (long)(tp >> (tz + 1));
+        const double h = (b - a) / (double)(1L << (lev - 1));
+        const double px = (a + 0.5 * h) + h * (double)j;
+        const int st = halo_state_at(group, c, px);
+        cls = st == sl ? 0 : (st == sr ? 1 : 2);
+      }
+      const unsigned long long b0 = __ballot(cls == 0), b1 = __ballot(cls == 1), b2 = __ballot(cls == 2);
+      if ((tid & 63) == 0) { W.m0[wv] = b0; W.m1[wv] = b1; W.m2[wv] = b2; }
+      __syncthreads();
+      // (every thread: the same scan over the wavefronts' masks)
+      int first1 = -1, last0 = -1;
+      bool third = false;
+      for (int w2 = 0; w2 < nwv; ++w2) {
+        const unsigned long long q0 = W.m0[w2], q1 = W.m1[w2], q2 = W.m2[w2];
+        third = third || q2 != 0ull;
+        if (q1 != 0ull && first1 < 0) first1 = 64 * w2 + __builtin_ctzll(q1);
+        if (q0 != 0ull) last0 = 64 * w2 + 63 - __builtin_clzll(q0);
+      }
+      __syncthreads();                                         // (the masks are re-written next round)
+      if (third || (first1 >= 0 && last0 > first1)) { bad = true; break; }
+      const int nlo = last0 >= 0 ? lo + step * (last0 + 1) : lo;
+      const int nhi = first1 >= 0 ? lo + step * (first1 + 1) : hi;
+      lo = nlo;
+      hi = nhi;
+    }
+    if (tid == 0) {
+      if (bad) P.geom[x] = 0; else P.tstar[x] = hi;
+    }
+  }
+  __syncthreads();
+  copy_doubles(reinterpret_cast<double*>(out), reinterpret_cast<const double*>(&P), kDeepPlanDoubles);
+}
+
+// ---------------------------------------------------------------------------
+// k_halo_knots: grid (n_epoch, ceil(NK / 4) [+ 1], n_groups), block 256 = four wavefronts,
+// each with one knot ln k_i of group groups[blockIdx.z] (0: h_m + pp_mm, 1: h_g + pp_gm,
+// 2: pp_gg): the pair's Romberg on the node table, levels <= kNodeLevel.  The first round
+// fills the wavefront exactly (romberg_wave6: lane p on node p of the level-6 grid, the
+// upper end point from the table halo_nodes_block left), so the four fifths of the knots
+// that scipy stops at level 6 or 7 cost one or two evaluations per lane.  Integrals not
+// converged at the depth of the node table are listed for k_halo_knots_fast (pending[];
+// npend[e] counts an epoch's listed knots on top of its token).  A block only stages the
+// Si/Ci tables: everything else it needs is in the (epoch, group) node table.
+// With want_nbar the extra y-block of z == 0 does the epoch's n_bar integral
+// (halo.py:674-700) beside the knots; with want_plan a further extra y-block of every z builds
+// the break-point plan of its (epoch, group) for k_halo_knots_fast (DeepPlan).
+// The epochs are the FASTEST grid axis: blocks are dispatched in linear order, a (k, z) grid's
+// launch is 900 blocks for 512-768 resident ones, and with the epochs slowest the last epochs'
+// deepest knots entered the chip 11-15 us into the launch (tools/dev_knots_stamps2.py).
+// KNW = 1 (a batch of a few dozen epochs): four knots to a block up to level 7, then the
+// block's knots that go on are walked by all four wavefronts together (below), capped at three
+// wavefronts per SIMD (168 registers, 4 spills: every block of a 64-epoch launch but the last
+// 128 is resident at once).  37.9 -> 29.6 us per configs[1] launch.
+// KNW = 4 (a whole block per knot pair, grid y = NK [+ 1]): for a set-up of one or a few epochs,
+// whose launch lasts as long as its slowest knot -- 1, 1, 2, 4, 8 NFW transforms per lane at
+// levels 6..10 on one wavefront, 1, 1, 1, 1, 2 on four.
+// ---------------------------------------------------------------------------
+// KNW = 0: one wavefront per knot pair AND per block (64 threads): a finished knot frees its
+// slot for the next block at once, instead of idling beside the one slow knot of its four
+// (from ~80 epochs x 50 knots on, and for the two-group HOD set-ups).
+template <int KNW>
+__global__ __launch_bounds__(KNW == 0 ? 64 : 256, KNW == 1 ? 3 : 1) void k_halo_knots(
+    chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs, double* __restrict__ tab,
+    const chomp_halo_par* __restrict__ profile, const HodDev* __restrict__ hod,
+    const SiCiTab* __restrict__ sici_g, const double* __restrict__ nodes,
+    const double* __restrict__ endp, int g0, int g1, int g2, unsigned mask, int want_nbar,
+    int* __restrict__ pending, int* __restrict__ npend, unsigned* __restrict__ status,
+    int hod_cap, int want_plan, int max_rough, int max_fine, DeepPlan* __restrict__ plans) {
+  extern __shared__ __align__(16) double sm[];
+  __shared__ SiCiTab S;
+  __shared__ Epoch E;              // (the extra blocks only)
+  const int NK = L.NK;
+  const int e = blockIdx.x, n_epoch = (int)gridDim.x;
+  const int kb = KNW == 1 ? (NK + 3) / 4 : NK;     // knot blocks
+  KNSTAMP(0, __builtin_amdgcn_s_memrealtime());
+  // Blocks are dispatched x (the epochs) fastest, z slowest: the long units of EVERY epoch first
+  // -- the n_bar integrals, the highest k (the deepest Romberg), the HOD groups (plan slots 1, 2)
+  // before the smooth one -- so that the launch ends with the knots that stop at level 6.
+  const int bx = (int)gridDim.y - 1 - (int)blockIdx.y, bz = (int)gridDim.z - 1 - (int)blockIdx.z;
+  if (bx >= kb) {                  // ---- the extra blocks: n_bar, the groups' break-point plans
+    const int ex = bx - kb;
+    const int gx = bz == 0 ? g0 : (bz == 1 ? g1 : g2);
+    const bool nbar_block = want_nbar && ex == 0 && bz == 0;
+    const bool plan_block = want_plan && ex == (want_nbar ? 1 : 0) && gx >= 0 && gx <= 2;
+    if (!nbar_block && !plan_block) return;
+    HaloLds H;
+    H.stage(L, E, S, epochs, e, tab + (size_t)e * L.stride, profile, hod, sici_g, sm);
+    if (nbar_block) {
+      HaloCtx c{&E, &S, H.nu_knots, H.lnm_pp, L.NM, 0.0, false};
+      IntegrandNbar f{c};
+      const double v = romberg1<(KNW == 0 ? 1 : 4)>(f, E.ln_nu_lo_first, log(E.nu_max),
+                                                    cfg.global_precision, cfg.halo_precision,
+                                                    cfg.divmax, H.rest);
+      if (threadIdx.x == 0) tab[(size_t)e * L.stride + L.off_misc] = v;
+      return;
+    }
+    // (what the listed knots of (e, gx) share: see DeepPlan)
+    __shared__ DeepPlanLds<kNodeTabLevel> plan_lds;
+    deep_plan_block<kNodeTabLevel>(E, H.nu_knots, H.lnm_pp, L.NM, gx,
+                                   nodes + ((size_t)e * 3 + gx) * kNodeStride, max_rough, max_fine,
+                                   cfg.divmax, plan_lds, plans + (size_t)e * 3 + gx);
+    return;
+  }
+  const int group = bz == 0 ? g0 : (bz == 1 ? g1 : g2);
+  if (group < 0 || group > 2) return;
+  copy_doubles(reinterpret_cast<double*>(&S), reinterpret_cast<const double*>(sici_g),
+               (int)(sizeof(SiCiTab) / sizeof(double)));
+  __syncthreads();
+  constexpr bool kCoop = KNW == 1;
+  // KNW = 1 with the cooperative tail (below): wavefront w of block bx takes knot bx + kb w --
+  // the knots that run deep are the highest k, and this way a block holds one of them at most
+  const int ik = KNW == 1 ? (kCoop ? bx + kb * (int)(threadIdx.x >> 6) : bx * 4 + (int)(threadIdx.x >> 6)) : bx;
+  KNSTAMP(1, __builtin_amdgcn_s_memrealtime());
+  const bool have = ik < NK;
+  if (!kCoop && !have) return;     // (no barrier below unless kCoop: the wavefronts are independent)
+  const double* node = nodes + ((size_t)e * 3 + group) * kNodeStride;
+  const double a = node[kNodeFields * kNodeCount], b = node[kNodeFields * kNodeCount + 1];
+  const double* ep = endp + ((size_t)e * 3 + group) * 2 * NK + 2 * (have ? ik : 0);
+  const double fb[2] = {ep[0], ep[1]};
+  double* t = tab + (size_t)e * L.stride;
+  const double ln_k0 = log(cfg.k_min), ln_k1 = log(cfg.k_max);
+  const double ln_k = linspace_at(ln_k0, ln_k1, NK, have ? ik : 0);          // halo.py:52-54
+  const bool exclusion = (mask & kMaskExclusion) != 0;
+  NodeIntegrand f{&S, node, KnotK::uniform(ln_k), exclusion};
+  // How deep a knot walks the node table here.  The HOD groups' knots that do not converge
+  // within the table are listed for k_halo_knots_fast, whose sampling launch evaluates every
+  // node of the table for them anyway: what such a knot sums here beyond level hod_cap is
+  // done twice (at the default HOD the pairs either stop at levels 8-9 or run to 11..20, so
+  // level 10 -- half the table's nodes, on one wavefront -- is evaluated for the listed only).
+  const int top = (group > 0 && (mask & kMaskDeepNodes) && hod_cap < kNodeLevel) ? hod_cap : kNodeLevel;
+  const int dmax = cfg.divmax < top ? cfg.divmax : top;
+  RombergOut<2> r;
+  if constexpr (kCoop) {
+    // Four knots to a block, one per wavefront, up to level kCoopLevel (four fifths of the
+    // knots stop there: one or two NFW transforms per lane).  The tail -- the one knot in ten
+    // that goes on to levels 8..10, another 2 + 4 + 8 transforms per lane on its own wavefront,
+    // which is what the launch lasted -- is then walked by the WHOLE block, knot after knot
+    // (RombergResume from the state the wavefront left: 1 + 1 + 2 transforms per thread).
+    constexpr int kCoopLevel = 7;
+    __shared__ double co_dump[4][2 * kRombergDump];
+    __shared__ double co_val[4][2];
+    __shared__ int co_lev[4][2], co_conv[4][2], co_need[4];
+    const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    const bool coop = dmax > kCoopLevel;
+    r.value[0] = r.value[1] = 0.0;
+    r.level[0] = r.level[1] = 0;
+    r.converged[0] = r.converged[1] = true;
+    if (have) {
+      if (dmax >= 6)
+        r = romberg_wave6<2>(f, a, b, fb, cfg.global_precision, cfg.halo_precision,
+                             coop ? kCoopLevel : dmax, co_dump[wave]);
+      else
+        r = romberg_group<1, 2>(f, a, b, cfg.global_precision, cfg.halo_precision, dmax, nullptr);
+    }
+    if (lane == 0) {
+      co_need[wave] = (have && coop && !(r.converged[0] && r.converged[1])) ? 1 : 0;
+      co_val[wave][0] = r.value[0]; co_val[wave][1] = r.value[1];
+      co_lev[wave][0] = r.level[0]; co_lev[wave][1] = r.level[1];
+      co_conv[wave][0] = r.converged[0] ? 1 : 0; co_conv[wave][1] = r.converged[1] ? 1 : 0;
+    }
+    __syncthreads();
+    for (int w = 0; w < 4; ++w) {
+      if (!co_need[w]) continue;                 // (block-uniform)
+      const int ikw = bx + kb * w;
+      NodeIntegrand fw{&S, node, KnotK::uniform(linspace_at(ln_k0, ln_k1, NK, ikw)), exclusion};
+      RombergResume R[2];
+      bool dn[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        R[q].load(co_dump[w] + q * kRombergDump, kCoopLevel, b - a, cfg.global_precision,
+                  cfg.halo_precision);
+        R[q].value = co_val[w][q];
+        R[q].level = co_lev[w][q];
+        dn[q] = co_conv[w][q] != 0;
+      }
+      bool all = dn[0] && dn[1];
+      int flip = 0;
+      for (int i = kCoopLevel + 1; i <= dmax && !all; ++i) {
+        const double c_il = CHOMP_ROMBERG_C[i][lane & 31];
+        const long numtosum = 1L << (i - 1);
+        const double h = (b - a) / (double)numtosum;
+        const double lox = a + 0.5 * h;
+        double part[2] = {0.0, 0.0};
+        for (long j = threadIdx.x; j < numtosum; j += 256) {
+          double v[2];
+          fw(lox + h * (double)j, v, i, j);
+          part[0] += v[0];
+          part[1] += v[1];
+        }
+        all = true;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const double Sq = group_sum<4>(part[q], sm, flip);
+          if (!dn[q]) {
+            R[q].advance(i, Sq, c_il);
+            dn[q] = R[q].done;
+          }
+          all = all && dn[q];
+        }
+      }
+      __syncthreads();                            // (sm: the last sums have been read)
+      if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          co_val[w][q] = R[q].value;
+          co_lev[w][q] = R[q].level;
+          co_conv[w][q] = dn[q] ? 1 : 0;
+        }
+      }
+    }
+    __syncthreads();
+    if (!have) return;
+    r.value[0] = co_val[wave][0]; r.value[1] = co_val[wave][1];
+    r.level[0] = co_lev[wave][0]; r.level[1] = co_lev[wave][1];
+    r.converged[0] = co_conv[wave][0] != 0; r.converged[1] = co_conv[wave][1] != 0;
+  } else if constexpr (KNW <= 1) {
+    if (dmax >= 6)
+      r = romberg_wave6<2>(f, a, b, fb, cfg.global_precision, cfg.halo_precision, dmax);
+    else
+      r = romberg_group<1, 2>(f, a, b, cfg.global_precision, cfg.halo_precision, dmax, nullptr);
+  } else {
+    (void)fb;
+    r = romberg_group<KNW, 2>(f, a, b, cfg.global_precision, cfg.halo_precision, dmax, sm);
+  }
+  KNSTAMP(2, __builtin_amdgcn_s_memrealtime());
+  KNSTAMP(3, (r.level[0] > r.level[1] ? r.level[0] : r.level[1]) + 100 * ik);
+  if ((KNW <= 1 ? (threadIdx.x & 63) : threadIdx.x) == 0) {
+    double* lev = t + L.off_levels;
+    const int fa = group_fa(group), fb_ = group_fb(group);
+    const bool more = cfg.divmax > top;
+    if (group != 2 && (mask & (1u << fa))) {
+      t[L.off_knot[fa] + ik] = r.value[0];
+      lev[fa * NK + ik] = (!r.converged[0] && more) ? kPendingLevel : (double)r.level[0];
+    }
+    bool any = false;
+    if (group != 2 && (mask & (1u << fa))) any = any || (!r.converged[0] && more);
+    if (mask & (1u << fb_)) {
+      t[L.off_knot[fb_] + ik] = r.value[1];
+      lev[fb_ * NK + ik] = (!r.converged[1] && more) ? kPendingLevel : (double)r.level[1];
+      any = any || (!r.converged[1] && more);
+    }
+    // divmax within the node tables: scipy returns the last row with an AccuracyWarning
+    if (!more) {
+      unsigned st = 0u;
+      if (group != 2 && (mask & (1u << fa)) && !r.converged[0]) st |= kStHaloDivmax0 << fa;
+      if ((mask & (1u << fb_)) && !r.converged[1]) st |= kStHaloDivmax0 << fb_;
+      if (st) atomicOr(&status[e], st);
+    }
+    // work list of k_halo_knots_fast (layout at kPendingHead): the deepest-running knots --
+    // the highest k -- at the front, the rest from the back of the buffer downwards
+    if (any) {
+      atomicAdd(&npend[e], 1);
+      const int item = (int)((bz * n_epoch + e) * NK + ik);
+      const int cap = 3 * n_epoch * NK;
+      if (4 * ik >= 3 * NK) pending[kPendingHead + atomicAdd(&pending[0], 1)] = item;
+      else pending[kPendingHead + cap - 1 - atomicAdd(&pending[2], 1)] = item;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // The coarse samples of the listed knots: one slot of the context's sample buffer per listed
 // knot (list position -> slot), filled by k_halo_knots_samples -- a launch of its own over ALL
 // listed knots, so that the 2^LC + 1 NFW transforms of a knot are chip time (a thread each)
 // and not 2 x 20 us on the critical path of the block that then sums the knot's levels.
-// Layout of a slot (doubles): F0[kDeepF], F1[kDeepF], the nodes' states as bytes [kDeepF].
+// Layout of a slot (doubles): F0[kDeepF], F1[kDeepF].
 // A sample array holds the even-numbered samples first and the odd ones from kDeepOdd on
 // (deep_pos): every phase of k_halo_knots_fast then reads LDS at unit stride -- the self-check
 // predicts every odd sample from the even ones (stride-2 doubles: a two-way bank conflict by
@@ -1066,34 +1358,38 @@ __device__ __forceinline__ double deep_coarse_x(double a, double b, int q) {
 // ---------------------------------------------------------------------------
 constexpr int kDeepOdd = 1040;
 constexpr int kDeepF = kDeepOdd + (1 << (kDeepCoarse - 1));      // 2064
-constexpr int kDeepSlot = 4400;                                  // 2 x 2064 + 2064 / 8, padded
-constexpr int kDeepPsum = 16;                                    // per (slot, part): levels 11..4 x 2
-static_assert(2 * kDeepF + kDeepF / 8 <= kDeepSlot, "slot layout");
+constexpr int kDeepSlot = 2 * kDeepF;                            // (33 024 bytes: 516 lines of 64)
+constexpr int kDeepPsum = 24;                                    // per (slot, chunk): levels 11..1 x 2, padded
 __host__ __device__ inline int deep_pos(int q) { return (q & 1) ? kDeepOdd + (q >> 1) : (q >> 1); }
 // LDS doubles in front of a block's sample arrays (the epoch's splines, the reductions'
 // scratch), rounded to 16 bytes: the arrays are copied as double2
 __host__ __device__ inline int deep_f_off(int NM) { return (NM + 8 * (NM - 1) + kDeepScratch + 1) & ~1; }
 
-// grid: any (blocks stride over the work items), block 256.  Work item = (listed knot, part):
-// part p of `parts` (1, 2, 4, 8) is samples [p NC / parts, (p + 1) NC / parts) in POSITION
-// order, thread t on t, t + 256, ...: the reads of the (epoch, group) node table are gathers
-// (runs of 32, 16, 8 ... consecutive nodes of a level; the table is L2-resident, shared by the
-// group's knots), the writes of a slot are contiguous.  The upper end point comes from d_endp
-// (the node-table stage evaluated it for every knot).  A thread's samples all belong to one
-// Romberg level -- LC - ctz(t), t != 0 -- so the per-level sums scipy's rows need are taken
-// here, from the registers: psum[(slot * parts + part) * 16 + 2 (LC - level) + f], levels
-// LC .. LC - 7; thread 0's samples (multiples of 256: levels <= 3 and the end points) are read
-// from the slot by the consumer.
+// grid: any (blocks stride over the work items), block 256.  The node table is level-major, and
+// so is the work: chunk c = 0..7 of a knot is table nodes 256 c + 1 .. 256 c + 256 -- levels
+// 1..8 (and the lower end point, node 0, in place of node 1, the upper one, which comes from
+// d_endp: the node-table stage evaluated it for every knot), level 9, level 10 (two chunks),
+// level 11 (four) -- thread t on node 256 c + 1 + t: the nine fields of a node are read at
+// unit stride across the wavefront (in position order they were gathers of runs of 32, 16,
+// 8 ... nodes: 50 us per configs[2] launch, most of it waiting), and the stores of a slot are
+// contiguous for level 11 -- the odd half of deep_pos order -- and strided by 2, 4 ... for the
+// levels below.  Work item = (listed knot, part): part p of `parts` (1, 2, 4, 8) is chunks
+// [8 p / parts, 8 (p + 1) / parts).  A chunk's samples belong to one Romberg level (chunk 0:
+// wavefronts 2-3 level 8, wavefront 1 level 7, wavefront 0 by lane ranges), so the per-level
+// sums scipy's rows need are taken here, from the registers: row (slot * 8 + chunk) of psum,
+// entry 2 (LC - level) + f, zero for the levels a chunk does not hold.
+constexpr int kDeepChunks = 8;
 template <int LC>
 __global__ __launch_bounds__(256) void k_halo_knots_samples(
     chomp_config cfg, TabLayout L, const SiCiTab* __restrict__ sici_g, int g0, int g1, int g2,
     unsigned mask, int n_epoch, const int* __restrict__ pending, const double* __restrict__ nodes,
     const double* __restrict__ endp, double* __restrict__ samples, double* __restrict__ psum,
     int parts, int slot_lo, int slot_hi) {
+  static_assert(LC == 11, "the chunk -> level map below is the level-11 table's");
   constexpr int NC = 1 << LC;
   __shared__ SiCiTab S;
-  __shared__ double xs[4][2][6];
-  __shared__ double single[3][2];
+  __shared__ double xs[4][2];
+  __shared__ double w0[2][64];
   const int NK = L.NK, tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
   const int count_front = pending[0], count = count_front + pending[2];
   const int hi = count < slot_hi ? count : slot_hi;
@@ -1103,7 +1399,7 @@ __global__ __launch_bounds__(256) void k_halo_knots_samples(
                (int)(sizeof(SiCiTab) / sizeof(double)));
   __syncthreads();
   const bool exclusion = (mask & kMaskExclusion) != 0;
-  const int span = NC / parts;
+  const int per = kDeepChunks / parts;
   for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
     const int li = slot_lo + w / parts, part = w % parts;
     const int item = li < count_front
@@ -1113,69 +1409,51 @@ __global__ __launch_bounds__(256) void k_halo_knots_samples(
     const int group = zg == 0 ? g0 : (zg == 1 ? g1 : g2);
     if (group < 0 || group > 2) continue;          // (never listed)
     const double* nd = nodes + ((size_t)e * 3 + group) * kNodeStride;
-    const double ln_k = linspace_at(log(cfg.k_min), log(cfg.k_max), NK, ik);
+    const KnotK kk = KnotK::uniform(linspace_at(log(cfg.k_min), log(cfg.k_max), NK, ik));
     double* slot = samples + (size_t)(li - slot_lo) * kDeepSlot;
-    unsigned char* code = reinterpret_cast<unsigned char*>(slot + 2 * kDeepF);
-    double a0 = 0.0, a1 = 0.0;
-    for (int q = part * span + tid; q < (part + 1) * span; q += 256) {
-      int idx = 0;
-      if (q != 0) {                                // position -> level-major
-        const int tz = __builtin_ctz((unsigned)q);
-        idx = 1 + (1 << (LC - tz - 1)) + (q >> (tz + 1));
-      }
-      const double state = nd[6 * kNodeCount + idx];
+    for (int c = part * per; c < (part + 1) * per; ++c) {
+      // (chunk 0, thread 0: node 0 -- the lower end point -- instead of node 1)
+      const int idx = (c == 0 && tid == 0) ? 0 : 256 * c + 1 + tid;
       double o[2];
-      node_pair(S, ln_k, exclusion, nd[idx], nd[kNodeCount + idx], nd[2 * kNodeCount + idx],
+      node_pair(S, kk, exclusion, nd[idx], nd[kNodeCount + idx], nd[2 * kNodeCount + idx],
                 nd[3 * kNodeCount + idx], nd[4 * kNodeCount + idx], nd[5 * kNodeCount + idx],
-                state, o);
+                nd[6 * kNodeCount + idx], nd[7 * kNodeCount + idx], nd[8 * kNodeCount + idx], o);
+      int q = 0;                                   // level-major -> position
+      if (idx >= 2) {
+        const int m = idx - 1;
+        const int lv = 32 - __builtin_clz((unsigned)m);
+        q = (2 * (m - (1 << (lv - 1))) + 1) << (LC - lv);
+      }
       const int at = deep_pos(q);
       slot[at] = o[0];
       slot[kDeepF + at] = o[1];
-      code[q] = (unsigned char)(int)state;
-      a0 += o[0];
-      a1 += o[1];
-    }
-    if (part == parts - 1 && tid == 255) {         // the upper end point (node 1 of the table)
-      const double* ep = endp + ((size_t)e * 3 + group) * 2 * NK + 2 * ik;
-      slot[deep_pos(NC)] = ep[0];
-      slot[kDeepF + deep_pos(NC)] = ep[1];
-      code[NC] = (unsigned char)(int)nd[6 * kNodeCount + 1];
-    }
-    // per-level sums: lanes of class c = ctz(lane) hold level LC - c (c = 0..5); inside a row
-    // of 16 lanes by DPP, the four rows through v_readlane
-    double r0[6], r1[6];
-    {
-      const double b0 = a0 + dpp_move<0x128>(a0), b1 = a1 + dpp_move<0x128>(a1);     // {i, i + 8}
-      const double c0 = b0 + dpp_move<0x124>(b0), c1 = b1 + dpp_move<0x124>(b1);     // = mod 4
-      const double d0 = c0 + dpp_move<0x4E>(c0), d1 = c1 + dpp_move<0x4E>(c1);       // = mod 2
-      r0[0] = (readlane_d(d0, 1) + readlane_d(d0, 17)) + (readlane_d(d0, 33) + readlane_d(d0, 49));
-      r1[0] = (readlane_d(d1, 1) + readlane_d(d1, 17)) + (readlane_d(d1, 33) + readlane_d(d1, 49));
-      r0[1] = (readlane_d(c0, 2) + readlane_d(c0, 18)) + (readlane_d(c0, 34) + readlane_d(c0, 50));
-      r1[1] = (readlane_d(c1, 2) + readlane_d(c1, 18)) + (readlane_d(c1, 34) + readlane_d(c1, 50));
-      r0[2] = (readlane_d(b0, 4) + readlane_d(b0, 20)) + (readlane_d(b0, 36) + readlane_d(b0, 52));
-      r1[2] = (readlane_d(b1, 4) + readlane_d(b1, 20)) + (readlane_d(b1, 36) + readlane_d(b1, 52));
-      r0[3] = (readlane_d(a0, 8) + readlane_d(a0, 24)) + (readlane_d(a0, 40) + readlane_d(a0, 56));
-      r1[3] = (readlane_d(a1, 8) + readlane_d(a1, 24)) + (readlane_d(a1, 40) + readlane_d(a1, 56));
-      r0[4] = readlane_d(a0, 16) + readlane_d(a0, 48);
-      r1[4] = readlane_d(a1, 16) + readlane_d(a1, 48);
-      r0[5] = readlane_d(a0, 32);
-      r1[5] = readlane_d(a1, 32);
-    }
-    __syncthreads();                               // (xs, single: the previous item's were read)
-    if (ln == 0) {
-#pragma unroll
-      for (int c = 0; c < 6; ++c) { xs[wv][0][c] = r0[c]; xs[wv][1][c] = r1[c]; }
-      // threads 64, 192: level LC - 6; thread 128: level LC - 7 (thread 0: see above)
-      if (wv > 0) { single[wv - 1][0] = a0; single[wv - 1][1] = a1; }
-    }
-    __syncthreads();
-    if (tid < kDeepPsum) {
-      const int c = tid >> 1, f = tid & 1;
-      double v;
-      if (c < 6) v = (xs[0][f][c] + xs[1][f][c]) + (xs[2][f][c] + xs[3][f][c]);
-      else if (c == 6) v = single[0][f] + single[2][f];
-      else v = single[1][f];
-      psum[((size_t)(li - slot_lo) * parts + part) * kDeepPsum + tid] = v;
+      if (c == 0 && tid == 0) {                    // the upper end point (node 1 of the table)
+        const double* ep = endp + ((size_t)e * 3 + group) * 2 * NK + 2 * ik;
+        slot[deep_pos(NC)] = ep[0];
+        slot[kDeepF + deep_pos(NC)] = ep[1];
+        o[0] = 0.0;                                // (an end point: in no level's sum)
+        o[1] = 0.0;
+      }
+      const double x0 = wave_sum(o[0]), x1 = wave_sum(o[1]);
+      __syncthreads();                             // (xs, w0: the previous chunk's were read)
+      if (ln == 0) { xs[wv][0] = x0; xs[wv][1] = x1; }
+      if (c == 0 && wv == 0) { w0[0][ln] = o[0]; w0[1][ln] = o[1]; }
+      __syncthreads();
+      if (tid < 24) {
+        const int f = tid & 1, l = LC - (tid >> 1);
+        double v = 0.0;
+        if (c >= 1) {
+          const int lc = c == 1 ? 9 : (c <= 3 ? 10 : 11);
+          if (l == lc) v = (xs[0][f] + xs[1][f]) + (xs[2][f] + xs[3][f]);
+        } else if (l == 8) {
+          v = xs[2][f] + xs[3][f];
+        } else if (l == 7) {
+          v = xs[1][f];
+        } else if (l >= 1 && l <= 6) {             // threads 2^(l - 1) .. 2^l - 1 of wavefront 0
+          for (int t = 1 << (l - 1); t < (1 << l); ++t) v += w0[f][t];
+        }
+        psum[((size_t)(li - slot_lo) * kDeepChunks + c) * kDeepPsum + tid] = v;
+      }
     }
   }
 }
@@ -1191,7 +1469,7 @@ template <int LC>
 inline size_t deep_fast_lds(int NM, int divmax) {
   const size_t deep = (size_t)(deep_f_off(NM) + 2 * kDeepF +
                                deep_w_levels(divmax, LC) * kDeepWStride + (divmax + 1) * 32) *
-                          sizeof(double) + (size_t)kDeepF;
+                          sizeof(double);
   return deep;                     // (> finalize_lds_doubles(NK) for any NK <= 512 at LC >= 11)
 }
 // ... of k_halo_knots_literal.
@@ -1285,14 +1563,14 @@ __device__ __forceinline__ void deep_arrive(const chomp_config& cfg, const TabLa
 // the list positions the lean one left at pending_eval_base(); the knots' samples are still
 // in their slots).
 template <int LC, int NT, bool SELF, bool EVAL>
-__global__ __launch_bounds__(NT, (!EVAL && NT == 256) ? 3 : 512 / NT) void k_halo_knots_fast(
+__global__ __launch_bounds__(NT, SELF ? 1 : ((!EVAL && NT == 256) ? 3 : 512 / NT)) void k_halo_knots_fast(
     chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs, double* __restrict__ tab,
     const SiCiTab* __restrict__ sici_g, int g0, int g1, int g2, unsigned mask, int n_epoch,
     int* __restrict__ pending, int* __restrict__ npend, Epoch* __restrict__ epochs_rw,
     unsigned fam_mask, unsigned* __restrict__ status, const double* __restrict__ deepw,
     int all_literal, double tol, int max_rough, int max_fine, int* __restrict__ stats,
     const double* __restrict__ samples, const double* __restrict__ psum, int parts,
-    int round, int slot_lo, int slot_hi, int from_eval) {
+    int round, int slot_lo, int slot_hi, int from_eval, const DeepPlan* __restrict__ plans) {
   static_assert(LC == kNodeTabLevel, "the coarse samples are the node table's grid");
   constexpr int NC = 1 << LC;
   constexpr int NWV = NT / 64;
@@ -1302,12 +1580,11 @@ __global__ __launch_bounds__(NT, (!EVAL && NT == 256) ? 3 : 512 / NT) void k_hal
   constexpr bool kNeedsSici = SELF || EVAL;
   __shared__ std::conditional_t<kNeedsSici, SiCiTab, double> S_store;
   SiCiTab& S = *reinterpret_cast<SiCiTab*>(&S_store);
-  __shared__ int item_sh, n_rough_sh, n_fine_sh, n_seg_sh, last_sh, bail_sh;
-  __shared__ int rough_sh[kDeepMaxRough], fine_sh[kDeepMaxFine];
-  __shared__ int seg_lo[kDeepMaxRough + 1], seg_hi[kDeepMaxRough + 1];
-  // per node-by-node interval: the states of its two end nodes (low / high nibble), and whether
-  // its nodes may be read off the one-sided continuations of the neighbouring smooth segments
-  __shared__ unsigned char fine_states[kDeepMaxFine], fine_poly[kDeepMaxFine];
+  __shared__ int item_sh, last_sh, bail_sh;
+  __shared__ DeepPlan PL;                          // the (epoch, group)'s break-point plan
+  // whether a node-by-node interval's nodes may be read off the one-sided continuations of the
+  // neighbouring smooth segments (the plan's geometry and this knot's eighth differences)
+  __shared__ unsigned char fine_poly[kDeepMaxFine];
   // per smooth segment [lo, hi]: the sum of the samples lo .. hi - 7 (see the deep rounds)
   __shared__ double seg_sum[2][kDeepMaxRough + 1], seg_slot[NWV][2][kDeepMaxRough + 1];
   __shared__ double rows_park[2][RombergRows2::kPark];
@@ -1345,6 +1622,9 @@ __global__ __launch_bounds__(NT, (!EVAL && NT == 256) ? 3 : 512 / NT) void k_hal
   bool first_item = true;
   int n_items = 0;
 #endif
+  // (drawing the next knot while the current one is worked on -- the atomic's round trip off the
+  //  chain -- was measured and is worse: the blocks that start first, on the deepest knots, then
+  //  also hold the first of the knots left over, 100 against 88 us per configs[2] launch)
   for (;;) {
 #ifdef CHOMP_STAMPS
     first_item = (n_items++ == 0);
@@ -1416,24 +1696,49 @@ __global__ __launch_bounds__(NT, (!EVAL && NT == 256) ? 3 : 512 / NT) void k_hal
       continue;
     }
     KSTAMP(0);
-    // ---- the epoch's tables
+    // (the sampling launch's level sums, its chunks in order: on their way while the samples are copied)
+    double lsum_pre = 0.0;
+    if (tid < 2 * (LC + 1) && tid % (LC + 1) >= 1) {
+      const int f = tid / (LC + 1), l = tid % (LC + 1);
+      const double* ps = psum + (size_t)(item_sh - slot_lo) * kDeepChunks * kDeepPsum + 2 * (LC - l) + f;
+      for (int pt = 0; pt < kDeepChunks; ++pt) lsum_pre += ps[pt * kDeepPsum];
+    }
+    // ---- the (epoch, group)'s break-point plan (k_halo_knots' extra block built it)
+    copy_doubles(reinterpret_cast<double*>(&PL),
+                 reinterpret_cast<const double*>(plans + (size_t)e * 3 + group), kDeepPlanDoubles);
     double* nu_knots = sm;
     double* lnm_pp = nu_knots + L.NM;
-    copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
-                 kEpochDoubles);
-    copy_doubles(nu_knots, t + L.off_nu, L.NM);
-    copy_doubles(lnm_pp, t + L.off_lnm_pp, 4 * (L.NM - 1));
-    if (tid == 0) { n_rough_sh = 0; n_fine_sh = 0; n_seg_sh = 0; bail_sh = 0; }
-    __syncthreads();
-    KSTAMP(1);
+    if constexpr (EVAL) {            // (the integrand's tables: only where nodes are evaluated)
+      copy_doubles(reinterpret_cast<double*>(&E), reinterpret_cast<const double*>(&epochs[e]),
+                   kEpochDoubles);
+      copy_doubles(nu_knots, t + L.off_nu, L.NM);
+      copy_doubles(lnm_pp, t + L.off_lnm_pp, 4 * (L.NM - 1));
+    }
+    if (tid == 0) bail_sh = 0;
+    // ---- the knot's coarse samples: k_halo_knots_samples left them in slot (list position)
+    // of the sample buffer, already in deep_pos order, with the sums of levels LC - 7 .. LC
+    // beside them: a contiguous copy into LDS
     double* red = sm + L.NM + 8 * (L.NM - 1);
     double* F0 = sm + deep_f_off(L.NM);
     double* F1 = F0 + kDeepF;                              // (both in deep_pos order)
     double* W = F1 + kDeepF;                               // [divmax - LC][kDeepWStride]
     const double* Ctab = W + deep_w_levels(cfg.divmax, LC) * kDeepWStride;   // [divmax + 1][32]
-    unsigned char* code = reinterpret_cast<unsigned char*>(
-        W + deep_w_levels(cfg.divmax, LC) * kDeepWStride + (cfg.divmax + 1) * 32);
-    const double a = group_lower(E, group), b = log(E.nu_max);
+    {
+      const double2* src = reinterpret_cast<const double2*>(samples + (size_t)(item_sh - slot_lo) * kDeepSlot);
+      double2* dst = reinterpret_cast<double2*>(F0);
+      for (int i = tid; i < kDeepF; i += NT) dst[i] = src[i];              // F0 and F1
+    }
+    __syncthreads();
+    KSTAMP(1);
+    KSTAMP(2);
+    if (PL.flag != 0) {              // block-uniform: too many break points / intervals
+      if (tid == 0) {
+        lit_items[atomicAdd(&pending[4], 1)] = item;
+        if (stats) atomicAdd(&stats[PL.flag == 1 ? 2 : 3], 1);
+      }
+      continue;
+    }
+    const double a = PL.a, b = PL.b;
     HaloCtx c{&E, &S, nu_knots, lnm_pp, L.NM,
               linspace_at(log(cfg.k_min), log(cfg.k_max), NK, ik), (mask & kMaskExclusion) != 0};
     bool literal = false, to_eval = false;
@@ -1441,237 +1746,136 @@ __global__ __launch_bounds__(NT, (!EVAL && NT == 256) ? 3 : 512 / NT) void k_hal
     RombergRows2 R;
     R.ctab = Ctab;
     {
-      // ---- the knot's coarse samples: k_halo_knots_samples left them in slot (list position)
-      // of the sample buffer, already in deep_pos order, with the states of the nodes behind
-      // them and the sums of levels LC - 7 .. LC beside them: a contiguous copy into LDS
-      {
-        const double* slot = samples + (size_t)(item_sh - slot_lo) * kDeepSlot;
-        const double2* src = reinterpret_cast<const double2*>(slot);
-        double2* dst = reinterpret_cast<double2*>(F0);
-        for (int i = tid; i < kDeepF; i += NT) dst[i] = src[i];              // F0 and F1
-        const unsigned* csrc = reinterpret_cast<const unsigned*>(slot + 2 * kDeepF);
-        unsigned* cdst = reinterpret_cast<unsigned*>(code);
-        for (int i = tid; i < kDeepF / 4; i += NT) cdst[i] = csrc[i];
-      }
-      __syncthreads();
-      KSTAMP(2);
-      // ---- levels 0..LC: the wavefronts' sums in a fixed order, then scipy's rows
+      // ---- levels 0..LC: their sums (the sampling launch's parts in order; the lowest three
+      // from the samples), then scipy's rows -- all LC extrapolations at once (they do not
+      // depend on each other: only the stopping test walks through them in order)
       {
         double* lsum = red + 2 * NWV;                          // [2][LC + 1] (behind group_sum's slots)
         if (tid < 2 * (LC + 1)) {
           const int f = tid / (LC + 1), l = tid % (LC + 1);
-          const double* Ff = f ? F1 : F0;
-          double v = 0.0;
-          if (l >= LC - 7) {                                   // the sampling launch's parts, in order
-            const double* ps = psum + (size_t)(item_sh - slot_lo) * parts * kDeepPsum + 2 * (LC - l) + f;
-            for (int pt = 0; pt < parts; ++pt) v += ps[pt * kDeepPsum];
-          } else if (l >= 1) {                                 // samples 256 m, m odd multiples of 2^(3 - l)
-            const int step = 1 << (LC - l);
-            for (int q = step; q < NC; q += 2 * step) v += Ff[deep_pos(q)];
-          }
+          const double v = lsum_pre;
           lsum[f * (LC + 1) + l] = v;
         }
         __syncthreads();
-        R.start(b - a, cfg.global_precision, cfg.halo_precision,
-                0.5 * (F0[0] + F0[deep_pos(NC)]), 0.5 * (F1[0] + F1[deep_pos(NC)]), pa, pb);
-        for (int l = 1; l <= LC && !R.all_done(); ++l) R.advance(l, lsum[l], lsum[LC + 1 + l]);
+        R.start_levels<LC>(b - a, cfg.global_precision, cfg.halo_precision,
+                           0.5 * (F0[0] + F0[deep_pos(NC)]), 0.5 * (F1[0] + F1[deep_pos(NC)]),
+                           lsum, lsum + LC + 1, pa, pb);
       }
       KSTAMP(3);
+      const int nf_all = PL.n_fine, ns = PL.n_seg;
       if (!R.all_done()) {
-        // ---- break points: coarse intervals whose ends are in different states
-        for (int i = tid; i < NC; i += NT)
-          if (code[i] != code[i + 1]) {
-            const int at = atomicAdd(&n_rough_sh, 1);
-            if (at < kDeepMaxRough) rough_sh[at] = i;
+        // ---- a break-point interval between two smooth segments: on either side of the
+        // break the integrand is the smooth continuation of its neighbour's branch (each
+        // `if` of halo.py:1038-1041, 1084-1086, hod.py:189-230 switches between analytic
+        // expressions), so a node inside it need not be EVALUATED: its branch is decided by
+        // the plan's xstar, its value read off the degree-7 polynomial through the last /
+        // first 8 samples of that neighbour, continued by less than one coarse spacing.
+        // The eighth difference at the segment's end bounds that continuation's error
+        // (0.2 of it at mid-interval); a singular satellite onset (alpha != 1) is not
+        // continued across: those intervals have no smooth neighbour on that side.
+        if (tid < nf_all) {
+          const int i = PL.fine[tid];
+          bool ok = PL.geom[tid] != 0;
+          if (ok) {
+            // |Delta^8 F| at the two ends against the size of the samples there
+            const double w8[9] = {1.0, -8.0, 28.0, -56.0, 70.0, -56.0, 28.0, -8.0, 1.0};
+            double dl0 = 0.0, dl1 = 0.0, dr0 = 0.0, dr1 = 0.0, sc0 = 0.0, sc1 = 0.0;
+#pragma unroll
+            for (int m = 0; m < 9; ++m) {
+              const int pl = deep_pos(i - 8 + m), pr = deep_pos(i + 1 + m);
+              dl0 = fma(w8[m], F0[pl], dl0);
+              dl1 = fma(w8[m], F1[pl], dl1);
+              dr0 = fma(w8[m], F0[pr], dr0);
+              dr1 = fma(w8[m], F1[pr], dr1);
+              sc0 += fabs(F0[pl]) + fabs(F0[pr]);
+              sc1 += fabs(F1[pl]) + fabs(F1[pr]);
+            }
+            // (budget: the nodes of a break-point interval are 1 / NC of a level's; with up to
+            //  four such intervals an error of tol NC / 4 of the samples' size per node keeps
+            //  the level sum within tol -- 5e-7 at the defaults; sc sums 18 samples)
+            const double lim = tol * (double)NC / (4.0 * 18.0);
+            ok = fabs(dl0) <= lim * sc0 && fabs(dr0) <= lim * sc0 &&
+                 fabs(dl1) <= lim * sc1 && fabs(dr1) <= lim * sc1;
           }
-        __syncthreads();
-        const int nr = n_rough_sh;
-        if (nr > max_rough) {
-          literal = true;                                      // block-uniform
-          if (stats && tid == 0) atomicAdd(&stats[2], 1);
-        } else {
-          if (tid == 0) {
-            // node-by-node intervals: the break points, and above one where the satellites
-            // switch on a margin in which (M - M_0)^alpha is still too singular to interpolate
-            int nf = 0;
-            bool over = false;
-            // (pp_gg starts AT M_0 when that lies inside the mass range, halo.py:1002-1006:
-            //  the same singular onset, with no change of state to announce it)
-            // (alpha = 1: N_sat is linear in M - M_0 -- a kink, smooth on either side: no margin)
-            const bool singular_onset = E.hod_alpha != 1.0;
-            if (singular_onset && group == 2 && E.ln_nu_lo_second > log(E.nu_min))
-              for (int d = 0; d <= kDeepKinkMargin; ++d) fine_sh[nf++] = d;
-            for (int x = 0; x < nr; ++x) {
-              const int i = rough_sh[x];
-              const int span = (((code[i] ^ code[i + 1]) & 2) && singular_onset) ? kDeepKinkMargin : 0;
-              for (int d = 0; d <= span && i + d < NC; ++d) {
-                if (nf < kDeepMaxFine) fine_sh[nf++] = i + d; else over = true;
-              }
-            }
-            for (int x = 1; x < nf; ++x) {                     // insertion sort
-              const int v = fine_sh[x];
-              int y = x - 1;
-              while (y >= 0 && fine_sh[y] > v) { fine_sh[y + 1] = fine_sh[y]; --y; }
-              fine_sh[y + 1] = v;
-            }
-            int nu = 0;                                        // unique
-            for (int x = 0; x < nf; ++x)
-              if (x == 0 || fine_sh[x] != fine_sh[x - 1]) fine_sh[nu++] = fine_sh[x];
-            // smooth segments between them (node ranges); one shorter than a stencil is
-            // evaluated node by node as well
-            int ns = 0, lo = 0, extra = nu;
-            for (int x = 0; x <= nu; ++x) {
-              const int hi = x < nu ? fine_sh[x] : NC;         // last node of the segment
-              if (hi - lo + 1 >= kDeepStencil) {
-                if (ns <= kDeepMaxRough) { seg_lo[ns] = lo; seg_hi[ns] = hi; ++ns; } else over = true;
-              } else {
-                for (int i = lo; i < hi; ++i) {
-                  if (extra < kDeepMaxFine) fine_sh[extra++] = i; else over = true;
-                }
-              }
-              lo = hi + 1;
-            }
-            n_fine_sh = (over || extra > max_fine) ? kDeepMaxFine + 1 : extra;
-            n_seg_sh = ns;
-          }
-          __syncthreads();
-          const int ns = n_seg_sh;
-          if (n_fine_sh > kDeepMaxFine) {
-            literal = true;
-            if (stats && tid == 0) atomicAdd(&stats[3], 1);
-          } else {
-            const int nf_all = n_fine_sh;
-            if (tid < nf_all) {
-              const int i = fine_sh[tid];
-              fine_states[tid] = (unsigned char)((code[i] & 15) | ((code[i + 1] & 15) << 4));
-            }
-            __syncthreads();
-            // interval -> 1 + its segment (0: node by node); the states are no longer needed
-            for (int i = tid; i < NC; i += NT) {
-              int sg = 0;
-              for (int x = 0; x < ns; ++x)
-                if (i >= seg_lo[x] && i < seg_hi[x]) sg = x + 1;
-              code[i] = (unsigned char)sg;
-            }
-            __syncthreads();
-            // ---- a break-point interval between two smooth segments: on either side of the
-            // break the integrand is the smooth continuation of its neighbour's branch (each
-            // `if` of halo.py:1038-1041, 1084-1086, hod.py:189-230 switches between analytic
-            // expressions), so a node inside it need not be EVALUATED: its branch is decided by
-            // the exact discrete state at the node (halo_state_at: what does not depend on k,
-            // no NFW transform), its value read off the degree-7 polynomial through the last /
-            // first 8 samples of that neighbour, continued by less than one coarse spacing.
-            // The eighth difference at the segment's end bounds that continuation's error
-            // (0.2 of it at mid-interval); a singular satellite onset (alpha != 1) is not
-            // continued across: those intervals have no smooth neighbour on that side.
-            if (tid < nf_all) {
-              const int i = fine_sh[tid];
-              bool ok = i > 0 && i < NC - 1 && code[i - 1] != 0 && code[i + 1] != 0 &&
-                        (fine_states[tid] & 15) != (fine_states[tid] >> 4);
-              if (ok) {
-                const int sl = code[i - 1] - 1, sr = code[i + 1] - 1;
-                ok = seg_hi[sl] == i && seg_lo[sr] == i + 1 && i - seg_lo[sl] >= 8 &&
-                     seg_hi[sr] - (i + 1) >= 8;
-              }
-              if (ok) {
-                // |Delta^8 F| at the two ends against the size of the samples there
-                const double w8[9] = {1.0, -8.0, 28.0, -56.0, 70.0, -56.0, 28.0, -8.0, 1.0};
-                double dl0 = 0.0, dl1 = 0.0, dr0 = 0.0, dr1 = 0.0, sc0 = 0.0, sc1 = 0.0;
+          fine_poly[tid] = ok ? 1 : 0;
+        }
+        // ---- per smooth segment the sum of its samples lo .. hi - 7: all a deep level
+        // needs of the segment's interior (below); every segment in one pass, one exchange
+        {
 #pragma unroll
-                for (int m = 0; m < 9; ++m) {
-                  const int pl = deep_pos(i - 8 + m), pr = deep_pos(i + 1 + m);
-                  dl0 = fma(w8[m], F0[pl], dl0);
-                  dl1 = fma(w8[m], F1[pl], dl1);
-                  dr0 = fma(w8[m], F0[pr], dr0);
-                  dr1 = fma(w8[m], F1[pr], dr1);
-                  sc0 += fabs(F0[pl]) + fabs(F0[pr]);
-                  sc1 += fabs(F1[pl]) + fabs(F1[pr]);
-                }
-                // (budget: the nodes of a break-point interval are 1 / NC of a level's; with up to
-                //  four such intervals an error of tol NC / 4 of the samples' size per node keeps
-                //  the level sum within tol -- 5e-7 at the defaults; sc sums 18 samples)
-                const double lim = tol * (double)NC / (4.0 * 18.0);
-                ok = fabs(dl0) <= lim * sc0 && fabs(dr0) <= lim * sc0 &&
-                     fabs(dl1) <= lim * sc1 && fabs(dr1) <= lim * sc1;
+          for (int sgi = 0; sgi <= kDeepMaxRough; ++sgi) {
+            double a0 = 0.0, a1 = 0.0;
+            if (sgi < ns) {                                  // block-uniform
+              const int hi7 = PL.seg_hi[sgi] - 7;
+              for (int q = PL.seg_lo[sgi] + tid; q <= hi7; q += NT) {
+                const int at = deep_pos(q);
+                a0 += F0[at];
+                a1 += F1[at];
               }
-              fine_poly[tid] = ok ? 1 : 0;
+              a0 = wave_sum(a0);
+              a1 = wave_sum(a1);
+              if (ln == 0) { seg_slot[wv][0][sgi] = a0; seg_slot[wv][1][sgi] = a1; }
             }
-            // ---- per smooth segment the sum of its samples lo .. hi - 7: all a deep level
-            // needs of the segment's interior (below); every segment in one pass, one exchange
-            {
-#pragma unroll
-              for (int sgi = 0; sgi <= kDeepMaxRough; ++sgi) {
-                double a0 = 0.0, a1 = 0.0;
-                if (sgi < ns) {                                  // block-uniform
-                  const int hi7 = seg_hi[sgi] - 7;
-                  for (int q = seg_lo[sgi] + tid; q <= hi7; q += NT) {
-                    const int at = deep_pos(q);
-                    a0 += F0[at];
-                    a1 += F1[at];
-                  }
-                  a0 = wave_sum(a0);
-                  a1 = wave_sum(a1);
-                  if (ln == 0) { seg_slot[wv][0][sgi] = a0; seg_slot[wv][1][sgi] = a1; }
-                }
-              }
-            }
-            __syncthreads();
-            if (tid < 2 * (kDeepMaxRough + 1)) {
-              const int f = tid / (kDeepMaxRough + 1), sgi = tid % (kDeepMaxRough + 1);
-              double v = 0.0;
-              if (sgi < ns) {
-#pragma unroll
-                for (int w2 = 0; w2 < NWV; ++w2) v += seg_slot[w2][f][sgi];
-              }
-              seg_sum[f][sgi] = v;
-            }
-            // (visible to the rounds below: the self-check's exchanges carry barriers)
-            KSTAMP(4);
-            // ---- self-check: the same machinery one level up.  Every odd sample is predicted
-            // from the even ones (stencils of twice the spacing, shifted at segment ends
-            // exactly as below) and compared with its true value; at the spacing actually
-            // used the interpolation error is 2^8 times smaller.
-            double e0 = 0.0, e1 = 0.0, m0 = 0.0, m1 = 0.0;
-            for (int ep = tid; ep < NC / 2; ep += NT) {
-              const int sg = code[2 * ep];
-              if (!sg || code[2 * ep + 1] != sg) continue;     // node by node
-              const int lo_e = (seg_lo[sg - 1] + 1) >> 1, hi_e = seg_hi[sg - 1] >> 1;   // even nodes / 2
-              if (hi_e - lo_e + 1 < kDeepStencil) continue;
-              int st = ep - 3;
-              st = st < lo_e ? lo_e : (st > hi_e - 7 ? hi_e - 7 : st);
-              const double* w = W + (ep - st) * kDeepStencil;
-              double p0 = 0.0, p1 = 0.0;
-#pragma unroll
-              for (int m = 0; m < kDeepStencil; ++m) {
-                p0 = fma(w[m], F0[st + m], p0);                // (even sample 2 (st + m))
-                p1 = fma(w[m], F1[st + m], p1);
-              }
-              e0 += fabs(p0 - F0[kDeepOdd + ep]);              // (odd sample 2 ep + 1)
-              e1 += fabs(p1 - F1[kDeepOdd + ep]);
-            }
-            for (int q = tid; q <= NC / 2; q += NT) { m0 += F0[q]; m1 += F1[q]; }
-            for (int q = tid; q < NC / 2; q += NT) { m0 += F0[kDeepOdd + q]; m1 += F1[kDeepOdd + q]; }
-            e0 = group_sum<NWV>(e0, red, flip);
-            e1 = group_sum<NWV>(e1, red, flip);
-            m0 = group_sum<NWV>(m0, red, flip);
-            m1 = group_sum<NWV>(m1, red, flip);
-            const bool bad0 = !R.done[0] && !(e0 * (1.0 / 256.0) <= tol * fabs(m0));
-            const bool bad1 = !R.done[1] && !(e1 * (1.0 / 256.0) <= tol * fabs(m1));
-            if (bad0 || bad1) literal = true;
-            bool need_eval = false;
-            if constexpr (!EVAL) {   // an interval that has to be evaluated node by node
-              for (int x = 0; x < nf_all; ++x) need_eval = need_eval || fine_poly[x] == 0;
-            }
-            if (stats && tid == 0) {
-              if (!literal && need_eval) atomicAdd(&stats[6], 1);
-              if (literal) atomicAdd(&stats[4], 1);
-              const float r0 = R.done[0] ? 0.0f : (float)(e0 * (1.0 / 256.0) / fabs(m0));
-              const float r1 = R.done[1] ? 0.0f : (float)(e1 * (1.0 / 256.0) / fabs(m1));
-              atomicMax(&stats[5], __float_as_int(fmaxf(r0, r1)));   // (positive floats order as ints)
-            }
-            if (need_eval && !literal) to_eval = true;
           }
         }
+        __syncthreads();
+        if (tid < 2 * (kDeepMaxRough + 1)) {
+          const int f = tid / (kDeepMaxRough + 1), sgi = tid % (kDeepMaxRough + 1);
+          double v = 0.0;
+          if (sgi < ns) {
+#pragma unroll
+            for (int w2 = 0; w2 < NWV; ++w2) v += seg_slot[w2][f][sgi];
+          }
+          seg_sum[f][sgi] = v;
+        }
+        // (visible to the rounds below: the self-check's exchanges carry barriers)
+        KSTAMP(4);
+        // ---- self-check: the same machinery one level up.  Every odd sample is predicted
+        // from the even ones (stencils of twice the spacing, shifted at segment ends
+        // exactly as below) and compared with its true value; at the spacing actually
+        // used the interpolation error is 2^8 times smaller.
+        double e0 = 0.0, e1 = 0.0, m0 = 0.0, m1 = 0.0;
+        for (int ep = tid; ep < NC / 2; ep += NT) {
+          // the segment that holds both intervals 2 ep and 2 ep + 1 (none: node by node)
+          int sg = -1;
+          for (int x = 0; x < ns; ++x)
+            if (2 * ep >= PL.seg_lo[x] && 2 * ep + 1 < PL.seg_hi[x]) sg = x;
+          if (sg < 0) continue;
+          const int lo_e = (PL.seg_lo[sg] + 1) >> 1, hi_e = PL.seg_hi[sg] >> 1;   // even nodes / 2
+          if (hi_e - lo_e + 1 < kDeepStencil) continue;
+          int st = ep - 3;
+          st = st < lo_e ? lo_e : (st > hi_e - 7 ? hi_e - 7 : st);
+          const double* w = W + (ep - st) * kDeepStencil;
+          double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+          for (int m = 0; m < kDeepStencil; ++m) {
+            p0 = fma(w[m], F0[st + m], p0);                // (even sample 2 (st + m))
+            p1 = fma(w[m], F1[st + m], p1);
+          }
+          e0 += fabs(p0 - F0[kDeepOdd + ep]);              // (odd sample 2 ep + 1)
+          e1 += fabs(p1 - F1[kDeepOdd + ep]);
+        }
+        for (int q = tid; q <= NC / 2; q += NT) { m0 += F0[q]; m1 += F1[q]; }
+        for (int q = tid; q < NC / 2; q += NT) { m0 += F0[kDeepOdd + q]; m1 += F1[kDeepOdd + q]; }
+        e0 = group_sum<NWV>(e0, red, flip);
+        e1 = group_sum<NWV>(e1, red, flip);
+        m0 = group_sum<NWV>(m0, red, flip);
+        m1 = group_sum<NWV>(m1, red, flip);
+        const bool bad0 = !R.done[0] && !(e0 * (1.0 / 256.0) <= tol * fabs(m0));
+        const bool bad1 = !R.done[1] && !(e1 * (1.0 / 256.0) <= tol * fabs(m1));
+        if (bad0 || bad1) literal = true;
+        bool need_eval = false;
+        if constexpr (!EVAL) {   // an interval that has to be evaluated node by node
+          for (int x = 0; x < nf_all; ++x) need_eval = need_eval || fine_poly[x] == 0;
+        }
+        if (stats && tid == 0) {
+          if (!literal && need_eval) atomicAdd(&stats[6], 1);
+          if (literal) atomicAdd(&stats[4], 1);
+          const float r0 = R.done[0] ? 0.0f : (float)(e0 * (1.0 / 256.0) / fabs(m0));
+          const float r1 = R.done[1] ? 0.0f : (float)(e1 * (1.0 / 256.0) / fabs(m1));
+          atomicMax(&stats[5], __float_as_int(fmaxf(r0, r1)));   // (positive floats order as ints)
+        }
+        if (need_eval && !literal) to_eval = true;
       }
       if (literal) {               // block-uniform: on to k_halo_knots_literal, still counted
         if (tid == 0) lit_items[atomicAdd(&pending[4], 1)] = item;
@@ -1682,14 +1886,14 @@ __global__ __launch_bounds__(NT, (!EVAL && NT == 256) ? 3 : 512 / NT) void k_hal
         continue;
       }
       KSTAMP(5);
-      KSTAMP_VALUE(22, n_fine_sh);
+      KSTAMP_VALUE(22, nf_all);
       {
         // ---- deeper levels, kDeepRound at a time (their sums are independent; what a level
         // costs here is latency -- a handful of node-by-node evaluations and two reductions --
         // so a pass over three levels takes little longer than one; a knot that stops at the
         // first of them has summed two levels for nothing): weighted sums of the samples + the
         // break-point intervals, then the rows one by one
-        const int nf = n_fine_sh;
+        const int nf = nf_all;
         for (int lv0 = LC + 1; lv0 <= cfg.divmax && !R.all_done(); lv0 += kDeepRound) {
           const int ng = cfg.divmax - lv0 + 1 < kDeepRound ? cfg.divmax - lv0 + 1 : kDeepRound;
           // (read back behind the round's exchange; two buffers in turn: a wavefront may still
@@ -1709,10 +1913,9 @@ __global__ __launch_bounds__(NT, (!EVAL && NT == 256) ? 3 : 512 / NT) void k_hal
           // <= 9 x 3 x 7 threads with 8 multiply-adds each, where a pass over all 2048 intervals
           // cost 40 LDS reads per interval and level round (6.7 us of a ~11 us round).
           {
-            const int nseg = n_seg_sh;
-            if (tid < nseg * ng * 7) {
+            if (tid < ns * ng * 7) {
               const int part = tid % 7, g = (tid / 7) % ng, sgi = tid / (7 * ng);
-              const int lo = seg_lo[sgi], hi = seg_hi[sgi];
+              const int lo = PL.seg_lo[sgi], hi = PL.seg_hi[sgi];
               const double* w = Wl + g * kDeepWStride + part * kDeepStencil;
               double v0 = 0.0, v1 = 0.0;
               if (part != 3) {
@@ -1750,24 +1953,19 @@ __global__ __launch_bounds__(NT, (!EVAL && NT == 256) ? 3 : 512 / NT) void k_hal
             int g = 0, r = idx;
             while (r >= (per0 << g)) { r -= per0 << g; ++g; }
             const int n = n0 << g;
-            const int xi = r / n, rr = r % n, iv = fine_sh[xi];
+            const int xi = r / n, rr = r % n, iv = PL.fine[xi];
             const long j = (long)iv * n + rr;
             const double h = (b - a) / (double)(1L << (lv0 + g - 1));
             const double x = (a + 0.5 * h) + h * (double)j;
             double o[2];
-            bool done = false;
             if (fine_poly[xi]) {
-              const int st = halo_state_at(group, c, x);
-              const int sl = fine_states[xi] & 15, sr = fine_states[xi] >> 4;
-              if (st == sl || st == sr) {
-                const bool left = st == sl;
-                const int s0i = left ? iv - 7 : iv + 1;
-                const double t = (left ? 7.0 : -1.0) + ((double)rr + 0.5) / (double)n;
-                lagrange8_pair(t, F0, F1, s0i, [](int q) { return deep_pos(q); }, &o[0], &o[1]);
-                done = true;
-              }
-            }
-            if (!done) {
+              // (the node's branch: the plan's tstar on the interval's grid of 2^(divmax - LC)
+              //  parts, where this node is the odd multiple 2 rr + 1 of 2^(divmax - level))
+              const bool left = ((2 * rr + 1) << (cfg.divmax - (lv0 + g))) < PL.tstar[xi];
+              const int s0i = left ? iv - 7 : iv + 1;
+              const double t = (left ? 7.0 : -1.0) + ((double)rr + 0.5) / (double)n;
+              lagrange8_pair(t, F0, F1, s0i, [](int q) { return deep_pos(q); }, &o[0], &o[1]);
+            } else {
               if constexpr (EVAL) {
                 int st;
                 halo_eval_coded(group, c, x, o, &st);
@@ -1807,8 +2005,8 @@ __global__ __launch_bounds__(NT, (!EVAL && NT == 256) ? 3 : 512 / NT) void k_hal
           }
           if (lv0 == LC + 1) KSTAMP(12);
           if constexpr (!EVAL) {
-            // (a node of a break-point interval whose state is neither neighbour's; read behind
-            //  the exchange's barrier: block-uniform)
+            // (read behind the exchange's barrier: block-uniform; cannot happen while the
+            //  pre-check above sends every knot with such an interval on, kept as the guard)
             if (bail_sh) { to_eval = true; break; }
           }
           R.unpark(park);

@@ -71,7 +71,9 @@ constexpr int kNodeLevel = 10;
 constexpr int kNodeTabLevel = 11;
 constexpr int kNodeBase = (1 << kNodeLevel) + 1;        // nodes k_halo_knots reads
 constexpr int kNodeCount = (1 << kNodeTabLevel) + 1;    // nodes of the table (the field stride)
-constexpr int kNodeFields = 7;   // wA, wB, ln_rs, con, ln_cp, inv_mass_k, state (bit 0: flag)
+constexpr int kNodeFields = 9;   // wA, wB, ln_rs, con, ln_cp, inv_mass_k, state (bit 0: flag),
+                                 // r_s, 1 / ((1 + c) r_s): k r_s and its reciprocal are then two
+                                 // multiplications per (knot, node) -- no exp, no division
 constexpr int kNodeStride = kNodeFields * kNodeCount + 8;   // doubles per (epoch, group);
                                                             // tail: integration limits a, b
 __host__ __device__ inline int node_index(int lev, long j) {
