@@ -505,6 +505,7 @@ __global__ __launch_bounds__(256) void k_sigma_nodes(chomp_config cfg,
 
 // The interpolated integrand with the g table in LDS and k from exp (k_sigma_lns).
 struct SigmaInterpLds {
+  static constexpr bool kLaneMajor = true;   // (the six taps below: a gather from LDS at an index ~ ln k)
   const double* g;         // g / k^6 on the grid, in LDS (index 0 = first pad point)
   double xlo, dx, inv_dx, scale, nine_over_r6;
   bool tiny_r;

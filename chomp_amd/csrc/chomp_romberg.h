@@ -23,6 +23,8 @@
 // Nodes follow SciPy's formula lox + h*j with h = (b-a)/2^(i-1), lox = a + h/2.
 #pragma once
 
+#include <type_traits>
+
 #include <hip/hip_runtime.h>
 
 namespace chomp {
@@ -92,6 +94,11 @@ constexpr int romberg_scratch() {
 }
 
 namespace detail {
+// An integrand may declare `static constexpr bool kLaneMajor = true`: see romberg_wave6's level loop.
+template <class F, class = void>
+struct lane_major : std::false_type {};
+template <class F>
+struct lane_major<F, std::void_t<decltype(F::kLaneMajor)>> : std::bool_constant<F::kLaneMajor> {};
 // Integrands may take the node's (level, index-within-level) besides x, so that
 // table-driven integrands can look their node up; plain ones take (x, out).
 template <class F, int NF>
@@ -497,11 +504,27 @@ __device__ __forceinline__ RombergOut<NF> romberg_wave6(const F& f, double a, do
     double part[NF];
 #pragma unroll
     for (int q = 0; q < NF; ++q) part[q] = 0.0;
-    for (long j = lane; j < numtosum; j += 64) {
-      double w[NF];
-      detail::call_f<F, NF>(f, lox + h * (double)j, w, i, j, 0);
+    if constexpr (detail::lane_major<F>::value) {
+      // (an integrand that GATHERS from an LDS table at an index proportional to x: a lane
+      //  takes numtosum / 64 consecutive nodes, so that the lanes of a wavefront are a 64th of
+      //  the range apart at every level -- the same bank pattern as the first pass -- instead of
+      //  one node spacing apart, which at the deep levels is a few table entries: 4-8 lanes to
+      //  a bank)
+      const long per = numtosum >> 6;                      // (i > L0 = 6: numtosum >= 64)
+      for (long p = 0; p < per; ++p) {
+        const long j = (long)lane * per + p;
+        double w[NF];
+        detail::call_f<F, NF>(f, lox + h * (double)j, w, i, j, 0);
 #pragma unroll
-      for (int q = 0; q < NF; ++q) part[q] += w[q];
+        for (int q = 0; q < NF; ++q) part[q] += w[q];
+      }
+    } else {
+      for (long j = lane; j < numtosum; j += 64) {
+        double w[NF];
+        detail::call_f<F, NF>(f, lox + h * (double)j, w, i, j, 0);
+#pragma unroll
+        for (int q = 0; q < NF; ++q) part[q] += w[q];
+      }
     }
     all_done = true;
 #pragma unroll
@@ -529,6 +552,7 @@ __device__ __forceinline__ RombergOut<NF> romberg_wave6(const F& f, double a, do
 // Single-integrand convenience wrapper: F is double operator()(double).
 template <class F>
 struct Scalar1 {
+  static constexpr bool kLaneMajor = detail::lane_major<F>::value;
   const F& f;
   __device__ __forceinline__ void operator()(double x, double (&out)[1]) const {
     out[0] = f(x);

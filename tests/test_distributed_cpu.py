@@ -188,8 +188,11 @@ def test_bench_launches_its_own_ranks():
     import torch
     if torch.cuda.is_available():
         pytest.skip("CPU rehearsal of the launcher (on a GPU box bench.py itself is run)")
+    # (--no-cpu-baseline: rank 0 would otherwise time the oracle first, at every N, and be
+    #  torn down by the launcher when rank 1 fails meanwhile)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
-                        "--warmup", "0"], capture_output=True, text=True, timeout=300)
+                        "--warmup", "0", "--no-cpu-baseline"], capture_output=True, text=True,
+                       timeout=300)
     assert p.returncode != 0
     assert p.stderr.count("bench.py needs MI355X GPUs") >= 2, p.stderr[-2000:]
     assert "launch with torch.distributed.run" not in p.stderr

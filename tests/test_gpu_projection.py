@@ -118,9 +118,8 @@ def test_c5_precision_sweep(mods):
     """configs[4] "mixed fp32/fp64 with tolerance sweep" (SURVEY 8(d) C5): w_GGL(theta) with
     HaloFit power_gm in the four arithmetic modes against G7.  fp64 is held to the 1e-4
     bar; the narrowed modes are measured and only bounded loosely (they are not a product
-    path) -- the numbers land in gpurun_out/precision_sweep.json for DESIGN.md."""
-    import json
-    import os
+    path).  (The numbers kept under profiles/ come from tools/precision_sweep.py, run by
+    tools/profile_round.sh: a test leaves nothing in the tree it tests.)"""
     from chomp_amd import _lib
     cosmology, kernel, correlation, halo = mods
     g = load_golden("g7_ggl_halofit")
@@ -139,11 +138,6 @@ def test_c5_precision_sweep(mods):
         ctx.set_precision(_lib.PREC_F64)
     with pytest.raises(ValueError):
         ctx.set_precision(7)
-    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
-    os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "precision_sweep.json"), "w") as fh:
-        json.dump({"case": "G7 w_GGL(theta), 33 theta, HaloFit power_gm, J2 kernel",
-                   "max_rel_err_vs_reference": errs}, fh, indent=1)
     print("precision sweep:", errs)
     assert errs["fp64"] < PROJ_RTOL
     # measured on MI355X (profiles/round1_c5_precision_sweep.json): fp64 7e-12, fp32 tables

@@ -845,3 +845,104 @@ def test_many_cosmologies_in_one_batch_equal_single_epochs():
         assert numpy.array_equal(one.ctx.table("ln_mass", 0), big.ctx.table("ln_mass", i))
         assert numpy.max(numpy.abs(one.ctx.table("nu", 0) / big.ctx.table("nu", i) - 1)) < 1e-12, i
         assert numpy.max(numpy.abs(p_one / p_big[i] - 1)) < 1e-12, i
+
+
+def test_large_batch_shapes_vs_oracle():
+    """The launch shapes only a large batch takes -- from 16 distinct cosmologies on
+    k_sigma_nodes<., 4> + k_sigma_lns (cosmology-only tables without arrival counts, sigma_8
+    and the aiming table behind the kernel boundary), from 128 epochs on k_epoch_probe<., 1>
+    + <., 2> (probes, then their certification as a launch of its own), single-wavefront knot
+    blocks -- pinned DIRECTLY to the oracle, not to the device's own single-epoch answer:
+    eight epochs of a 144-epoch design (the consumer: simulation_design.py:116-155) against
+    oracle.chomp_oracle -- the ln M limits of the mass function bit for bit wherever the
+    status word does not flag a saturated search, sigma_norm, the nu table and P_mm(k) to 1e-7."""
+    from chomp_amd import grid, _lib
+    from oracle import chomp_oracle as o
+    rng = numpy.random.default_rng(404)
+    base = dict(o.default_cosmo_dict)
+    n, n_cosmo = 144, 24
+    pool = []
+    for _ in range(n_cosmo):
+        om = rng.uniform(0.25, 0.33)
+        pool.append(dict(base, omega_m0=om - base["omega_r0"], omega_l0=1.0 - om,
+                         omega_b0=rng.uniform(0.04, 0.05), h=rng.uniform(0.66, 0.74),
+                         sigma_8=rng.uniform(0.77, 0.86), n_scalar=rng.uniform(0.94, 0.99)))
+    cds = [pool[i % n_cosmo] for i in range(n)]          # every cosmology at six redshifts
+    zs = [float(z) for z in rng.uniform(0.0, 1.3, n)]
+    k = numpy.logspace(-3, 2, 48)
+    big = grid.HaloGrid(numpy.array(zs), cosmo_dict=cds)
+    p_big = big.power("power_mm", k)
+    status = big.status()
+    n_exact = 0
+    for i in (0, 5, 23, 24, 71, 100, 127, 143):
+        e = o.epoch(cds[i], zs[i])
+        lo, hi, _ = o.mass_limits(e)
+        sc = big.ctx.scalars(i)
+        flagged = bool(status[i] & (_lib.ST_SATURATED | _lib.ST_MASS_SEARCH_EXHAUSTED))
+        if not flagged:
+            assert sc["ln_mass_min"] == lo and sc["ln_mass_max"] == hi, (i, zs[i])
+            n_exact += 1
+        m = o.mass_table(e)
+        assert abs(sc["sigma_norm"] / e.sigma_norm - 1) < 1e-9, i
+        if not flagged:
+            assert numpy.max(numpy.abs(big.ctx.table("nu", i) / m.nu_arr - 1)) < 1e-7, i
+            t = o.halo_table(e, m, families=("mm",))
+            ref = o.halo_power(t, "mm", k)
+            ok = ref > 0
+            assert numpy.max(numpy.abs(p_big[i][ok] / ref[ok] - 1)) < 1e-7, (i, zs[i])
+            assert numpy.array_equal(p_big[i][~ok], ref[~ok])
+    assert n_exact >= 6
+
+
+def test_soak_seed_flag_iff_mismatch():
+    """One seed of tools/soak.py as a test: random cosmologies, HODs and redshifts, device
+    P_mm (and P_gm for the first few) against the oracle.  Every epoch the status word does
+    not flag agrees to 1e-7 -- and a saturated mass-limit search, the one documented limit of
+    parity (the reference's own answer is decided by rounding noise there), is FLAGGED: flag <=>
+    the oracle's walk ends in that regime too."""
+    from chomp_amd import grid, _lib
+    from oracle import chomp_oracle as o
+    rng = numpy.random.default_rng(7)
+    n, n_gm = 16, 2
+    k = numpy.logspace(-3, 2, 40)
+    cos, zs, hods = [], [], []
+    for i in range(n):
+        c = dict(o.default_cosmo_dict)
+        c["omega_m0"] = rng.uniform(0.2, 0.4) - c["omega_r0"]
+        c["omega_l0"] = 1.0 - c["omega_m0"] - c["omega_r0"]
+        c["omega_b0"] = rng.uniform(0.035, 0.055)
+        c["h"] = rng.uniform(0.6, 0.8)
+        c["sigma_8"] = rng.uniform(0.7, 0.9)
+        c["n_scalar"] = rng.uniform(0.92, 1.0)
+        cos.append(c)
+        zs.append(float(rng.uniform(0.0, 1.5)))
+        h = dict(o.default_hod_dict)
+        h["log_M_min"] = rng.uniform(11.8, 12.6)
+        h["log_M_0"] = h["log_M_min"]
+        h["sigma"] = rng.uniform(0.1, 0.4)
+        h["log_M_1p"] = h["log_M_min"] + rng.uniform(1.0, 1.5)
+        hods.append(h)
+    g = grid.HaloGrid(numpy.array(zs), cosmo_dict=cos, hod_dict=hods)
+    pm = g.power("power_mm", k)
+    status = g.status()
+    pg = g.power("power_gm", k)
+    n_flagged = 0
+    for i in range(n):
+        e = o.epoch(cos[i], zs[i])
+        lo, _, _ = o.mass_limits(e)
+        R = (3.0 * numpy.exp(lo) / (4.0 * numpy.pi * o.rho_bar(e))) ** (1.0 / 3.0)
+        saturated = 100.0 * e.limits["k_max"] * R < 0.2
+        flagged = bool(status[i] & (_lib.ST_SATURATED | _lib.ST_MASS_SEARCH_EXHAUSTED))
+        assert flagged == bool(saturated), (i, zs[i], int(status[i]))
+        if flagged:
+            n_flagged += 1
+            continue
+        fam = ("mm", "gm") if i < n_gm else ("mm",)
+        tb = o.halo_table(e, o.mass_table(e), o.zheng(hods[i]), families=fam)
+        ref = o.halo_power(tb, "mm", k)
+        ok = ref > 0
+        assert numpy.max(numpy.abs(pm[i][ok] / ref[ok] - 1)) < 1e-7, (i, zs[i])
+        if i < n_gm:
+            refg = o.halo_power(tb, "gm", k)
+            assert numpy.max(numpy.abs(pg[i][ok] / refg[ok] - 1)) < 1e-7, (i, zs[i])
+    assert n_flagged <= 3

@@ -5,7 +5,7 @@ roofline_stage_k reads) from the SQ counter passes.
 import json, os, shutil, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "round3"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "round4"
 src, dst = os.path.join(R, "gpurun_out", tag), os.path.join(R, "profiles")
 STAGE_K = ("k_sigma_nodes", "k_sigma_lns", "k_epoch_probe", "k_nu_table", "k_mass_nodes", "k_halo_nodes",
            "k_halo_knots", "k_halo_knots_fast", "k_halo_knots_literal")
@@ -38,6 +38,8 @@ json.dump(out, open(os.path.join(dst, rnd + "_stage_k_counters.json"), "w"), ind
 for f in ("stage_e_fetch_counter_collection.csv", "stage_e_write_counter_collection.csv"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, rnd + "_pmc", f))
+if os.path.exists(os.path.join(src, "c5_precision_sweep.json")):
+    shutil.copy(os.path.join(src, "c5_precision_sweep.json"), os.path.join(dst, rnd + "_c5_precision_sweep.json"))
 if os.path.exists(os.path.join(src, "stage_e_pmc.json")):
     shutil.copy(os.path.join(src, "stage_e_pmc.json"), os.path.join(dst, "stage_e_pmc.json"))
 log = os.path.join(R, "gpurun_out", tag + ".log")

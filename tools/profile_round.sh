@@ -37,6 +37,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch --
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/tools/pmc_stage_e.py > $O/pmc_write.log 2>&1 || { echo "pmc write failed"; exit 1; }
 cd $R
 python3 tools/pmc_parse.py $O/pmc_fetch $O/pmc_write $O/stage_e_pmc.json > $O/pmc_parse.log 2>&1
+python3 tools/precision_sweep.py > $O/c5_precision_sweep.json 2> $O/precision_sweep.err || { echo "precision sweep failed"; exit 1; }
 cp $O/pmc_fetch/*/*counter_collection.csv $O/stage_e_fetch_counter_collection.csv 2>/dev/null
 cp $O/pmc_write/*/*counter_collection.csv $O/stage_e_write_counter_collection.csv 2>/dev/null
 python3 - <<PY
