@@ -924,13 +924,15 @@ static int launch_halo_knots(chomp_ctx* ctx, const HaloPlan& P) {
   size_t shf = deep_fast_lds<kDeepCoarse>(L.NM, ctx->cfg.divmax);
   if (shf < (size_t)finalize_lds_doubles(L.NK) * sizeof(double))
     shf = (size_t)finalize_lds_doubles(L.NK) * sizeof(double);
-#define CHOMP_KNOTS_FAST(NT, SELF, EVAL, GRID, ROUND, LO, HI, FROM)                                         \
-  hipLaunchKernelGGL((k_halo_knots_fast<kDeepCoarse, NT, SELF, EVAL>), dim3(GRID), dim3(NT), shf, ctx->stream, \
+#define CHOMP_KNOTS_FAST(NT, SELF, EVAL, GRID, ROUND, LO, HI, FROM) \
+  CHOMP_KNOTS_FAST_L(NT, SELF, EVAL, false, GRID, ROUND, LO, HI, FROM)
+#define CHOMP_KNOTS_FAST_L(NT, SELF, EVAL, LIT, GRID, ROUND, LO, HI, FROM)                                         \
+  hipLaunchKernelGGL((k_halo_knots_fast<kDeepCoarse, NT, SELF, EVAL, LIT>), dim3(GRID), dim3(NT), shf, ctx->stream, \
                      ctx->cfg, L, ctx->d_epochs, ctx->d_tab, ctx->d_sici, P.groups[0], P.groups[1], \
                      P.groups[2], P.kmask, (int)n, ctx->d_pending, ctx->d_npend, ctx->d_epochs,     \
                      P.fam, ctx->d_status, ctx->d_deepw, all_literal, deep_tol, max_rough, max_fine, \
                      ctx->d_deepstat, ctx->d_samples, ctx->d_psum, parts, ROUND, LO, HI, FROM,      \
-                     reinterpret_cast<const DeepPlan*>(ctx->d_plan))
+                     reinterpret_cast<const DeepPlan*>(ctx->d_plan), ctx->d_profile, ctx->d_hod)
 #define CHOMP_KNOTS_SAMPLES(GRID, LO, HI)                                                        \
   hipLaunchKernelGGL((k_halo_knots_samples<kDeepCoarse>), dim3(GRID), dim3(256), 0, ctx->stream,   \
                      ctx->cfg, L, ctx->d_sici, P.groups[0], P.groups[1], P.groups[2], P.kmask,      \
@@ -951,6 +953,9 @@ static int launch_halo_knots(chomp_ctx* ctx, const HaloPlan& P) {
       CHOMP_LDS_OPT_IN(kDeepThreads, false, false);
       CHOMP_LDS_OPT_IN(kDeepThreadsFew, false, true);
       CHOMP_LDS_OPT_IN(kDeepThreads, false, true);
+      HIPCHK(hipFuncSetAttribute(
+          reinterpret_cast<const void*>(&k_halo_knots_fast<kDeepCoarse, kDeepThreadsFew, false, true, true>),
+          hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
       CHOMP_LDS_OPT_IN(kDeepThreadsFew, true, true);
       CHOMP_LDS_OPT_IN(kDeepThreads, true, true);
 #undef CHOMP_LDS_OPT_IN
@@ -978,27 +983,27 @@ static int launch_halo_knots(chomp_ctx* ctx, const HaloPlan& P) {
         if (few) CHOMP_KNOTS_FAST(kDeepThreadsFew, false, true, g, r, lo, hi, 0);
         else CHOMP_KNOTS_FAST(kDeepThreads, false, true, g, r, lo, hi, 0);
       } else {
-        // (the lean instance, and behind it the evaluating one for the knots it hands on)
-        const unsigned ge = g < 256u ? g : 256u;
-        if (few) {
-          CHOMP_KNOTS_FAST(kDeepThreadsFew, false, false, g, r, lo, hi, 0);
-          CHOMP_KNOTS_FAST(kDeepThreadsFew, false, true, ge, r, lo, hi, 1);
-        } else {
-          // (the handed-on knots are few and long -- node-by-node intervals: 512 threads each)
-          CHOMP_KNOTS_FAST(kDeepThreads, false, false, g, r, lo, hi, 0);
-          CHOMP_KNOTS_FAST(kDeepThreadsFew, false, true, ge, r, lo, hi, 1);
-        }
+        // (the lean instance, and behind it ONE launch for what it hands on: the knots that
+        //  need node evaluations -- few and long: 512 threads each -- and, in the last round,
+        //  those that go to the literal evaluation)
+        const bool last_round = r == rounds - 1;
+        const unsigned ge = all_literal ? g : (g < 256u ? g : 256u);
+        if (few) CHOMP_KNOTS_FAST(kDeepThreadsFew, false, false, g, r, lo, hi, 0);
+        else CHOMP_KNOTS_FAST(kDeepThreads, false, false, g, r, lo, hi, 0);
+        if (last_round) CHOMP_KNOTS_FAST_L(kDeepThreadsFew, false, true, true, ge, r, lo, hi, 1);
+        else CHOMP_KNOTS_FAST(kDeepThreadsFew, false, true, ge, r, lo, hi, 1);
       }
     }
   }
   // knots can only be handed on when some HOD Romberg may run beyond the node tables
-  if (deep_route) {
+  if (deep_route && P.eval) {       // (alpha != 1: no launch behind the fast sums that could take the list)
     const size_t shl = deep_literal_lds(L.NM, L.NK);
     // (an empty list is the rule: few blocks, each returns after one read)
     const unsigned gl = all_literal ? gd : (gd < 256u ? gd : 256u);
     if (few) CHOMP_KNOTS_LITERAL(kDeepThreadsFew, gl); else CHOMP_KNOTS_LITERAL(kDeepThreads, gl);
   }
 #undef CHOMP_KNOTS_FAST
+#undef CHOMP_KNOTS_FAST_L
 #undef CHOMP_KNOTS_SAMPLES
 #undef CHOMP_KNOTS_LITERAL
   HIPCHK(hipGetLastError());

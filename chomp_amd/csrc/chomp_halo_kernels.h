@@ -1562,8 +1562,16 @@ __device__ __forceinline__ void deep_arrive(const chomp_config& cfg, const TabLa
 // knots) on to a second launch of the EVAL instance behind it (from_eval: that launch draws
 // the list positions the lean one left at pending_eval_base(); the knots' samples are still
 // in their slots).
+template <int NT>
+__device__ __forceinline__ void deep_literal_loop(
+    chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs, double* __restrict__ tab,
+    const chomp_halo_par* __restrict__ profile, const HodDev* __restrict__ hod,
+    const SiCiTab* __restrict__ sici_g, int g0, int g1, int g2, unsigned mask, int n_epoch,
+    int* __restrict__ pending, int* __restrict__ npend, Epoch* __restrict__ epochs_rw,
+    unsigned fam_mask, unsigned* __restrict__ status, int* __restrict__ stats);
+
 template <int LC, int NT, bool SELF, bool EVAL>
-__global__ __launch_bounds__(NT, SELF ? 1 : ((!EVAL && NT == 256) ? 3 : 512 / NT)) void k_halo_knots_fast(
+__device__ __forceinline__ void deep_fast_body(
     chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs, double* __restrict__ tab,
     const SiCiTab* __restrict__ sici_g, int g0, int g1, int g2, unsigned mask, int n_epoch,
     int* __restrict__ pending, int* __restrict__ npend, Epoch* __restrict__ epochs_rw,
@@ -2041,13 +2049,37 @@ __global__ __launch_bounds__(NT, SELF ? 1 : ((!EVAL && NT == 256) ? 3 : 512 / NT
   }   // next item
 }
 
+// LIT: the instance also works off the list of knots handed on to the literal evaluation
+// (deep_literal_loop) once its own list is empty -- the launch behind the lean instance does
+// both, so that the chain carries one near-empty launch behind the fast sums, not two.
+template <int LC, int NT, bool SELF, bool EVAL, bool LIT = false>
+__global__ __launch_bounds__(NT, SELF ? 1 : ((!EVAL && NT == 256) ? 3 : 512 / NT)) void k_halo_knots_fast(
+    chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs, double* __restrict__ tab,
+    const SiCiTab* __restrict__ sici_g, int g0, int g1, int g2, unsigned mask, int n_epoch,
+    int* __restrict__ pending, int* __restrict__ npend, Epoch* __restrict__ epochs_rw,
+    unsigned fam_mask, unsigned* __restrict__ status, const double* __restrict__ deepw,
+    int all_literal, double tol, int max_rough, int max_fine, int* __restrict__ stats,
+    const double* __restrict__ samples, const double* __restrict__ psum, int parts,
+    int round, int slot_lo, int slot_hi, int from_eval, const DeepPlan* __restrict__ plans,
+    const chomp_halo_par* __restrict__ profile, const HodDev* __restrict__ hod) {
+  deep_fast_body<LC, NT, SELF, EVAL>(cfg, L, epochs, tab, sici_g, g0, g1, g2, mask, n_epoch, pending,
+                                     npend, epochs_rw, fam_mask, status, deepw, all_literal, tol,
+                                     max_rough, max_fine, stats, samples, psum, parts, round,
+                                     slot_lo, slot_hi, from_eval, plans);
+  if constexpr (LIT) {
+    __syncthreads();
+    deep_literal_loop<NT>(cfg, L, epochs, tab, profile, hod, sici_g, g0, g1, g2, mask, n_epoch,
+                          pending, npend, epochs_rw, fam_mask, status, stats);
+  }
+}
+
 // The knots k_halo_knots_fast handed on (pending[4] of them, behind pending_literal_base):
 // every node of scipy's Romberg evaluated (deep_literal) -- the checker of the fast path and
 // its fallback.  grid: any (blocks draw from the list), block NT.  Launched behind
 // k_halo_knots_fast whenever knots can be listed at all; with an empty list (the rule) every
 // block returns after one read.
 template <int NT>
-__global__ __launch_bounds__(NT) void k_halo_knots_literal(
+__device__ __forceinline__ void deep_literal_loop(
     chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs, double* __restrict__ tab,
     const chomp_halo_par* __restrict__ profile, const HodDev* __restrict__ hod,
     const SiCiTab* __restrict__ sici_g, int g0, int g1, int g2, unsigned mask, int n_epoch,
@@ -2095,6 +2127,17 @@ __global__ __launch_bounds__(NT) void k_halo_knots_literal(
     }
     deep_arrive(cfg, L, epochs_rw, tab, e, fam_mask, status, npend, true, &last_sh, sm);
   }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_halo_knots_literal(
+    chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs, double* __restrict__ tab,
+    const chomp_halo_par* __restrict__ profile, const HodDev* __restrict__ hod,
+    const SiCiTab* __restrict__ sici_g, int g0, int g1, int g2, unsigned mask, int n_epoch,
+    int* __restrict__ pending, int* __restrict__ npend, Epoch* __restrict__ epochs_rw,
+    unsigned fam_mask, unsigned* __restrict__ status, int* __restrict__ stats) {
+  deep_literal_loop<NT>(cfg, L, epochs, tab, profile, hod, sici_g, g0, g1, g2, mask, n_epoch,
+                        pending, npend, epochs_rw, fam_mask, status, stats);
 }
 
 }  // namespace chomp

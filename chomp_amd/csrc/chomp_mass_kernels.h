@@ -582,6 +582,7 @@ __global__ __launch_bounds__(kLnsThreads) void k_sigma_lns(chomp_config cfg,
       SigmaInterpLds f{gl, xlo, dx, 1.0 / dx, R, 9.0 / (r3 * r3), 100.0 * E.k_max * R < 1.0};
       if (dmax >= 6) {             // levels 0..6 in one pass (seven dependent round trips less)
         Scalar1<SigmaInterpLds> w{f};
+        static_assert(detail::lane_major<Scalar1<SigmaInterpLds>>::value, "lane-major level loop");
         const double fb[1] = {f(hi)};
         s2 = romberg_wave6<1>(w, lo, hi, fb, cfg.global_precision, 1e-5, dmax).value[0];
       } else {
@@ -786,7 +787,7 @@ __device__ __noinline__ double nu_probe(const Epoch& E, const double* snode, dou
                                            double thr_hi, double* red) {
   // (a cosmo_precision looser than the probe tolerance is used as it is: the reference's
   // decision rests on exactly that integral)
-  const double kAmbiguous = 2e-5;
+  const double kAmbiguous = 2e-5;    // (4e-6 measured: no probe of configs[1] falls in either window)
   const double rtol_probe = 1e-6;
   if (!(cfg.cosmo_precision < rtol_probe))
     return nu_of_mass_block<NW, 1, BAO>(E, snode, m, cfg, cfg.cosmo_precision, red);

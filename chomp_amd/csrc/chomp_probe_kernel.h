@@ -8,7 +8,8 @@ namespace chomp {
 
 // grid (n_epoch, 2 * kProbes), block 64 * kInitNW.  blockIdx.y = kProbes * side + p
 // certifies candidate j - 2 + p of side 0 (mass_min) / 1 (mass_max); role kProbes also
-// does the comoving distance (or only that, with fixed mass limits).  The last block of
+// does the comoving distance (or only that, with fixed mass limits; a ninth block per epoch
+// for it was measured: 576 blocks for 512 resident ones, 34.1 against 32.8 us).  The last block of
 // an epoch to finish combines the results (count[e], reset by it): a side whose probes
 // show "fails at c - 1, passes at c" is settled; any other (the estimate off by more than
 // the probes cover, a walk that leaves the ln S table: rare) falls back to the bracketing
@@ -104,14 +105,22 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_probe(
     __syncthreads();
     PSTAMP(5);
     if (!last) return;
-    __threadfence();
+    // (no fence on this side: everything the last block reads of the others -- the probe record
+    //  -- is read with agent-scope loads, issued behind the arrival count's return)
   }
-  // ---- last block of the epoch: certify both sides (thread 0: scalar logic on 8 numbers)
-  if (threadIdx.x == 0) {
-    auto peek = [](const double* q) {
-      return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    for (int sd = 0; sd < 2; ++sd) {
+  // ---- last block of the epoch: certify both sides (thread 0: scalar logic on 8 numbers).
+  // The epoch's probe record -- written by the other seven blocks -- is fetched by 24 lanes at
+  // once, one agent-scope load each, and the logic reads the copy in LDS: read where they are
+  // used, the ~20 loads were a chain of dependent round trips, 9 of the launch's 38 us
+  // (tools/dev_probe_stamps4.py: arrival at 25 us, end at 34.5).
+  __shared__ double rec[kProbeStride];
+  if (threadIdx.x < kProbeStride)
+    rec[threadIdx.x] = __hip_atomic_load(pr + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (threadIdx.x < 2) {           // (the two sides side by side: lane 0 mass_min, lane 1 mass_max)
+    auto peek = [&](const double* q) { return rec[q - pr]; };
+    {
+      const int sd = (int)threadIdx.x;
       const double* pl = pr + 2 * kProbes + 4 + 4 * sd;
       const double mode = peek(pl);
       const bool ok = mode != 0.0, at_edge = mode == 2.0;
@@ -188,8 +197,10 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_probe(
         if (st) atomicOr(&status[e], st);
       }
     }
-    E.chi = peek(pr + 2 * kProbes);
-    if (PHASE == 0) count[e] = 0;
+    if (threadIdx.x == 0) {
+      E.chi = peek(pr + 2 * kProbes);
+      if (PHASE == 0) count[e] = 0;
+    }
   }
   __syncthreads();
   for (int sd = 0; sd < 2; ++sd) {

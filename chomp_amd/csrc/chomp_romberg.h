@@ -455,37 +455,74 @@ __device__ __forceinline__ RombergOut<NF> romberg_wave6(const F& f, double a, do
     }
     detail::call_f<F, NF>(f, x, v, lev, j, 0);
   }
-  // C_s = sum of the interior nodes at multiples of s; level l (stride s = N0 >> l) sums to
-  // C_s - C_2s.  One xor butterfly leaves C_32 .. C_1 in lane 0 on the way.
+  // The sums of levels 1..6: level l is the lanes whose lowest set bit is 2^(6 - l) (lane 32;
+  // 16 and 48; ...; the odd lanes).  Inside a row of 16 lanes by DPP (three adds), the four rows
+  // through v_readlane -- the xor butterfly this replaces took six dependent ds_bpermute round
+  // trips per integrand (the sums then came out as differences of nested partial sums).
   double n = 1.0;
 #pragma unroll
   for (int q = 0; q < NF; ++q) {
-    double C[7];                                         // C[st] = C_(32 >> st); C[6]: dummy
-    double x = (lane > 0 && lane < N0) ? v[q] : 0.0;
-#pragma unroll
-    for (int st = 0; st < 6; ++st) {
-      x += dpp_or_shfl_xor(x, 32 >> st);
-      C[st] = readlane_d(x, 0);
+    double Ls[L0max + 1];
+    {
+      const double x0 = lane > 0 ? v[q] : 0.0;                   // (lane 0: the lower end point)
+      const double x8 = x0 + dpp_move<0x128>(x0);                // lanes {i, i + 8} of a row
+      const double x4 = x8 + dpp_move<0x124>(x8);                // = mod 4
+      const double x2 = x4 + dpp_move<0x4E>(x4);                 // = mod 2
+      Ls[6] = (readlane_d(x2, 1) + readlane_d(x2, 17)) + (readlane_d(x2, 33) + readlane_d(x2, 49));
+      Ls[5] = (readlane_d(x4, 2) + readlane_d(x4, 18)) + (readlane_d(x4, 34) + readlane_d(x4, 50));
+      Ls[4] = (readlane_d(x8, 4) + readlane_d(x8, 20)) + (readlane_d(x8, 36) + readlane_d(x8, 52));
+      Ls[3] = (readlane_d(x0, 8) + readlane_d(x0, 24)) + (readlane_d(x0, 40) + readlane_d(x0, 56));
+      Ls[2] = readlane_d(x0, 16) + readlane_d(x0, 48);
+      Ls[1] = readlane_d(x0, 32);
     }
-    C[6] = 0.0;
     ordsum[q] = 0.5 * (readlane_d(v[q], 0) + fb[q]);
     out.value[q] = intrange * ordsum[q];
     out.level[q] = 0;
     prev[q] = out.value[q];
     Tl[q] = (lane == 0) ? out.value[q] : 0.0;
     done[q] = false;
-    // rows 1..L0 of this integrand (the integrands are independent: replaying one after the
-    // other visits the same rows as interleaving them)
+    // rows 1..L0 of this integrand: lane l forms T_l from the running sum of the level sums
+    // (Ls[i], above), the L0
+    // extrapolations R[i][i] are taken back to back -- they do not depend on each other; row
+    // by row each waited for the butterfly of the one before, six round trips per integrand in
+    // front of every integral's first deeper level -- and only the stopping test walks through
+    // them in order.  Same operations on the same operands as the row-by-row replay.
     double nq = 1.0;
+    {
+      double os = ordsum[q], mine = ordsum[q], pw = 1.0, mypw = 1.0;
+      double osum[L0max + 1];
+      osum[0] = os;
 #pragma unroll
-    for (int i = 1; i <= L0max; ++i) {
-      if (!done[q]) {
-        nq *= 2.0;
-        // level i: stride 64 >> i = 32 >> (i - 1), i.e. C[i - 1] - C[i - 2] (C_64 = 0)
-        const double Cs = C[i - 1];
-        const double C2s = i >= 2 ? C[i - 2] : 0.0;
-        advance(q, i, Cs - C2s, nq, crow[i]);
+      for (int i = 1; i <= L0max; ++i) {
+        os += Ls[i];
+        osum[i] = os;
+        pw *= 2.0;
+        if (i <= lane) { mine = os; mypw = pw; }
       }
+      const double T = lane <= L0max ? intrange * mine / mypw : 0.0;
+      double cur[L0max + 1];
+#pragma unroll
+      for (int i = 1; i <= L0max; ++i) cur[i] = wave_sum(lane <= i ? crow[i] * T : 0.0);
+      int stop = 0;
+#pragma unroll
+      for (int i = 1; i <= L0max; ++i) {
+        if (!done[q]) {
+          nq *= 2.0;
+          const double err = fabs(cur[i] - prev[q]);
+          prev[q] = cur[i];
+          out.value[q] = cur[i];
+          out.level[q] = i;
+          stop = i;
+          if (err < tol || err < rtol * fabs(cur[i])) done[q] = true;
+        }
+      }
+      // (the state the row-by-row replay leaves: the sums and T_l up to the row reached)
+      double upto = osum[0];
+#pragma unroll
+      for (int i = 1; i <= L0max; ++i)
+        if (i == stop) upto = osum[i];
+      ordsum[q] = upto;
+      Tl[q] = lane <= stop ? T : 0.0;
     }
     n = nq > n ? nq : n;
   }
