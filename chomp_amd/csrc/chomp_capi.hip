@@ -168,10 +168,15 @@ struct chomp_ctx {
   // nothing w(theta) produces: they run here, beside the context's stream, ordered against it
   // by events -- behind everything queued on `stream` when they start, and joined back before
   // anything reads what they wrote (proj_pending: lazily, at the next call that looks at the
-  // projection tables).  Never while `stream` is being captured.
+  // projection tables).  Under stream capture the fork and the join are captured with the rest
+  // (the side stream joins the capture through ev_side_go and is joined back before the
+  // capture ends: every call that forks also joins, the lazy projection join at the first
+  // reader); what must not happen is a join, inside a capture, of side work queued before it.
   hipStream_t side = nullptr;
   hipEvent_t ev_side_go = nullptr, ev_proj_ready = nullptr, ev_side_done = nullptr;
   bool proj_pending = false;
+  bool proj_pending_captured = false;   // ... and it was queued inside the capture in progress
+  bool status_posted_in_capture = false;   // the post is a graph node: no event to wait for
 };
 
 namespace {
@@ -266,9 +271,16 @@ struct SideScope {
   hipStream_t saved = nullptr;
   hipEvent_t* done;                // (a member of *ctx: the events are created by begin())
   bool active = false;
-  SideScope(chomp_ctx* c, hipEvent_t* done_) : ctx(c), done(done_) {}
+  bool marks_proj;                 // the work is a projection set-up: proj_pending on EVERY way out
+  SideScope(chomp_ctx* c, hipEvent_t* done_, bool marks_proj_ = false)
+      : ctx(c), done(done_), marks_proj(marks_proj_) {}
   int begin() {
-    if (capturing(ctx)) return CHOMP_OK;
+    // (the side stream and its events exist before any capture: an eager call of the same kind
+    //  comes first -- buffers and parameters have to be in place for a capture anyway)
+    if (capturing(ctx) && !ctx->side)
+      return fail(ctx, CHOMP_ERR_STATE,
+                  "the first call that runs work beside the context's stream came while the stream "
+                  "is being captured: run the step once eagerly before capturing it");
     const int rc = side_create(ctx);
     if (rc) return rc;
     HIPCHK(hipEventRecord(ctx->ev_side_go, ctx->stream));
@@ -282,6 +294,10 @@ struct SideScope {
   void end() {
     if (!active) return;
     (void)hipEventRecord(*done, ctx->side);
+    if (marks_proj) {              // (also on an error return: what was queued is still in flight)
+      ctx->proj_pending = true;
+      ctx->proj_pending_captured = capturing(ctx);
+    }
     ctx->stream = saved;
     active = false;
   }
@@ -292,12 +308,14 @@ struct SideScope {
 // a projection set-up still in flight on the side stream.
 int proj_join(chomp_ctx* ctx) {
   if (!ctx->proj_pending) return CHOMP_OK;
-  if (capturing(ctx))
+  if (capturing(ctx) && !ctx->proj_pending_captured)
     return fail(ctx, CHOMP_ERR_STATE,
-                "a projection set-up is still in flight beside the stream being captured: make "
-                "any projection call (or chomp_sync) before the capture begins");
-  HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_proj_ready, 0));
+                "a projection set-up queued BEFORE the capture is still in flight beside the "
+                "stream being captured: make any projection call (or chomp_sync) before the "
+                "capture begins");
+  HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_proj_ready, 0));   // (captured under capture)
   ctx->proj_pending = false;
+  ctx->proj_pending_captured = false;
   return CHOMP_OK;
 }
 
@@ -640,7 +658,11 @@ int chomp_status_post(chomp_ctx* ctx) {
   if (!ctx) return CHOMP_ERR_ARG;
   if (!ctx->have_epochs) return fail(ctx, CHOMP_ERR_STATE, "status_post before epochs_set");
   HIPCHK(hipSetDevice(ctx->device));
-  if (capturing(ctx)) return fail(ctx, CHOMP_ERR_STATE, "status_post during stream capture");
+  const bool cap = capturing(ctx);
+  if (cap && (ctx->n_epoch > ctx->cap_hstatus || !ctx->h_status || !ctx->ev_status))
+    return fail(ctx, CHOMP_ERR_STATE,
+                "status_post during stream capture before any eager post of this size (the "
+                "pinned words would have to be allocated)");
   if (ctx->n_epoch > ctx->cap_hstatus || !ctx->h_status) {
     if (ctx->ev_status) HIPCHK(hipEventSynchronize(ctx->ev_status));   // (a copy may be in flight)
     if (ctx->h_status) HIPCHK(hipHostFree(ctx->h_status));
@@ -652,7 +674,10 @@ int chomp_status_post(chomp_ctx* ctx) {
   if (!ctx->ev_status) HIPCHK(hipEventCreateWithFlags(&ctx->ev_status, hipEventDisableTiming));
   HIPCHK(hipMemcpyAsync(ctx->h_status, ctx->d_status, ctx->n_epoch * sizeof(unsigned),
                         hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipEventRecord(ctx->ev_status, ctx->stream));
+  // (under capture the copy is a node of the graph: every replay posts the words, and whoever
+  //  looks at them waits for the stream the graph was launched on, not for an event)
+  if (!cap) HIPCHK(hipEventRecord(ctx->ev_status, ctx->stream));
+  ctx->status_posted_in_capture = cap;
   ctx->n_hstatus = ctx->n_epoch;
   return CHOMP_OK;
 }
@@ -662,7 +687,12 @@ int chomp_status_wait(chomp_ctx* ctx, size_t epoch0, size_t n, unsigned* out) {
   if (!ctx->n_hstatus) return fail(ctx, CHOMP_ERR_STATE, "status_wait before status_post");
   if (epoch0 + n > ctx->n_hstatus) return fail(ctx, CHOMP_ERR_ARG, "status_wait: epoch range");
   HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipEventSynchronize(ctx->ev_status));
+  if (capturing(ctx))
+    return fail(ctx, CHOMP_ERR_STATE,
+                "status_wait while the context's stream is being captured (a wait on the host "
+                "cannot be part of a graph): look at the status before the capture or after a replay");
+  if (ctx->status_posted_in_capture) HIPCHK(hipStreamSynchronize(ctx->stream));
+  else HIPCHK(hipEventSynchronize(ctx->ev_status));
   std::memcpy(out, ctx->h_status + epoch0, n * sizeof(unsigned));
   return CHOMP_OK;
 }

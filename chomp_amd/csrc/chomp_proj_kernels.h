@@ -86,16 +86,20 @@ struct ProjState {
   ProjLayout L;
   ProjDev host;            // host copy of the scalars (refreshed by kernel_info)
   ProjDev* d_pd = nullptr;
+  ProjDev* d_pd_init = nullptr;   // the block as the host prepared it (the device fills d_pd in)
   double* d_tab = nullptr;
   size_t cap_tab = 0;      // doubles allocated at d_tab
+  size_t pp_total = 0;     // doubles of tabulated redshift distributions behind the tables
   bool cov_ready = false;  // covariance table (chomp_covariance_table) valid
   double* d_cov = nullptr;
 };
 inline void proj_free(ProjState& p) {
   if (p.d_pd) (void)hipFree(p.d_pd);
+  if (p.d_pd_init) (void)hipFree(p.d_pd_init);
   if (p.d_tab) (void)hipFree(p.d_tab);
   if (p.d_cov) (void)hipFree(p.d_cov);
   p.d_pd = nullptr;
+  p.d_pd_init = nullptr;
   p.d_tab = nullptr;
   p.d_cov = nullptr;
   p.ready = false;

@@ -93,9 +93,16 @@ class Halo(object):
         the saturated mass-limit search (include/chomp_mi355x.h, chomp_get_status).  Waits for
         that copy, not for work enqueued after it."""
         if self._status_pending and self._ctx is not None:
+            try:
+                word = int(self._ctx.warn_status(0, 1, stacklevel=stacklevel, posted=True)[0])
+            except _lib.ChompError as exc:
+                # (the context's stream is being captured into a HIP graph: the host cannot wait
+                #  inside a capture -- the word stays pending and is read after a replay)
+                if "captured" not in str(exc):
+                    raise
+                return self._status_word
             self._status_pending = False
-            self._status_word = int(
-                self._ctx.warn_status(0, 1, stacklevel=stacklevel, posted=True)[0])
+            self._status_word = word
         return self._status_word
 
     status = property(lambda self: self._resolve_status())

@@ -318,3 +318,59 @@ def test_wtheta_and_cell_in_one_call(mods, ggl):
     if not ggl:        # (G7b's HaloFit was first evaluated at z = 0; this one at z_bar)
         wf, cf_ = ctx.wtheta_cell(code, 0, corr._k_lim[0], corr._k_lim[1], corr.D_z, g["theta"], g["ell"])
         assert rel_err(wf, g["w_power_gg"]) < PROJ_RTOL and rel_err(cf_, g["cl_power_gg"]) < PROJ_RTOL
+
+
+@pytest.mark.parametrize("ggl", [False, True])
+def test_projection_step_replays_from_a_hip_graph(mods, ggl):
+    """A whole projection step -- the projection set-up on the context's side stream beside the
+    halo set-up, the lazy join at the first reader, C_l beside w(theta), (HaloFit beside the knot
+    integrals), the status post -- captured into ONE HIP graph: the forks and joins of the side
+    stream are captured with the rest (events inside the capture), and a replay returns the
+    eager step's numbers bit for bit.  (The host queues ~25 launches per eager step; a replay is
+    one call.)"""
+    import warnings
+    import torch
+    cosmology, kernel, correlation, halo = mods
+    d2r = numpy.pi / 180.0
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cm, kern = _projection(mods, ggl)
+        h = halo.HaloFit(0.0) if ggl else halo.Halo(0.0)
+        corr = correlation.Correlation(0.001, 1.0, kern, input_halo=h,
+                                       power_spec="power_gm" if ggl else "power_gg")
+        theta = torch.logspace(-3, 0, 96, dtype=torch.float64, device="cuda") * d2r
+        ell = torch.logspace(1, 4, 160, dtype=torch.float64, device="cuda")
+
+        def step():
+            kern._done.clear()                  # forget every table: the step rebuilds all of it
+            h._epoch_sig = None
+            h._nbar_valid = False
+            h._reset_flags(all_tables=True)
+            if ggl:
+                h._initialized_sigma_spline = False
+            ctx, code = corr._prepare(defer_status=True)
+            return ctx.wtheta_cell(code, 0, corr._k_lim[0], corr._k_lim[1], corr.D_z, theta, ell)
+
+        w0, c0 = step()
+        w0, c0 = step()
+        torch.cuda.synchronize()
+        w0, c0 = w0.clone(), c0.clone()
+        st0 = int(h.status)
+        assert bool(torch.isfinite(w0).all()) and bool((c0 > 0).all())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            w, c = step()
+        torch.cuda.synchronize()
+        for _ in range(3):
+            w.zero_()
+            c.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(w, w0) and torch.equal(c, c0)
+        h._status_pending = True                # (the post is a node of the graph: readable after a replay)
+        assert int(h.status) == st0
+        # eager again, same numbers, and nothing of the capture lingers in the context
+        w1, c1 = step()
+        torch.cuda.synchronize()
+        assert torch.equal(w1, w0) and torch.equal(c1, c0)
