@@ -981,13 +981,12 @@ static int launch_halo_knots(chomp_ctx* ctx, const HaloPlan& P) {
           hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024))
       CHOMP_LDS_OPT_IN(kDeepThreadsFew, false, false);
       CHOMP_LDS_OPT_IN(kDeepThreads, false, false);
-      CHOMP_LDS_OPT_IN(kDeepThreadsFew, false, true);
       CHOMP_LDS_OPT_IN(kDeepThreads, false, true);
-      HIPCHK(hipFuncSetAttribute(
-          reinterpret_cast<const void*>(&k_halo_knots_fast<kDeepCoarse, kDeepThreadsFew, false, true, true>),
-          hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-      CHOMP_LDS_OPT_IN(kDeepThreadsFew, true, true);
+      CHOMP_LDS_OPT_IN(kDeepThreadsFew, false, true);
       CHOMP_LDS_OPT_IN(kDeepThreads, true, true);
+      HIPCHK(hipFuncSetAttribute(
+          reinterpret_cast<const void*>(&k_halo_knots_fast<kDeepCoarse, kDeepThreads, false, true, true>),
+          hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
 #undef CHOMP_LDS_OPT_IN
       ctx->lds_knots_set = true;
     }
@@ -997,8 +996,7 @@ static int launch_halo_knots(chomp_ctx* ctx, const HaloPlan& P) {
   //  knots there can be, the finer, so that a single epoch's handful still spreads over the chip)
   const int parts = few ? 8 : ((size_t)L.NK * n * ng <= 8192 ? 4 : 2);
   if (!hod_groups) {                // (group 0 alone: listed knots are done in the same launch)
-    if (few) CHOMP_KNOTS_FAST(kDeepThreadsFew, true, true, gd, 0, 0, 0x7fffffff, 0);
-    else CHOMP_KNOTS_FAST(kDeepThreads, true, true, gd, 0, 0, 0x7fffffff, 0);
+    CHOMP_KNOTS_FAST(kDeepThreads, true, true, gd, 0, 0, 0x7fffffff, 0);
   } else if (!deep_route) {         // (divmax within the node tables: nothing is ever listed)
     if (few) CHOMP_KNOTS_FAST(kDeepThreadsFew, false, false, gd, 0, 0, 0, 0);
     else CHOMP_KNOTS_FAST(kDeepThreads, false, false, gd, 0, 0, 0, 0);
@@ -1010,8 +1008,8 @@ static int launch_halo_knots(chomp_ctx* ctx, const HaloPlan& P) {
       CHOMP_KNOTS_SAMPLES((unsigned)gs, lo, hi);
       const unsigned g = r == 0 ? gd : (gd < 512u ? gd : 512u);
       if (P.eval) {
-        if (few) CHOMP_KNOTS_FAST(kDeepThreadsFew, false, true, g, r, lo, hi, 0);
-        else CHOMP_KNOTS_FAST(kDeepThreads, false, true, g, r, lo, hi, 0);
+        if (few) CHOMP_KNOTS_FAST(kDeepThreadsFew, false, true, (g < 256u ? g : 256u), r, lo, hi, 0);
+        else CHOMP_KNOTS_FAST(kDeepThreads, false, true, (g < 512u ? g : 512u), r, lo, hi, 0);
       } else {
         // (the lean instance, and behind it ONE launch for what it hands on: the knots that
         //  need node evaluations -- few and long: 512 threads each -- and, in the last round,
@@ -1020,8 +1018,8 @@ static int launch_halo_knots(chomp_ctx* ctx, const HaloPlan& P) {
         const unsigned ge = all_literal ? g : (g < 256u ? g : 256u);
         if (few) CHOMP_KNOTS_FAST(kDeepThreadsFew, false, false, g, r, lo, hi, 0);
         else CHOMP_KNOTS_FAST(kDeepThreads, false, false, g, r, lo, hi, 0);
-        if (last_round) CHOMP_KNOTS_FAST_L(kDeepThreadsFew, false, true, true, ge, r, lo, hi, 1);
-        else CHOMP_KNOTS_FAST(kDeepThreadsFew, false, true, ge, r, lo, hi, 1);
+        if (last_round) CHOMP_KNOTS_FAST_L(kDeepThreads, false, true, true, ge, r, lo, hi, 1);
+        else CHOMP_KNOTS_FAST(kDeepThreads, false, true, ge, r, lo, hi, 1);
       }
     }
   }
@@ -1030,7 +1028,7 @@ static int launch_halo_knots(chomp_ctx* ctx, const HaloPlan& P) {
     const size_t shl = deep_literal_lds(L.NM, L.NK);
     // (an empty list is the rule: few blocks, each returns after one read)
     const unsigned gl = all_literal ? gd : (gd < 256u ? gd : 256u);
-    if (few) CHOMP_KNOTS_LITERAL(kDeepThreadsFew, gl); else CHOMP_KNOTS_LITERAL(kDeepThreads, gl);
+    CHOMP_KNOTS_LITERAL(kDeepThreads, gl);
   }
 #undef CHOMP_KNOTS_FAST
 #undef CHOMP_KNOTS_FAST_L

@@ -2053,7 +2053,12 @@ __device__ __forceinline__ void deep_fast_body(
 // (deep_literal_loop) once its own list is empty -- the launch behind the lean instance does
 // both, so that the chain carries one near-empty launch behind the fast sums, not two.
 template <int LC, int NT, bool SELF, bool EVAL, bool LIT = false>
-__global__ __launch_bounds__(NT, SELF ? 1 : ((!EVAL && NT == 256) ? 3 : 512 / NT)) void k_halo_knots_fast(
+// (register caps, by measurement: the lean instance three blocks of 256 to a CU; the instance
+//  that evaluates nodes, as the MAIN pass of a set-up with alpha != 1, capped at 256 registers
+//  -- it spills ~180 bytes in its node loop and is still 13 % faster than uncapped at one block
+//  per CU, 0.697 against 0.799 ms on a configs[2]-sized batch with alpha = 0.9; the instances
+//  that only see the rare hand-overs -- SELF, LIT -- uncapped and free of scratch)
+__global__ __launch_bounds__(NT, (SELF || LIT) ? 1 : (EVAL ? 512 / NT : (NT == 256 ? 3 : 1))) void k_halo_knots_fast(
     chomp_config cfg, TabLayout L, const Epoch* __restrict__ epochs, double* __restrict__ tab,
     const SiCiTab* __restrict__ sici_g, int g0, int g1, int g2, unsigned mask, int n_epoch,
     int* __restrict__ pending, int* __restrict__ npend, Epoch* __restrict__ epochs_rw,
