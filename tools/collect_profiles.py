@@ -8,7 +8,7 @@ tag = sys.argv[1]
 rnd = sys.argv[2] if len(sys.argv) > 2 else "round4"
 src, dst = os.path.join(R, "gpurun_out", tag), os.path.join(R, "profiles")
 STAGE_K = ("k_sigma_nodes", "k_sigma_lns", "k_epoch_probe", "k_nu_table", "k_mass_nodes", "k_halo_nodes",
-           "k_halo_knots", "k_halo_knots_fast", "k_halo_knots_literal")
+           "k_halo_knots", "k_halo_knots_samples", "k_halo_knots_fast", "k_halo_knots_literal")
 shutil.copy(os.path.join(src, "bench_default.json"), os.path.join(dst, rnd + "_bench_default.json"))
 for w in ("c2", "c3", "c4", "c5", "b1024d", "b1024o"):
     shutil.copy(os.path.join(src, "kernel_stats_%s.csv" % w), os.path.join(dst, "%s_kernel_stats_%s.csv" % (rnd, w)))

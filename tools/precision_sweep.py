@@ -11,8 +11,11 @@ from chomp_amd import _lib, cosmology, kernel, correlation, halo
 g = numpy.load(os.path.join(R, "tests", "golden", "g7_ggl_halofit.npz"))
 d2r = numpy.pi / 180.0
 warnings.simplefilter("ignore")
+import contextlib
 cm = cosmology.MultiEpoch(0.0, 5.0)
-wa = kernel.WindowFunctionGalaxy(kernel.dNdzMagLim(0.0, 2.0, 2.0, 0.3, 2.0), cm)
+with contextlib.redirect_stdout(sys.stderr):        # (the reference's z_max warning is a print)
+    lens = kernel.dNdzMagLim(0.0, 2.0, 2.0, 0.3, 2.0)
+wa = kernel.WindowFunctionGalaxy(lens, cm)
 wb = kernel.WindowFunctionConvergence(kernel.dNdzGaussian(0.0, 2.0, 1.0, 0.2), cm)
 kern = kernel.GalaxyGalaxyLensingKernel(1e-6 * d2r, 100.0 * d2r, wa, wb, cm)
 hf = halo.HaloFit(0.0)
