@@ -1134,31 +1134,49 @@ __device__ __forceinline__ void mass_setup_block(
                      sys == 0 ? M.c_nu : M.c_lnm, M.work + sys * 9 * NM, tid, 128, true);
   }
   MSTAMP(2);
-  if (threadIdx.x == 0) {
-    E.ln_mass_min = ln_mass_min;
-    E.ln_mass_max = ln_mass_max;
-    E.n_search = n_search;
-    E.nu_min = 1.001 * M.y_nu[0];                       // mass_function.py:212-213
-    E.nu_max = 0.999 * M.y_nu[NM - 1];
-    E.m_star = exp(spline_eval(M.y_nu, M.c_lnm, NM, 1.0));   // :223
-    E.stq = hp.stq;
-    E.st_a = hp.st_little_a;
-    E.mf_delta_v = (hp.delta_v == -1.0) ? E.delta_v : hp.delta_v;
-    E.mf_kind = mf_kind;
-    E.f_norm = 1.0;
-    E.bias_norm = 1.0;
-    E.ln_st_a = log(hp.st_little_a);
-    E.ln_t_beta = 0.0;
-    if (mf_kind == CHOMP_MF_TINKER) {                 // mass_function.py:547-564
-      const double ld = log(E.mf_delta_v);
+  if (threadIdx.x < 64) {
+    // (one wavefront: the five Tinker parameters -- a look-up in the 9-row table from global
+    //  memory and a power of 1 + z each, mass_function.py:547-564 -- in five lanes at once, m_star
+    //  in a sixth: done one after the other by thread 0 they were 6.7 us of every block's chain
+    //  on a Tinker set-up (tools/dev_mass_stamps.py).  Same calls on the same arguments.)
+    const int lane = (int)threadIdx.x;
+    const double mf_delta_v = (hp.delta_v == -1.0) ? E.delta_v : hp.delta_v;
+    double mine = 0.0;
+    if (mf_kind == CHOMP_MF_TINKER && lane < 5) {
+      const double ld = log(mf_delta_v);
       const double opz = 1.0 + E.z;
-      E.t_alpha = spline_eval(tinker->x, tinker->c[0], 9, ld);
-      E.t_beta = spline_eval(tinker->x, tinker->c[1], 9, ld) * pow(opz, 0.20);
-      E.t_gamma = spline_eval(tinker->x, tinker->c[2], 9, ld) * pow(opz, -0.01);
-      E.t_phi = spline_eval(tinker->x, tinker->c[3], 9, ld) * pow(opz, -0.08);
-      E.t_eta = spline_eval(tinker->x, tinker->c[4], 9, ld) * pow(opz, 0.27);
-      E.ln_t_beta = log(E.t_beta);
-      tinker_bias_constants(E);
+      mine = spline_eval(tinker->x, tinker->c[lane], 9, ld);
+      const double ex = lane == 1 ? 0.20 : (lane == 2 ? -0.01 : (lane == 3 ? -0.08 : 0.27));
+      if (lane > 0) mine *= pow(opz, ex);
+    }
+    if (lane == 5) mine = exp(spline_eval(M.y_nu, M.c_lnm, NM, 1.0));   // :223
+    const double t_alpha = readlane_d(mine, 0), t_beta = readlane_d(mine, 1);
+    const double t_gamma = readlane_d(mine, 2), t_phi = readlane_d(mine, 3);
+    const double t_eta = readlane_d(mine, 4), m_star = readlane_d(mine, 5);
+    if (lane == 0) {
+      E.ln_mass_min = ln_mass_min;
+      E.ln_mass_max = ln_mass_max;
+      E.n_search = n_search;
+      E.nu_min = 1.001 * M.y_nu[0];                       // mass_function.py:212-213
+      E.nu_max = 0.999 * M.y_nu[NM - 1];
+      E.m_star = m_star;
+      E.stq = hp.stq;
+      E.st_a = hp.st_little_a;
+      E.mf_delta_v = mf_delta_v;
+      E.mf_kind = mf_kind;
+      E.f_norm = 1.0;
+      E.bias_norm = 1.0;
+      E.ln_st_a = log(hp.st_little_a);
+      E.ln_t_beta = 0.0;
+      if (mf_kind == CHOMP_MF_TINKER) {
+        E.t_alpha = t_alpha;
+        E.t_beta = t_beta;
+        E.t_gamma = t_gamma;
+        E.t_phi = t_phi;
+        E.t_eta = t_eta;
+        E.ln_t_beta = log(E.t_beta);
+        tinker_bias_constants(E);
+      }
     }
   }
   __syncthreads();
