@@ -910,7 +910,12 @@ static int launch_halo_knots(chomp_ctx* ctx, const HaloPlan& P) {
     rck = ensure(ctx, &ctx->d_psum, &ctx->cap_psum, slots * (size_t)(kDeepChunks * kDeepPsum));
     if (rck) return rck;
   }
-  int hod_cap = ctx->tune[CHOMP_TUNE_HOD_CAP] >= 0 ? (int)ctx->tune[CHOMP_TUNE_HOD_CAP] : kHodCapLevel;
+  // (a set-up of one or a few epochs -- every launch lasts as long as its slowest unit -- leaves
+  //  the table at level 9; a batch, where the ~11 % of knots that converge AT level 10 would each
+  //  take a slot, a sampling work item and a summing block, walks the whole table: 888 against
+  //  1001 listed knots and -6.6 us per configs[2] step, tools/scratch/hod_cap.py)
+  int hod_cap = ctx->tune[CHOMP_TUNE_HOD_CAP] >= 0 ? (int)ctx->tune[CHOMP_TUNE_HOD_CAP]
+                : ((size_t)L.NK * n * ng <= 768 ? kHodCapLevel : kNodeLevel);
   if (hod_cap < 6) hod_cap = 6;
   // chomp_set_tuning: the checker (every listed knot by literal evaluation) and the two
   // thresholds at which a knot leaves the fast path by itself

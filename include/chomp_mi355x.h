@@ -319,9 +319,10 @@ int chomp_status_wait(chomp_ctx* ctx, size_t epoch0, size_t n, unsigned* out);
  *                            the margin above a singular satellite onset, segments shorter
  *                            than a stencil) and still take the fast sums (default and
  *                            maximum 64)
- *   CHOMP_TUNE_HOD_CAP       Romberg level (6..10, default 9) up to which a knot of the HOD
- *                            integrands walks the node table before it is listed for the fast
- *                            deep-level sums (10: the whole table, as for the smooth pair)
+ *   CHOMP_TUNE_HOD_CAP       Romberg level (6..10; default 9 for a set-up of one or a few
+ *                            epochs, 10 for a batch) up to which a knot of the HOD integrands
+ *                            walks the node table before it is listed for the fast deep-level
+ *                            sums (10: the whole table, as for the smooth pair)
  *   CHOMP_TUNE_WTHETA_DIRECT 1: w(theta) by evaluating the kernel spline at every Romberg node
  *                            (the checker of the moment route of chomp_wtheta)
  *   CHOMP_TUNE_CELL_ONE_KERNEL 1: C_l with every Romberg level in the per-multipole kernel (the
