@@ -115,7 +115,7 @@ ST_NONFINITE = 0x10000
 ST_SATURATED = ST_MASS_MIN_SATURATED | ST_MASS_MAX_SATURATED
 TUNE_E_STREAM_MIN, TUNE_E_ROWS, TUNE_DEEP_LITERAL, TUNE_ROCTX, TUNE_WTHETA_DIRECT = 0, 1, 2, 3, 4
 TUNE_CELL_ONE_KERNEL = 5
-TUNE_DEEP_TOL, TUNE_DEEP_MAX_BREAKS, TUNE_DEEP_MAX_FINE, TUNE_HOD_CAP = 6, 7, 8, 9
+TUNE_DEEP_TOL, TUNE_DEEP_MAX_BREAKS, TUNE_DEEP_MAX_FINE, TUNE_HOD_CAP, TUNE_DEEP_SLOTS = 6, 7, 8, 9, 10
 
 
 class ChompAccuracyWarning(UserWarning):

@@ -103,7 +103,7 @@ struct chomp_ctx {
   unsigned* d_status = nullptr;    // per-epoch status word (chomp_get_status)
   double* d_endp = nullptr;        // integrand pairs of the knots at the upper end point
   int* d_npend = nullptr;          // per epoch: listed knots + 1 token (k_halo_knots_fast)
-  long long tune[CHOMP_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};   // chomp_set_tuning
+  long long tune[CHOMP_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};   // chomp_set_tuning
   bool have_epochs = false, have_mass = false, have_halo = false;
   unsigned fam_mask = 0;          // families (F_* bits) with valid splines
   std::vector<char> have_halofit;
@@ -902,6 +902,8 @@ static int launch_halo_knots(chomp_ctx* ctx, const HaloPlan& P) {
     const size_t worst = (size_t)ng * n * (size_t)L.NK;
     const size_t budget = ((size_t)1 << 30) / ((size_t)kDeepSlot * sizeof(double));
     slots = worst < budget ? worst : budget;
+    if (ctx->tune[CHOMP_TUNE_DEEP_SLOTS] > 0 && (size_t)ctx->tune[CHOMP_TUNE_DEEP_SLOTS] < slots)
+      slots = (size_t)ctx->tune[CHOMP_TUNE_DEEP_SLOTS];
     if ((worst + slots - 1) / slots > (size_t)kPendingRounds)
       slots = (worst + kPendingRounds - 1) / kPendingRounds;
     rounds = (int)((worst + slots - 1) / slots);

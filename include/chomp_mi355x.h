@@ -323,6 +323,10 @@ int chomp_status_wait(chomp_ctx* ctx, size_t epoch0, size_t n, unsigned* out);
  *                            epochs, 10 for a batch) up to which a knot of the HOD integrands
  *                            walks the node table before it is listed for the fast deep-level
  *                            sums (10: the whole table, as for the smooth pair)
+ *   CHOMP_TUNE_DEEP_SLOTS    slots of the sample buffer of the listed knots (default: one per
+ *                            knot that can be listed, up to 1 GiB): with fewer slots than
+ *                            listed knots the sampling and summing launches work the list off
+ *                            in rounds (the path of a batch of hundreds of epochs, for a test)
  *   CHOMP_TUNE_WTHETA_DIRECT 1: w(theta) by evaluating the kernel spline at every Romberg node
  *                            (the checker of the moment route of chomp_wtheta)
  *   CHOMP_TUNE_CELL_ONE_KERNEL 1: C_l with every Romberg level in the per-multipole kernel (the
@@ -342,7 +346,8 @@ int chomp_status_wait(chomp_ctx* ctx, size_t epoch0, size_t n, unsigned* out);
 #define CHOMP_TUNE_DEEP_MAX_BREAKS 7
 #define CHOMP_TUNE_DEEP_MAX_FINE 8
 #define CHOMP_TUNE_HOD_CAP 9
-#define CHOMP_TUNE_COUNT 10
+#define CHOMP_TUNE_DEEP_SLOTS 10
+#define CHOMP_TUNE_COUNT 11
 int chomp_set_tuning(chomp_ctx* ctx, int what, long long value);
 /* Measurement aid: out[7] <- knots beyond the node tables done so far (since the context was
  * created) by [0] the fast deep-level sums, [1] literal evaluation of every node; why literal:

@@ -946,3 +946,74 @@ def test_soak_seed_flag_iff_mismatch():
             refg = o.halo_power(tb, "gm", k)
             assert numpy.max(numpy.abs(pg[i][ok] / refg[ok] - 1)) < 1e-7, (i, zs[i])
     assert n_flagged <= 3
+
+
+@pytest.mark.parametrize("alpha", [1.0, 0.9])
+def test_deep_knots_in_rounds_of_the_sample_buffer(alpha):
+    """The sample buffer of the listed knots holds a slot for every knot that can be listed only
+    up to a budget; beyond it (hundreds of epochs) the sampling and the summing launches work
+    the list off in rounds of `slots` knots -- per-round draw counters, the epochs' tokens in
+    round 0, the hand-over launch behind every round, the literal list behind the last.
+    CHOMP_TUNE_DEEP_SLOTS shrinks the buffer until a 6-epoch batch takes several rounds: every
+    number must come out as in one round, bit for bit -- with the lean instance and its
+    hand-over launch (alpha = 1), with the evaluating instance as the main pass (alpha != 1),
+    and with knots leaving for the literal evaluation in the middle of it."""
+    from chomp_amd import grid, _lib
+    z = numpy.linspace(0.0, 1.4, 6)
+    k = numpy.logspace(-3, 2, 90)
+    hd = dict(log_M_min=12.1, sigma=0.2, log_M_0=12.2, log_M_1p=13.3, alpha=alpha)
+
+    def run(tune):
+        hg = grid.HaloGrid(z, mass_function="tinker", hod_dict=hd)
+        hg.ctx = hg.ctx.__class__(hg.ctx.config, device=hg.ctx.device)      # (a context of its own)
+        for what, v in tune:
+            hg.ctx.set_tuning(what, v)
+        out = {w: hg.power(w, k) for w in ("power_gm", "power_gg")}
+        tabs = {(n, i): hg.ctx.table(n, i) for i in range(z.size) for n in ("h_g", "pp_gg", "levels")}
+        f, l = hg.ctx.deep_stats()
+        return out, tabs, f, l, hg.status()
+
+    one = run([])
+    assert one[2] > 60 and one[3] == 0
+    for slots in (17, 64):
+        many = run([(_lib.TUNE_DEEP_SLOTS, slots)])
+        assert many[2] == one[2] and many[3] == 0, slots
+        for w in one[0]:
+            assert numpy.array_equal(many[0][w], one[0][w]), (slots, w)
+        for key in one[1]:
+            assert numpy.array_equal(many[1][key], one[1][key]), (slots, key)
+        assert numpy.array_equal(many[4], one[4])
+    # knots that leave for the literal evaluation, in rounds: same numbers as in one round
+    lit1 = run([(_lib.TUNE_DEEP_MAX_BREAKS, 1)])
+    litn = run([(_lib.TUNE_DEEP_MAX_BREAKS, 1), (_lib.TUNE_DEEP_SLOTS, 23)])
+    assert lit1[3] > 0 and (litn[2], litn[3]) == (lit1[2], lit1[3])
+    for w in one[0]:
+        assert numpy.array_equal(litn[0][w], lit1[0][w]), w
+        assert numpy.max(numpy.abs(lit1[0][w] / one[0][w] - 1)) < 1e-9, w
+
+
+def test_deep_knots_with_other_point_counts():
+    """The fast deep-level sums at table sizes other than 50 x 50 (an odd mass_npoints moves the
+    sample arrays' place in a block's LDS, which are copied 16 bytes at a time; 30 knots): every
+    listed knot against the literal evaluation of every Romberg node."""
+    from chomp_amd import defaults, grid, _lib
+    saved = copy.deepcopy(defaults.default_precision)
+    try:
+        defaults.default_precision.update(dict(halo_npoints=30, mass_npoints=41))
+        z = numpy.array([0.0, 0.8])
+        k = numpy.logspace(-3, 2, 60)
+
+        def run(tune):
+            hg = grid.HaloGrid(z, mass_function="tinker")
+            for what, v in tune:
+                hg.ctx.set_tuning(what, v)
+            return hg.power("power_gm", k), [hg.ctx.table("levels", i) for i in range(2)], hg.ctx.deep_stats()
+
+        fast, lit = run([]), run([(_lib.TUNE_DEEP_LITERAL, 1)])
+        assert fast[2][0] > 10 and fast[2][1] == 0 and lit[2][0] == 0
+        assert numpy.max(numpy.abs(fast[0] / lit[0] - 1)) < 1e-9
+        for a, b in zip(fast[1], lit[1]):
+            assert numpy.array_equal(a, b)
+    finally:
+        defaults.default_precision.clear()
+        defaults.default_precision.update(saved)
