@@ -136,6 +136,7 @@ struct chomp_ctx {
   size_t cap_samples = 0, cap_psum = 0, cap_plan = 0;
   char* d_plan = nullptr;          // per (epoch, group): the break-point plan (DeepPlan; k_halo_knots -> _fast)
   double* d_deepw = nullptr;       // k_halo_knots_fast: level weights (deep_weights_host)
+  double* d_hf_ainv = nullptr;     // k_halofit_finalize: inverse collocation matrix of the ln R grid
   int* d_deepstat = nullptr;       // k_halo_knots_fast: knots done by the fast / literal path
   size_t cap_slow = 0, cap_winfo = 0, cap_ktab = 0, cap_wnodes = 0;
   // chomp_power_plan: the k-only table of a registered k grid, kept across chomp_power calls
@@ -415,6 +416,13 @@ int setup_constants(chomp_ctx* ctx) {
     HIPCHK(hipMalloc(&ctx->d_deepstat, 8 * sizeof(int)));
     HIPCHK(hipMemset(ctx->d_deepstat, 0, 8 * sizeof(int)));
   }
+  if (ctx->cfg.halo_npoints >= 12) {   // (fewer points: the serial quintic solve of k_halofit_finalize)
+    const int nk = ctx->cfg.halo_npoints;
+    std::vector<double> ai((size_t)nk * nk);
+    halofit_collocation_inverse_host(nk, ai.data());
+    HIPCHK(hipMalloc(&ctx->d_hf_ainv, ai.size() * sizeof(double)));
+    HIPCHK(hipMemcpy(ctx->d_hf_ainv, ai.data(), ai.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   HIPCHK(hipMalloc(&ctx->d_cand, cand.size() * sizeof(double)));
   HIPCHK(hipMemcpy(ctx->d_cand, cand.data(), cand.size() * sizeof(double),
                    hipMemcpyHostToDevice));
@@ -532,7 +540,7 @@ void chomp_ctx_destroy(chomp_ctx* ctx) {
                   ctx->d_cand, ctx->d_cosmo, ctx->d_z, ctx->d_epochs, ctx->d_search, ctx->d_probe, ctx->d_count, ctx->d_pending,
                   ctx->d_tab, ctx->d_mass_par, ctx->d_profile, ctx->d_hod, ctx->d_nodes, ctx->d_snodes, ctx->d_slot, ctx->d_first, ctx->d_status, ctx->d_endp, ctx->d_npend,
                   ctx->d_stage_in, ctx->d_stage_in2, ctx->d_stage_out, ctx->d_slow, ctx->d_wnodes, ctx->d_cnodes, ctx->d_deepw, ctx->d_deepstat,
-                  ctx->d_winfo, ctx->d_ktab, ctx->d_samples, ctx->d_psum, ctx->d_plan};
+                  ctx->d_winfo, ctx->d_ktab, ctx->d_samples, ctx->d_psum, ctx->d_plan, ctx->d_hf_ainv};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (void* p : ctx->graveyard) (void)hipFree(p);

@@ -211,6 +211,86 @@ __device__ __forceinline__ void quintic_derivs_wave(const double* x, const doubl
   __syncthreads();
 }
 
+// The inverse of the quintic spline's collocation matrix on HaloFit's ln R grid
+// (linspace(ln 0.1, ln 10, n): halo.py:1270-1272 -- the grid, hence the matrix, depends on n
+// alone), transposed: ainv_t[j * n + i] = (A^-1)[i][j].  Host, once per context (long double
+// Gauss-Jordan with partial pivoting).  The B-spline coefficients of the sigma table are then
+// c = A^-1 y: fifty multiply-adds per lane, where the banded elimination and back substitution
+// of quintic_derivs_wave are ~150 dependent steps of one wavefront (30 of k_halofit_finalize's
+// 39 us).
+inline void halofit_collocation_inverse_host(int n, double* ainv_t) {
+  std::vector<double> x(n), t(n + 6);
+  for (int i = 0; i < n; ++i) x[i] = linspace_at(std::log(0.1), std::log(10.0), n, i);
+  for (int i = 0; i < 6; ++i) { t[i] = x[0]; t[n + i] = x[n - 1]; }
+  for (int i = 0; i < n - 6; ++i) t[6 + i] = x[3 + i];
+  std::vector<long double> a((size_t)n * 2 * n, 0.0L);          // [A | I]
+  int m = 5;
+  for (int i = 0; i < n; ++i) {
+    while (m < n - 1 && x[i] >= t[m + 1]) ++m;
+    double N[6];
+    bspline_basis(t.data(), m, 5, x[i], N);
+    for (int r = 0; r < 6; ++r) a[(size_t)i * 2 * n + (m - 5 + r)] = N[r];
+    a[(size_t)i * 2 * n + n + i] = 1.0L;
+  }
+  for (int col = 0; col < n; ++col) {
+    int piv = col;
+    for (int r = col + 1; r < n; ++r)
+      if (fabsl(a[(size_t)r * 2 * n + col]) > fabsl(a[(size_t)piv * 2 * n + col])) piv = r;
+    if (piv != col)
+      for (int j = 0; j < 2 * n; ++j) std::swap(a[(size_t)col * 2 * n + j], a[(size_t)piv * 2 * n + j]);
+    const long double d = a[(size_t)col * 2 * n + col];
+    for (int j = 0; j < 2 * n; ++j) a[(size_t)col * 2 * n + j] /= d;
+    for (int r = 0; r < n; ++r) {
+      if (r == col) continue;
+      const long double f = a[(size_t)r * 2 * n + col];
+      if (f == 0.0L) continue;
+      for (int j = 0; j < 2 * n; ++j) a[(size_t)r * 2 * n + j] -= f * a[(size_t)col * 2 * n + j];
+    }
+  }
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) ainv_t[(size_t)j * n + i] = (double)a[(size_t)i * 2 * n + n + j];
+}
+
+// quintic_derivs_wave with the coefficients from the tabulated inverse (one wavefront; work:
+// (n + 6) + n doubles of LDS; barriers inside).
+__device__ __forceinline__ void quintic_derivs_inv(const double* x, const double* y, int n,
+                                                   double xq, const double* __restrict__ ainv_t,
+                                                   double* work, double* d1, double* d2) {
+  const int lane = threadIdx.x & 63;
+  double* t = work;               // [n + 6]
+  double* c = t + (n + 6);        // [n]
+  for (int i = lane; i < 6; i += 64) { t[i] = x[0]; t[n + i] = x[n - 1]; }
+  for (int i = lane; i < n - 6; i += 64) t[6 + i] = x[3 + i];
+  for (int i = lane; i < n; i += 64) {
+    double acc = 0.0;
+    for (int j = 0; j < n; ++j) acc = fma(ainv_t[(size_t)j * n + i], y[j], acc);
+    c[i] = acc;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    int m = 5;
+    while (m < n - 1 && xq >= t[m + 1]) ++m;
+    double c1[6], c2[5], N[6];
+    for (int r = 1; r <= 5; ++r) {          // j = m-5+r = m-4 .. m
+      const int j = m - 5 + r;
+      c1[r] = 5.0 * (c[j] - c[j - 1]) / (t[j + 5] - t[j]);
+    }
+    for (int r = 2; r <= 5; ++r) {          // j = m-3 .. m
+      const int j = m - 5 + r;
+      c2[r - 1] = 4.0 * (c1[r] - c1[r - 1]) / (t[j + 4] - t[j]);
+    }
+    bspline_basis(t, m, 4, xq, N);
+    double s1 = 0.0;
+    for (int r = 0; r < 5; ++r) s1 += c1[r + 1] * N[r];
+    bspline_basis(t, m, 3, xq, N);
+    double s2 = 0.0;
+    for (int r = 0; r < 4; ++r) s2 += c2[r + 1] * N[r];
+    *d1 = s1;
+    *d2 = s2;
+  }
+  __syncthreads();
+}
+
 // grid 1, block 64 (one wavefront, on LDS copies): k_sigma, n_eff, C and the Takahashi et al.
 // coefficients (halo.py:1285-1317) of epoch `src` stored into epoch `dst`.  The cubic spline of
 // ln R over ln sigma^2 by parallel cyclic reduction, the quintic one of ln sigma^2 over ln R
@@ -219,7 +299,7 @@ __global__ __launch_bounds__(64) void k_halofit_finalize(TabLayout L, Epoch* __r
                                                          int dst, int src,
                                                          const double* __restrict__ tab, double f1,
                                                          double f2, double f3, double omega_l,
-                                                         double w) {
+                                                         double w, const double* __restrict__ ainv_t) {
   extern __shared__ __align__(16) double work[];
   __shared__ double sh_d[2];
   const int n = L.NK;
@@ -241,7 +321,10 @@ __global__ __launch_bounds__(64) void k_halofit_finalize(TabLayout L, Epoch* __r
   __syncthreads();
   spline_build_pcr(xr, yr, n, c, w2, (int)threadIdx.x, 64, true);
   const double k_s = 1.0 / exp(spline_eval(xr, c, n, 0.0));            // halo.py:1285-1287
-  quintic_derivs_wave(lnR, lns2, n, log(1.0 / k_s), w2, &sh_d[0], &sh_d[1]);   // :1289-1292
+  if (ainv_t != nullptr)                                                        // :1289-1292
+    quintic_derivs_inv(lnR, lns2, n, log(1.0 / k_s), ainv_t, w2, &sh_d[0], &sh_d[1]);
+  else
+    quintic_derivs_wave(lnR, lns2, n, log(1.0 / k_s), w2, &sh_d[0], &sh_d[1]);
   if (threadIdx.x != 0) return;
   const double ne = -sh_d[0] - 3.0, C = -sh_d[1];
   Epoch& E = epochs[dst];
