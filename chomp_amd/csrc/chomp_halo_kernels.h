@@ -1634,6 +1634,10 @@ __device__ __forceinline__ void deep_fast_body(
   //  chain -- was measured and is worse: the blocks that start first, on the deepest knots, then
   //  also hold the first of the knots left over, 100 against 88 us per configs[2] launch; and a
   //  block's FIRST draw issued in front of its staging, to overlap the two: C3 0.317 -> 0.325 ms)
+  // (a block's FIRST knot is its own number in the list -- no draw: the atomic's round trip,
+  //  ~2.5 us, off the front of every block's chain, and the list's order, deepest knots first,
+  //  is the dispatch order of the blocks anyway; the knots beyond the grid are drawn)
+  bool own_first = !from_eval;
   for (;;) {
 #ifdef CHOMP_STAMPS
     first_item = (n_items++ == 0);
@@ -1643,10 +1647,13 @@ __device__ __forceinline__ void deep_fast_body(
       if (from_eval) {
         const int d = atomicAdd(&pending[kPendingEvDraw + round], 1);
         item_sh = d < ev_count ? ev_items[d] : item_hi;
+      } else if (own_first) {
+        item_sh = slot_lo + (int)blockIdx.x;
       } else {
-        item_sh = slot_lo + atomicAdd(&pending[kPendingDraw + round], 1);
+        item_sh = slot_lo + (int)gridDim.x + atomicAdd(&pending[kPendingDraw + round], 1);
       }
     }
+    own_first = false;
     __syncthreads();
     if (item_sh >= item_hi) {      // block-uniform
       KSTAMP_BLOCK(19, __builtin_amdgcn_s_memtime());

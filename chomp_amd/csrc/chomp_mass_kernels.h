@@ -506,10 +506,12 @@ __global__ __launch_bounds__(256) void k_sigma_nodes(chomp_config cfg,
 // The interpolated integrand with the g table in LDS and k from exp (k_sigma_lns).
 struct SigmaInterpLds {
   static constexpr bool kLaneMajor = true;   // (the six taps below: a gather from LDS at an index ~ ln k)
+  static constexpr bool kGeometric = true;   // (k = exp(ln k): from the lane's previous node by a multiplication)
   const double* g;         // g / k^6 on the grid, in LDS (index 0 = first pad point)
   double xlo, dx, inv_dx, scale, nine_over_r6;
   bool tiny_r;
-  __device__ __forceinline__ double operator()(double ln_k) const {
+  __device__ __forceinline__ double operator()(double ln_k) const { return with_exp(ln_k, exp(ln_k)); }
+  __device__ __forceinline__ double with_exp(double ln_k, double k) const {
     const double u = (ln_k - xlo) * inv_dx;
     int i = (int)u;
     i = i < 0 ? 0 : (i > kGTabN - 1 ? kGTabN - 1 : i);
@@ -520,7 +522,6 @@ struct SigmaInterpLds {
     const double gv = q[0] * (b * cd * ef) * (-1.0 / 120.0) + q[1] * (a * cd * ef) * (1.0 / 24.0) +
                       q[2] * (ab * d * ef) * (-1.0 / 12.0) + q[3] * (ab * t * ef) * (1.0 / 12.0) +
                       q[4] * (ab * cd * f) * (-1.0 / 24.0) + q[5] * (ab * cd * e) * (1.0 / 120.0);
-    const double k = exp(ln_k);
     const double kR = scale * k;
     double s, c;
     fast_sincos(kR, &s, &c);
