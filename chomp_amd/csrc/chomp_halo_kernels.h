@@ -1508,17 +1508,24 @@ __device__ long long g_ks[kStampBlocks * kStampSlots];
 // One more arrival at epoch e (its token, or one of its listed knots done) by a whole block:
 // whoever brings npend[e] to zero finalises the epoch.  fences: knots were written by other
 // blocks of this or the previous launch's kernels since the counter was armed.
+// wrote: what THIS block has written that the finalising block will read -- kArriveNothing
+// (the token), kArrivePlain (plain stores: a fence, i.e. a write-back of the XCD's L2, in front
+// of the count), kArriveThrough (thread 0 stored its results with agent scope, knot_store():
+// written through, and only their completion is waited for -- the fence was 2 us of every
+// listed knot's chain).
+enum { kArriveNothing = 0, kArrivePlain = 1, kArriveThrough = 2 };
+__device__ __forceinline__ void knot_store(double* q, double v) {
+  __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void deep_arrive(const chomp_config& cfg, const TabLayout& L,
                                             Epoch* __restrict__ epochs_rw, double* __restrict__ tab,
                                             int e, unsigned fam_mask, unsigned* __restrict__ status,
                                             int* __restrict__ npend, bool fences, int* last_sh,
-                                            double* sm) {
+                                            double* sm, int wrote = kArrivePlain) {
   __syncthreads();                 // (the block's results are written)
   if (threadIdx.x == 0) {
-    if (fences) {
-      __threadfence();             // ... and visible before the count moves
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    if (fences && wrote == kArrivePlain) __threadfence();   // ... and visible before the count moves
+    if (fences && wrote != kArriveNothing) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     *last_sh = atomicSub(&npend[e], 1) == 1 ? 1 : 0;
   }
   __syncthreads();
@@ -1605,7 +1612,8 @@ __device__ __forceinline__ void deep_fast_body(
   //  reads comes from the previous launch, and no fence is needed)
   const bool fences = count != 0;
   if (round == 0 && !from_eval && (int)blockIdx.x < n_epoch)
-    deep_arrive(cfg, L, epochs_rw, tab, (int)blockIdx.x, fam_mask, status, npend, fences, &last_sh, sm);
+    deep_arrive(cfg, L, epochs_rw, tab, (int)blockIdx.x, fam_mask, status, npend, fences, &last_sh, sm,
+                kArriveNothing);
   // this round's share of the list: the knots whose samples are in the buffer's slots now
   const int item_hi = count < slot_hi ? count : slot_hi;
   if (item_hi <= slot_lo) return;  // nothing listed (for this round): no traffic on the queue head
@@ -1674,7 +1682,8 @@ __device__ __forceinline__ void deep_fast_body(
                     levs[fa * NK + ik] == kPendingLevel;
     const bool pb = group >= 0 && group <= 2 && (mask & (1u << fb)) && levs[fb * NK + ik] == kPendingLevel;
     if (!pa && !pb) {              // (never listed; keep the count right)
-      deep_arrive(cfg, L, epochs_rw, tab, e, fam_mask, status, npend, fences, &last_sh, sm);
+      deep_arrive(cfg, L, epochs_rw, tab, e, fam_mask, status, npend, fences, &last_sh, sm,
+                  kArriveNothing);
       if (!w_safe) { __syncthreads(); stage_weights(); }
       continue;
     }
@@ -2043,15 +2052,16 @@ __device__ __forceinline__ void deep_fast_body(
     KSTAMP(16);
     KSTAMP_VALUE(23, R.level[0] > R.level[1] ? R.level[0] : R.level[1]);
     if (tid == 0) {
-      if (pa) { t[L.off_knot[fa] + ik] = R.value[0]; levs[fa * NK + ik] = (double)R.level[0]; }
-      if (pb) { t[L.off_knot[fb] + ik] = R.value[1]; levs[fb * NK + ik] = (double)R.level[1]; }
+      if (pa) { knot_store(&t[L.off_knot[fa] + ik], R.value[0]); knot_store(&levs[fa * NK + ik], (double)R.level[0]); }
+      if (pb) { knot_store(&t[L.off_knot[fb] + ik], R.value[1]); knot_store(&levs[fb * NK + ik], (double)R.level[1]); }
       unsigned st = 0u;              // divmax exhausted (halo.py:1065-1071 and alike)
       if (pa && !R.done[0]) st |= kStHaloDivmax0 << fa;
       if (pb && !R.done[1]) st |= kStHaloDivmax0 << fb;
       if (st) atomicOr(&status[e], st);
       if (stats) atomicAdd(&stats[0], 1);
     }
-    deep_arrive(cfg, L, epochs_rw, tab, e, fam_mask, status, npend, fences, &last_sh, sm);
+    deep_arrive(cfg, L, epochs_rw, tab, e, fam_mask, status, npend, fences, &last_sh, sm,
+                kArriveThrough);
     KSTAMP(17);
     if (!w_safe) { __syncthreads(); stage_weights(); }
   }   // next item

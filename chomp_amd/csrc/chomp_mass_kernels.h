@@ -482,22 +482,26 @@ __global__ __launch_bounds__(256) void k_sigma_nodes(chomp_config cfg,
   }
   double* part = n + kSigmaOffPart + (size_t)blockIdx.x * (kSigmaLevel + 1);
   __syncthreads();
-  if (threadIdx.x <= kSigmaLevel)
-    part[threadIdx.x] = ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) +
-                        wsum[3][threadIdx.x];
+  if (threadIdx.x <= kSigmaLevel) {
+    // (agent-scope stores: the only thing another block of this launch reads -- the last one,
+    //  with agent-scope loads -- written through; each writer waits for its own store, the
+    //  barrier below for all of them: no fence, i.e. no write-back of the XCD's whole L2, in
+    //  front of the arrival count.  The tables are read by the next launch.)
+    __hip_atomic_store(part + threadIdx.x,
+                       ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) +
+                           wsum[3][threadIdx.x],
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   if constexpr (NPT != 1) {
     return;                        // (k_sigma_lns, behind this launch, finishes sigma_8)
   } else {
     int* arrivals = reinterpret_cast<int*>(n + kSigmaOffI8 + 1);
     __syncthreads();
-    if (threadIdx.x == 0) {
-      __threadfence();             // partial sums (and table) visible before the arrival counts
-      last_block = atomicAdd(arrivals, 1) == nb - 1 ? 1 : 0;
-    }
+    if (threadIdx.x == 0) last_block = atomicAdd(arrivals, 1) == nb - 1 ? 1 : 0;
     __syncthreads();
     if (!last_block) return;
-    // ---- last node block of this cosmology: sigma_8 from the level sums
-    __threadfence();
+    // ---- last node block of this cosmology: sigma_8 from the level sums (agent-scope loads)
     if (threadIdx.x == 0) *arrivals = 0;
     sigma8_from_parts<BAO>(cfg, E, n, nb, red);
   }

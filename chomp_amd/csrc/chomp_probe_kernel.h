@@ -56,7 +56,10 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_probe(
     const double chi = romberg1<kInitNW>(f, 0.0, E.z, cfg.global_precision,
                                          cfg.cosmo_precision, cfg.divmax, red);
     __syncthreads();
-    if (threadIdx.x == 0) { E.chi = chi; pr[2 * kProbes] = chi; }
+    if (threadIdx.x == 0) {
+      E.chi = chi;
+      __hip_atomic_store(pr + 2 * kProbes, chi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __syncthreads();
     if (fixed) {
       if (threadIdx.x == 0) {
@@ -87,11 +90,19 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_probe(
       }
     }
     if (threadIdx.x == 0) {
-      pr[role] = nu_mine;
+      // (agent-scope stores: written through to where the last block's agent-scope loads read
+      //  them -- PHASE 0 then needs no fence, i.e. no write-back of this XCD's whole L2, in
+      //  front of its arrival count, only the stores' completion)
+      auto put = [](double* q, double v) {
+        __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      };
+      put(pr + role, nu_mine);
       if (p == 0) {
         double* pl = pr + 2 * kProbes + 4 + 4 * side;
-        pl[0] = plan.ok ? (plan.at_edge ? 2.0 : 1.0) : 0.0; pl[1] = (double)plan.dir;
-        pl[2] = (double)plan.j; pl[3] = plan.nu_start;
+        put(pl, plan.ok ? (plan.at_edge ? 2.0 : 1.0) : 0.0);
+        put(pl + 1, (double)plan.dir);
+        put(pl + 2, (double)plan.j);
+        put(pl + 3, plan.nu_start);
       }
     }
   }
@@ -99,7 +110,7 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_probe(
   if constexpr (PHASE == 1) return;
   if constexpr (PHASE == 0) {
     if (threadIdx.x == 0) {
-      __threadfence();             // results visible before the arrival is counted
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the record's stores (above) have landed
       last = atomicAdd(&count[e], 1) == 2 * kProbes - 1 ? 1 : 0;
     }
     __syncthreads();
