@@ -536,11 +536,14 @@ __device__ __forceinline__ int group_fb(int group) {
 // reduction), the Stage-E record, n_bar into the epoch record.  sm: 51 NK doubles.
 // ---------------------------------------------------------------------------
 __host__ __device__ inline int finalize_lds_doubles(int NK) { return 42 * NK; }
+// through: the knot values were (in part) written by other blocks of this launch, with agent
+// scope: they are read with agent-scope loads, and the caller needs no fence in front.
 __device__ __forceinline__ void halo_finalize_block(const chomp_config& cfg, const TabLayout& L,
                                                     Epoch* __restrict__ epochs,
                                                     double* __restrict__ tab, int e,
                                                     unsigned fam_mask,
-                                                    unsigned* __restrict__ status, double* sm) {
+                                                    unsigned* __restrict__ status, double* sm,
+                                                    bool through = false) {
   const int NK = L.NK;
   double* xk = sm;                      // [NK]
   double* yk = xk + NK;                 // [5][NK]
@@ -572,7 +575,10 @@ __device__ __forceinline__ void halo_finalize_block(const chomp_config& cfg, con
       else if (f == F_PPGG) scale = rho_bar / (n_bar * n_bar);      // :1026
       bool bad = false;
       for (int i = lane; i < NK; i += 64) {
-        const double v = t[L.off_knot[f] + i] * scale;
+        const double raw = through ? __hip_atomic_load(&t[L.off_knot[f] + i], __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT)
+                                   : t[L.off_knot[f] + i];
+        const double v = raw * scale;
         yk[f * NK + i] = v;
         t[L.off_knot[f] + i] = v;
         bad = bad || !(fabs(v) <= 1.79769313486231570815e308);   // NaN or infinity
@@ -1530,8 +1536,9 @@ __device__ __forceinline__ void deep_arrive(const chomp_config& cfg, const TabLa
   }
   __syncthreads();
   if (*last_sh) {                  // block-uniform
-    if (fences) __threadfence();
-    halo_finalize_block(cfg, L, epochs_rw, tab, e, fam_mask, status, sm);
+    // (the knots of the other blocks: agent-scope loads, see halo_finalize_block; everything
+    //  else it reads is the previous launch's)
+    halo_finalize_block(cfg, L, epochs_rw, tab, e, fam_mask, status, sm, fences);
   }
 }
 
