@@ -53,6 +53,8 @@ __host__ __device__ inline size_t pending_eval_base(size_t n_epoch, int NK) {
 __host__ __device__ inline size_t pending_ints(size_t n_epoch, int NK) {
   return (size_t)kPendingHead + 3 * 3 * n_epoch * (size_t)NK;
 }
+constexpr int kItemOpenA = 1 << 29, kItemOpenB = 1 << 30;   // flags of a listed item: see k_halo_knots
+constexpr int kItemIndex = kItemOpenA - 1;                  // ... and the mask of its index
 constexpr unsigned kMaskExclusion = 1u << 8;   // bit of the kernels' family mask: HaloExclusion
 constexpr unsigned kMaskDeepNodes = 1u << 9;   // ... the node tables hold level kNodeTabLevel too
 
@@ -1323,13 +1325,14 @@ __global__ __launch_bounds__(KNW == 0 ? 64 : 256, KNW == 1 ? 3 : 1) void k_halo_
       t[L.off_knot[fa] + ik] = r.value[0];
       lev[fa * NK + ik] = (!r.converged[0] && more) ? kPendingLevel : (double)r.level[0];
     }
-    bool any = false;
-    if (group != 2 && (mask & (1u << fa))) any = any || (!r.converged[0] && more);
+    bool any = false, need_a = false, need_b = false;
+    if (group != 2 && (mask & (1u << fa))) need_a = !r.converged[0] && more;
     if (mask & (1u << fb_)) {
       t[L.off_knot[fb_] + ik] = r.value[1];
       lev[fb_ * NK + ik] = (!r.converged[1] && more) ? kPendingLevel : (double)r.level[1];
-      any = any || (!r.converged[1] && more);
+      need_b = !r.converged[1] && more;
     }
+    any = need_a || need_b;
     // divmax within the node tables: scipy returns the last row with an AccuracyWarning
     if (!more) {
       unsigned st = 0u;
@@ -1341,7 +1344,10 @@ __global__ __launch_bounds__(KNW == 0 ? 64 : 256, KNW == 1 ? 3 : 1) void k_halo_
     // the highest k -- at the front, the rest from the back of the buffer downwards
     if (any) {
       atomicAdd(&npend[e], 1);
-      const int item = (int)((bz * n_epoch + e) * NK + ik);
+      // (which of the pair is still open rides in the item: the consumer then need not read
+      //  the levels table -- a dependent round trip at the front of every listed knot)
+      const int item = (int)((bz * n_epoch + e) * NK + ik) | (need_a ? kItemOpenA : 0) |
+                       (need_b ? kItemOpenB : 0);
       const int cap = 3 * n_epoch * NK;
       if (4 * ik >= 3 * NK) pending[kPendingHead + atomicAdd(&pending[0], 1)] = item;
       else pending[kPendingHead + cap - 1 - atomicAdd(&pending[2], 1)] = item;
@@ -1408,9 +1414,9 @@ __global__ __launch_bounds__(256) void k_halo_knots_samples(
   const int per = kDeepChunks / parts;
   for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
     const int li = slot_lo + w / parts, part = w % parts;
-    const int item = li < count_front
-                         ? pending[kPendingHead + li]
-                         : pending[kPendingHead + 3 * n_epoch * NK - 1 - (li - count_front)];
+    const int item = kItemIndex & (li < count_front
+                                       ? pending[kPendingHead + li]
+                                       : pending[kPendingHead + 3 * n_epoch * NK - 1 - (li - count_front)]);
     const int ik = item % NK, e = (item / NK) % n_epoch, zg = item / (NK * n_epoch);
     const int group = zg == 0 ? g0 : (zg == 1 ? g1 : g2);
     if (group < 0 || group > 2) continue;          // (never listed)
@@ -1677,17 +1683,19 @@ __device__ __forceinline__ void deep_fast_body(
 #endif
       return;
     }
-    const int item = item_sh < count_front
-                         ? pending[kPendingHead + item_sh]
-                         : pending[kPendingHead + 3 * n_epoch * NK - 1 - (item_sh - count_front)];
+    const int item_raw = item_sh < count_front
+                             ? pending[kPendingHead + item_sh]
+                             : pending[kPendingHead + 3 * n_epoch * NK - 1 - (item_sh - count_front)];
+    const int item = item_raw & kItemIndex;
     const int ik = item % NK, e = (item / NK) % n_epoch, zg = item / (NK * n_epoch);
     const int group = zg == 0 ? g0 : (zg == 1 ? g1 : g2);
     double* t = tab + (size_t)e * L.stride;
     double* levs = t + L.off_levels;
     const int fa = group_fa(group < 0 ? 0 : group), fb = group_fb(group < 0 ? 0 : group);
+    // (which of the pair is open: from the item's flags -- the lister's levels[] == pending marks)
     const bool pa = group >= 0 && group <= 2 && group != 2 && (mask & (1u << fa)) &&
-                    levs[fa * NK + ik] == kPendingLevel;
-    const bool pb = group >= 0 && group <= 2 && (mask & (1u << fb)) && levs[fb * NK + ik] == kPendingLevel;
+                    (item_raw & kItemOpenA) != 0;
+    const bool pb = group >= 0 && group <= 2 && (mask & (1u << fb)) && (item_raw & kItemOpenB) != 0;
     if (!pa && !pb) {              // (never listed; keep the count right)
       deep_arrive(cfg, L, epochs_rw, tab, e, fam_mask, status, npend, fences, &last_sh, sm,
                   kArriveNothing);
