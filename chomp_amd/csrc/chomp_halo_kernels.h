@@ -1624,9 +1624,17 @@ __device__ __forceinline__ void deep_fast_body(
   // (with an empty list no block of this launch writes a knot: every value the finalisation
   //  reads comes from the previous launch, and no fence is needed)
   const bool fences = count != 0;
-  if (round == 0 && !from_eval && (int)blockIdx.x < n_epoch)
-    deep_arrive(cfg, L, epochs_rw, tab, (int)blockIdx.x, fam_mask, status, npend, fences, &last_sh, sm,
-                kArriveNothing);
+  if (round == 0 && !from_eval && (int)blockIdx.x < n_epoch) {
+    if (count == 0) {
+      // (nothing listed anywhere: every epoch's counter stands at its token, and block e
+      //  finalises epoch e without the atomic's round trip -- the headline chain's last launch
+      //  is nothing but this)
+      halo_finalize_block(cfg, L, epochs_rw, tab, (int)blockIdx.x, fam_mask, status, sm, false);
+    } else {
+      deep_arrive(cfg, L, epochs_rw, tab, (int)blockIdx.x, fam_mask, status, npend, fences, &last_sh, sm,
+                  kArriveNothing);
+    }
+  }
   // this round's share of the list: the knots whose samples are in the buffer's slots now
   const int item_hi = count < slot_hi ? count : slot_hi;
   if (item_hi <= slot_lo) return;  // nothing listed (for this round): no traffic on the queue head
