@@ -120,6 +120,7 @@ struct chomp_ctx {
   // is destroyed (graph_seen: a call of this context has been captured at least once).
   bool graph_seen = false;
   std::vector<void*> graveyard;
+  std::vector<void*> host_graveyard;   // (pinned words a graph's kernels or copies may write)
 
   // staging for host-pointer calls
   double* d_stage_in = nullptr;
@@ -177,7 +178,15 @@ struct chomp_ctx {
   hipEvent_t ev_side_go = nullptr, ev_proj_ready = nullptr, ev_side_done = nullptr;
   bool proj_pending = false;
   bool proj_pending_captured = false;   // ... and it was queued inside the capture in progress
-  bool status_posted_in_capture = false;   // the post is a graph node: no event to wait for
+  bool status_mirrored = false;    // the last set-up ended with a halo set-up: its finalising blocks
+                                   // wrote the status words to the pinned host words themselves
+  // (see ensure_hstatus / mirror_next / chomp_status_post)
+  unsigned long long* h_mirror = nullptr;
+  unsigned setup_seq = 0, posted_seq = 0;
+  int mirror_half = 0, mirror_region = 0, posted_half = 0;
+  int posted_kind = 0;             // 0 none, 1 the mirror, 2 the copy, 3 collected into posted_saved
+  bool posted_in_capture = false;
+  std::vector<unsigned> posted_saved;
 };
 
 namespace {
@@ -544,11 +553,13 @@ void chomp_ctx_destroy(chomp_ctx* ctx) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (void* p : ctx->graveyard) (void)hipFree(p);
+  for (void* p : ctx->host_graveyard) (void)hipHostFree(p);
   for (StagedBlock* b : {&ctx->sh_cosmo, &ctx->sh_z, &ctx->sh_mass, &ctx->sh_profile, &ctx->sh_hod,
                          &ctx->sh_slot, &ctx->sh_first, &ctx->sh_proj, &ctx->sh_pp[0],
                          &ctx->sh_pp[1]})
     b->release();
   if (ctx->h_status) (void)hipHostFree(ctx->h_status);
+  if (ctx->h_mirror) (void)hipHostFree(ctx->h_mirror);
   if (ctx->ev_status) (void)hipEventDestroy(ctx->ev_status);
   if (ctx->h_stage_in) (void)hipHostFree(ctx->h_stage_in);
   if (ctx->h_stage_out) (void)hipHostFree(ctx->h_stage_out);
@@ -662,45 +673,135 @@ int chomp_get_status(chomp_ctx* ctx, size_t epoch0, size_t n, unsigned* out) {
   return CHOMP_OK;
 }
 
+// The pinned host words of the status posts, large enough for the batch: h_mirror, three regions
+// the finalising blocks of the halo set-ups write (sequence number << 32 | word) into in turn
+// (known to the kernels through ctx->L), and h_status, where a post without a mirror is copied.
+// Not under stream capture (an allocation): returns OK with the words as they are.
+static int ensure_hstatus(chomp_ctx* ctx) {
+  if (ctx->n_epoch <= ctx->cap_hstatus && ctx->h_status && ctx->h_mirror) return CHOMP_OK;
+  if (capturing(ctx)) return CHOMP_OK;
+  HIPCHK(hipStreamSynchronize(ctx->stream));       // (a copy or a kernel's mirror may be in flight)
+  if (ctx->graph_seen) {
+    if (ctx->h_status) ctx->host_graveyard.push_back(ctx->h_status);
+    if (ctx->h_mirror) ctx->host_graveyard.push_back(ctx->h_mirror);
+  } else {
+    if (ctx->h_status) HIPCHK(hipHostFree(ctx->h_status));
+    if (ctx->h_mirror) HIPCHK(hipHostFree(ctx->h_mirror));
+  }
+  ctx->h_status = nullptr;
+  ctx->h_mirror = nullptr;
+  ctx->L.h_status = nullptr;
+  ctx->cap_hstatus = 0;
+  ctx->posted_kind = 0;
+  ctx->n_hstatus = 0;
+  HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_status), ctx->n_epoch * sizeof(unsigned),
+                       hipHostMallocDefault));
+  HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_mirror),
+                       3 * ctx->n_epoch * sizeof(unsigned long long), hipHostMallocDefault));
+  std::memset(ctx->h_mirror, 0, 3 * ctx->n_epoch * sizeof(unsigned long long));
+  ctx->cap_hstatus = ctx->n_epoch;
+  ctx->mirror_half = 0;
+  ctx->mirror_region = 0;
+  ctx->L.h_status = ctx->h_mirror;
+  ctx->L.h_seq = 0u;
+  return CHOMP_OK;
+}
+
+// The words of a mirrored post, once every one of them carries the post's sequence number
+// (the set-up's finalising blocks have written them).  Spins on the pinned words; gives up with
+// an error when the stream has drained and they still do not (a set-up that failed).
+static int mirror_collect(chomp_ctx* ctx, int half, unsigned seq, size_t epoch0, size_t n,
+                          unsigned* out) {
+  const volatile unsigned long long* w = ctx->h_mirror + (size_t)half * ctx->cap_hstatus + epoch0;
+  for (size_t i = 0; i < n; ++i) {
+    bool drained = false;
+    for (;;) {
+      const unsigned long long v = w[i];
+      if ((unsigned)(v >> 32) == seq) { out[i] = (unsigned)v; break; }
+      if (drained)
+        return fail(ctx, CHOMP_ERR_STATE, "status_wait: the posted set-up never finalised its epochs");
+      if (hipStreamQuery(ctx->stream) == hipSuccess) drained = true;   // (one more look, then give up)
+    }
+  }
+  return CHOMP_OK;
+}
+
+// In front of a halo set-up's kernels: the region its finalising blocks will mirror into and its
+// sequence number.  Eager set-ups take regions 0 and 1 in turn; a post of the region about to be
+// written again that nobody has waited for yet is collected first -- it is the set-up of two
+// set-ups ago.  A set-up under stream capture gets region 2 and a number of its own, both fixed
+// in the graph's kernel arguments: replays never write where an eager set-up's words are.
+static int mirror_next(chomp_ctx* ctx) {
+  if (!ctx->h_mirror) return CHOMP_OK;
+  int next = 2;
+  if (!capturing(ctx)) {
+    next = ctx->mirror_half ^ 1;
+    ctx->mirror_half = next;
+  }
+  if (ctx->posted_kind == 1 && ctx->posted_half == next && !capturing(ctx)) {
+    ctx->posted_saved.resize(ctx->n_hstatus);
+    const int rc = mirror_collect(ctx, next, ctx->posted_seq, 0, ctx->n_hstatus, ctx->posted_saved.data());
+    if (rc) return rc;
+    ctx->posted_kind = 3;
+  }
+  ctx->mirror_region = next;
+  ctx->L.h_status = ctx->h_mirror + (size_t)next * ctx->cap_hstatus;
+  ctx->L.h_seq = ++ctx->setup_seq;
+  return CHOMP_OK;
+}
+
 int chomp_status_post(chomp_ctx* ctx) {
   if (!ctx) return CHOMP_ERR_ARG;
   if (!ctx->have_epochs) return fail(ctx, CHOMP_ERR_STATE, "status_post before epochs_set");
   HIPCHK(hipSetDevice(ctx->device));
   const bool cap = capturing(ctx);
-  if (cap && (ctx->n_epoch > ctx->cap_hstatus || !ctx->h_status || !ctx->ev_status))
+  if (cap && (ctx->n_epoch > ctx->cap_hstatus || !ctx->h_status))
     return fail(ctx, CHOMP_ERR_STATE,
-                "status_post during stream capture before any eager post of this size (the "
+                "status_post during stream capture before any eager set-up of this size (the "
                 "pinned words would have to be allocated)");
-  if (ctx->n_epoch > ctx->cap_hstatus || !ctx->h_status) {
-    if (ctx->ev_status) HIPCHK(hipEventSynchronize(ctx->ev_status));   // (a copy may be in flight)
-    if (ctx->h_status) HIPCHK(hipHostFree(ctx->h_status));
-    ctx->h_status = nullptr;
-    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_status), ctx->n_epoch * sizeof(unsigned),
-                         hipHostMallocDefault));
-    ctx->cap_hstatus = ctx->n_epoch;
+  { const int rce = ensure_hstatus(ctx); if (rce) return rce; }
+  if (ctx->status_mirrored) {
+    // Behind a halo set-up the words are on their way already (its finalising blocks write them,
+    // with the set-up's sequence number): the post puts nothing on the stream -- it names the
+    // region and the number to wait for.
+    ctx->posted_kind = 1;
+    ctx->posted_half = ctx->mirror_region;
+    ctx->posted_seq = ctx->L.h_seq;
+  } else {
+    if (!ctx->ev_status) {
+      if (cap) return fail(ctx, CHOMP_ERR_STATE, "status_post during stream capture before any eager post");
+      HIPCHK(hipEventCreateWithFlags(&ctx->ev_status, hipEventDisableTiming));
+    }
+    if (ctx->posted_kind == 2 && !cap && !ctx->posted_in_capture)
+      HIPCHK(hipEventSynchronize(ctx->ev_status));       // (the previous copy into the same words)
+    HIPCHK(hipMemcpyAsync(ctx->h_status, ctx->d_status, ctx->n_epoch * sizeof(unsigned),
+                          hipMemcpyDeviceToHost, ctx->stream));
+    // (under capture the copy is a node of the graph, and whoever looks at the words waits for
+    //  the stream the graph was launched on, not for an event)
+    if (!cap) HIPCHK(hipEventRecord(ctx->ev_status, ctx->stream));
+    ctx->posted_kind = 2;
   }
-  if (!ctx->ev_status) HIPCHK(hipEventCreateWithFlags(&ctx->ev_status, hipEventDisableTiming));
-  HIPCHK(hipMemcpyAsync(ctx->h_status, ctx->d_status, ctx->n_epoch * sizeof(unsigned),
-                        hipMemcpyDeviceToHost, ctx->stream));
-  // (under capture the copy is a node of the graph: every replay posts the words, and whoever
-  //  looks at them waits for the stream the graph was launched on, not for an event)
-  if (!cap) HIPCHK(hipEventRecord(ctx->ev_status, ctx->stream));
-  ctx->status_posted_in_capture = cap;
+  ctx->posted_in_capture = cap;
   ctx->n_hstatus = ctx->n_epoch;
   return CHOMP_OK;
 }
 
 int chomp_status_wait(chomp_ctx* ctx, size_t epoch0, size_t n, unsigned* out) {
   if (!ctx || !out || n == 0) return fail(ctx, CHOMP_ERR_ARG, "status_wait: bad args");
-  if (!ctx->n_hstatus) return fail(ctx, CHOMP_ERR_STATE, "status_wait before status_post");
+  if (!ctx->n_hstatus || !ctx->posted_kind) return fail(ctx, CHOMP_ERR_STATE, "status_wait before status_post");
   if (epoch0 + n > ctx->n_hstatus) return fail(ctx, CHOMP_ERR_ARG, "status_wait: epoch range");
   HIPCHK(hipSetDevice(ctx->device));
   if (capturing(ctx))
     return fail(ctx, CHOMP_ERR_STATE,
                 "status_wait while the context's stream is being captured (a wait on the host "
                 "cannot be part of a graph): look at the status before the capture or after a replay");
-  if (ctx->status_posted_in_capture) HIPCHK(hipStreamSynchronize(ctx->stream));
-  else HIPCHK(hipEventSynchronize(ctx->ev_status));
+  if (ctx->posted_kind == 3) {                       // (collected when its region was needed again)
+    std::memcpy(out, ctx->posted_saved.data() + epoch0, n * sizeof(unsigned));
+    return CHOMP_OK;
+  }
+  if (ctx->posted_in_capture) HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (ctx->posted_kind == 1) return mirror_collect(ctx, ctx->posted_half, ctx->posted_seq, epoch0, n, out);
+  if (!ctx->posted_in_capture) HIPCHK(hipEventSynchronize(ctx->ev_status));
   std::memcpy(out, ctx->h_status + epoch0, n * sizeof(unsigned));
   return CHOMP_OK;
 }
@@ -721,6 +822,8 @@ int chomp_epochs_set(chomp_ctx* ctx, size_t n_epoch, const chomp_cosmo* cosmo,
   int rc = alloc_epochs(ctx, n_epoch);
   if (rc) return rc;
   ctx->n_epoch = n_epoch;
+  ctx->status_mirrored = false;     // (until a halo set-up of these epochs has finalised them)
+  { const int rch = ensure_hstatus(ctx); if (rch) return rch; }
   ctx->have_mass = ctx->have_halo = false;
   ctx->fam_mask = 0;
   ctx->have_halofit.assign(n_epoch, 0);
@@ -850,6 +953,7 @@ static int halo_prepare(chomp_ctx* ctx, const chomp_halo_par* profile, const cho
 
 // k_nu_table, then k_mass_nodes; plan != nullptr: the halo node tables in the same launch.
 static int launch_nu_mass(chomp_ctx* ctx, int mf_kind, const HaloPlan* plan) {
+  ctx->status_mirrored = false;    // (the mass function's status bits: mirrored by the halo set-up behind it, if any)
   const size_t n = ctx->n_epoch;
   const TabLayout& L = ctx->L;
   // (one cosmology or a few: epochs fastest in dispatch order, the longest integrals first;
@@ -887,6 +991,7 @@ static int launch_nu_mass(chomp_ctx* ctx, int mf_kind, const HaloPlan* plan) {
 // The knot integrals and everything after them (k_halo_knots, k_halo_knots_fast with the
 // per-epoch finalisation).
 static int launch_halo_knots(chomp_ctx* ctx, const HaloPlan& P) {
+  { const int rcm = mirror_next(ctx); if (rcm) return rcm; }
   const size_t n = ctx->n_epoch;
   const TabLayout& L = ctx->L;
   const int ng = P.ng > 0 ? P.ng : 1;
@@ -1052,6 +1157,7 @@ static int launch_halo_knots(chomp_ctx* ctx, const HaloPlan& P) {
   HIPCHK(hipGetLastError());
   ctx->have_halo = true;
   ctx->fam_mask |= P.fam;
+  ctx->status_mirrored = ctx->L.h_status != nullptr;
   return CHOMP_OK;
 }
 

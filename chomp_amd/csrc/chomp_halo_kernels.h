@@ -592,6 +592,17 @@ __device__ __forceinline__ void halo_finalize_block(const chomp_config& cfg, con
     spline_build_pcr(xk, yk + fs * NK, NK, t + L.off_kpp[fs], work + (wave & 3) * 9 * NK, lane, 64,
                      active);
   }
+  // The epoch's status word is final here (every kernel of the set-up has had its say, this
+  // block its own behind the barriers above): mirrored into the pinned host words, so that a
+  // status post behind the set-up puts NOTHING on the stream: the word arrives with the
+  // set-up's sequence number, which is what the host waits for -- a device-to-host copy node
+  // between two kernels cost the stream ~12 us, and so did an event record alone
+  // (tools/scratch/c4_gap.py).
+  if (L.h_status != nullptr && threadIdx.x == 0) {
+    const unsigned w = __hip_atomic_load(&status[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&L.h_status[e], ((unsigned long long)L.h_seq << 32) | (unsigned long long)w,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // ---------------------------------------------------------------------------

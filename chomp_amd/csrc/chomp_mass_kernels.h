@@ -36,6 +36,12 @@ struct TabLayout {
   int off_knot[5], off_kpp[5];
   int off_levels, off_hf_lns2, off_misc;   // misc[0] = n_bar / rho_bar (raw integral)
   int stride;
+  // pinned host words (device-accessible) the block that finalises an epoch's halo set-up
+  // mirrors the epoch's status word into -- (set-up sequence number << 32) | word, one 8-byte
+  // store: the host knows the word is this set-up's by the number, without an event -- or
+  // nullptr (chomp_status_post)
+  unsigned long long* h_status;
+  unsigned h_seq;
 };
 
 inline TabLayout make_layout(int NM, int NK) {
@@ -53,6 +59,8 @@ inline TabLayout make_layout(int NM, int NK) {
   L.off_hf_lns2 = o; o += NK;
   L.off_misc = o; o += 8;
   L.stride = (o + 7) & ~7;
+  L.h_status = nullptr;
+  L.h_seq = 0u;
   return L;
 }
 
