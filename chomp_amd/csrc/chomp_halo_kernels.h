@@ -347,7 +347,7 @@ __device__ __forceinline__ void halo_nodes_block(const chomp_config& cfg, const 
       const int m = idx - 1;
       const int lev = 32 - __builtin_clz((unsigned)m);      // floor(log2 m) + 1
       const long j = m - (1 << (lev - 1));
-      const double h = (b - a) / (double)(1L << (lev - 1));
+      const double h = ldexp(b - a, 1 - lev);
       x = (a + 0.5 * h) + h * (double)j;
     }
     double f[kNodeFields];
@@ -793,6 +793,7 @@ struct RombergRows2 {
   __device__ __forceinline__ void start_levels(double range_, double tol_, double rtol_, double e0,
                                                double e1, const double* ls0, const double* ls1,
                                                bool want0, bool want1) {
+    static_assert(LC < 16, "the rows' sums run over the first sixteen lanes (wave_sum16)");
     range = range_; tol = tol_; rtol = rtol_;
     const int lane = threadIdx.x & 63;
     const double* ls[2] = {ls0, ls1};
@@ -800,20 +801,19 @@ struct RombergRows2 {
     const bool want[2] = {want0, want1};
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      double os = send[q], mine = send[q], pw = 1.0, mypw = 1.0;
+      double os = send[q], mine = send[q];
 #pragma unroll
       for (int l = 1; l <= LC; ++l) {
         os += ls[q][l];
-        pw *= 2.0;
-        if (l <= lane) { mine = os; mypw = pw; }
+        if (l <= lane) mine = os;
       }
-      const double T = lane <= LC ? range * mine / mypw : 0.0;
+      const double T = lane <= LC ? ldexp(range * mine, -lane) : 0.0;   // (/ 2^lane)
       double cur[LC + 1];
       cur[0] = range * send[q];
 #pragma unroll
       for (int i = 1; i <= LC; ++i) {
         const double c_il = ctab != nullptr ? ctab[i * 32 + (lane & 31)] : CHOMP_ROMBERG_C[i][lane & 31];
-        cur[i] = wave_sum(lane <= i ? c_il * T : 0.0);
+        cur[i] = wave_sum16(lane <= i ? c_il * T : 0.0);
       }
       done[q] = !want[q];
       level[q] = 0;
@@ -874,9 +874,9 @@ struct RombergRows2 {
     for (int q = 0; q < 2; ++q) {
       if (done[q]) continue;                                   // block-uniform
       ordsum[q] += s[q];
-      const double Ti = range * ordsum[q] / n;
+      const double Ti = ldexp(range * ordsum[q], -i);          // (/ n, n = 2^i: the same bits)
       if (lane == i) Tl[q] = Ti;
-      const double cur = wave_sum(lane < 32 ? c_il * Tl[q] : 0.0);
+      const double cur = wave_sum32(c_il * Tl[q]);
       const double err = fabs(cur - prev[q]);
       prev[q] = cur;
       value[q] = cur;
@@ -927,7 +927,7 @@ __device__ __forceinline__ double deep_coarse_x(double a, double b, int q) {
   const int tz = __builtin_ctz((unsigned)q);
   const int lev = LC - tz;
   const long j = (long)(((q >> tz) - 1) >> 1);
-  const double h = (b - a) / (double)(1L << (lev - 1));
+  const double h = ldexp(b - a, 1 - lev);
   return (a + 0.5 * h) + h * (double)j;
 }
 
@@ -1103,7 +1103,7 @@ __device__ __forceinline__ void deep_plan_block(const Epoch& E, const double* nu
         const int tz = __builtin_ctz((unsigned)tp);
         const int lev = LC + D - tz;                           // (tz < D: tp is interior)
         const long j = ((long)iv << (lev - 1 - LC)) + (long)(tp >> (tz + 1));
-        const double h = (b - a) / (double)(1L << (lev - 1));
+        const double h = ldexp(b - a, 1 - lev);
         const double px = (a + 0.5 * h) + h * (double)j;
         const int st = halo_state_at(group, c, px);
         cls = st == sl ? 0 : (st == sr ? 1 : 2);
@@ -1282,7 +1282,7 @@ __global__ __launch_bounds__(KNW == 0 ? 64 : 256, KNW == 1 ? 3 : 1) void k_halo_
       for (int i = kCoopLevel + 1; i <= dmax && !all; ++i) {
         const double c_il = CHOMP_ROMBERG_C[i][lane & 31];
         const long numtosum = 1L << (i - 1);
-        const double h = (b - a) / (double)numtosum;
+        const double h = ldexp(b - a, 1 - i);                  // ((b - a) / numtosum)
         const double lox = a + 0.5 * h;
         double part[2] = {0.0, 0.0};
         for (long j = threadIdx.x; j < numtosum; j += 256) {
@@ -2014,7 +2014,7 @@ __device__ __forceinline__ void deep_fast_body(
             const int n = n0 << g;
             const int xi = r / n, rr = r % n, iv = PL.fine[xi];
             const long j = (long)iv * n + rr;
-            const double h = (b - a) / (double)(1L << (lv0 + g - 1));
+            const double h = ldexp(b - a, 1 - (lv0 + g));
             const double x = (a + 0.5 * h) + h * (double)j;
             double o[2];
             if (fine_poly[xi]) {

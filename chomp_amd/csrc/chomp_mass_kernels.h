@@ -87,6 +87,16 @@ constexpr int kNodeStride = kNodeFields * kNodeCount + 8;   // doubles per (epoc
 __host__ __device__ inline int node_index(int lev, long j) {
   return lev == 0 ? (int)j : 1 + (1 << (lev - 1)) + (int)j;
 }
+// A pointer into global memory of which every lane of the wavefront holds the same value, told to
+// the compiler: loads through it take the scalar base + 32-bit vector offset form instead of a
+// 64-bit address computed per lane (four vector instructions per table node).
+typedef const double __attribute__((address_space(1)))* UniformDoubles;
+__device__ __forceinline__ UniformDoubles uniform_ptr(const double* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (UniformDoubles)(((unsigned long long)hi << 32) | lo);
+}
 
 constexpr int kKnotScratch = romberg_scratch<4, 2>();   // LDS doubles of a knot block
 constexpr int kSearchJ = 2048;        // candidates per walking direction
@@ -221,6 +231,7 @@ constexpr int kSigmaOffG = kSigmaOffPart + kSigmaNodeBlocks * (kSigmaLevel + 1);
 // BAO instances keep the direct evaluation).
 constexpr int kGTabN = 8192;
 constexpr int kGTabPad = 3;
+static_assert(kGTabN == kGTabIntervals, "chomp_math.h: epoch_k_range");
 constexpr int kGTabCount = kGTabN + 1 + 2 * kGTabPad;
 constexpr int kGTabBlocks = (kGTabCount + 255) / 256;
 // doubles per cosmology: ..., then g / k^6 [kGTabCount] and k [kGTabCount]
@@ -230,19 +241,20 @@ constexpr int kSigmaStride = kSigmaOffG + 2 * kGTabCount;
 // factor and k interpolated from the cosmology's uniform ln k table (kGTab*; 6-point
 // Lagrange, k through a short series of exp over the fraction of a step).
 struct SigmaInterpIntegrand {
-  const double* g;         // g / k^6 on the grid (index 0 = first pad point)
+  UniformDoubles g;        // g / k^6 on the grid (index 0 = first pad point)
   double xlo, dx, inv_dx;
   double scale, amp2_nine_over_r6, amp2;
   // k R < 1 over the whole range (wave-uniform): the window in the reference's own form
   // 3 (sin x / x^3 - cos x / x^2), whose rounding error at x << 1 is what ends a saturated
   // mass-limit walk (search_status); s - x c is exactly 0 there and would never end it
   bool tiny_r;
+  SinCosLead lead = sincos_lead();
   __device__ __forceinline__ double operator()(double ln_k) const {
     const double u = (ln_k - xlo) * inv_dx;
     int i = (int)u;
     i = i < 0 ? 0 : (i > kGTabN - 1 ? kGTabN - 1 : i);
     const double t = u - (double)i;
-    const double* q = g + i + kGTabPad - 2;            // stencil nodes -2 .. 3 around interval i
+    UniformDoubles q = g + i + kGTabPad - 2;           // stencil nodes -2 .. 3 around interval i
     const double a = t + 2.0, b = t + 1.0, d = t - 1.0, e = t - 2.0, f = t - 3.0;
     const double ab = a * b, ef = e * f, cd = t * d;
     const double gv = q[0] * (b * cd * ef) * (-1.0 / 120.0) + q[1] * (a * cd * ef) * (1.0 / 24.0) +
@@ -252,14 +264,14 @@ struct SigmaInterpIntegrand {
     const double ey = fma(y, fma(y, fma(y, fma(y, 1.0 / 24.0, 1.0 / 6.0), 0.5), 1.0), 1.0);
     const double k = q[2 + kGTabCount] * ey;
     const double kR = scale * k;
-    double s, c;
-    fast_sincos(kR, &s, &c);
     if (tiny_r) {
+      double s, c;
+      fast_sincos_pm(kR, &s, &c);
       const double kR2 = kR * kR, k3 = k * k * k;
       const double W = 3.0 * (s / (kR2 * kR) - c / kR2);
       return amp2 * (gv * (k3 * k3)) * (W * W);
     }
-    const double w = s - kR * c;
+    const double w = tophat_numer_pm(kR, lead);
     return amp2_nine_over_r6 * gv * (w * w);
   }
 };
@@ -320,9 +332,9 @@ __device__ __forceinline__ void sigma8_from_parts(const chomp_config& cfg, const
       if (tab8 && i <= top && !conv) {
         nn *= 2.0;
         ordsum += S[i];
-        const double Ti = range * ordsum / nn;
+        const double Ti = ldexp(range * ordsum, -i);     // (/ nn, nn = 2^i: the same bits)
         if (lane == i) Tl = Ti;
-        result = wave_sum(lane < 32 ? crow[i] * Tl : 0.0);
+        result = wave_sum32(crow[i] * Tl);
         const double err = fabs(result - prev);
         prev = result;
         if (err < cfg.global_precision || err < cfg.cosmo_precision * fabs(result)) conv = 1;
@@ -463,7 +475,7 @@ __global__ __launch_bounds__(256) void k_sigma_nodes(chomp_config cfg,
         const int m = idx - 1;
         lev = 32 - __builtin_clz((unsigned)m);
         const long j = m - (1 << (lev - 1));
-        const double h = (b - a) / (double)(1L << (lev - 1));
+        const double h = ldexp(b - a, 1 - lev);
         x = (a + 0.5 * h) + h * (double)j;
       }
       const double k = exp(x);
@@ -473,9 +485,7 @@ __global__ __launch_bounds__(256) void k_sigma_nodes(chomp_config cfg,
       const double k3 = k * k * k;
       const double d2k6 = exp((3.0 + E.ns) * (x - E.ln_H0)) * T * T / (k3 * k3);
       n[kSigmaCount + idx] = d2k6;
-      double sn, cs;
-      fast_sincos(8.0 * k, &sn, &cs);
-      const double t = sn - 8.0 * k * cs;
+      const double t = tophat_numer_pm(8.0 * k);
       g = d2k6 * (9.0 / 262144.0) * (t * t);        // 9 / 8^6
     }
     if (first_idx < kSigmaCount) {                  // (block-uniform)
@@ -522,6 +532,7 @@ struct SigmaInterpLds {
   const double* g;         // g / k^6 on the grid, in LDS (index 0 = first pad point)
   double xlo, dx, inv_dx, scale, nine_over_r6;
   bool tiny_r;
+  SinCosLead lead = sincos_lead();
   __device__ __forceinline__ double operator()(double ln_k) const { return with_exp(ln_k, exp(ln_k)); }
   __device__ __forceinline__ double with_exp(double ln_k, double k) const {
     const double u = (ln_k - xlo) * inv_dx;
@@ -535,14 +546,14 @@ struct SigmaInterpLds {
                       q[2] * (ab * d * ef) * (-1.0 / 12.0) + q[3] * (ab * t * ef) * (1.0 / 12.0) +
                       q[4] * (ab * cd * f) * (-1.0 / 24.0) + q[5] * (ab * cd * e) * (1.0 / 120.0);
     const double kR = scale * k;
-    double s, c;
-    fast_sincos(kR, &s, &c);
     if (tiny_r) {
+      double s, c;
+      fast_sincos_pm(kR, &s, &c);
       const double kR2 = kR * kR, k3 = k * k * k;
       const double W = 3.0 * (s / (kR2 * kR) - c / kR2);
       return (gv * (k3 * k3)) * (W * W);
     }
-    const double w = s - kR * c;
+    const double w = tophat_numer_pm(kR, lead);
     return nine_over_r6 * gv * (w * w);
   }
 };
@@ -614,19 +625,20 @@ __global__ __launch_bounds__(kLnsThreads) void k_sigma_lns(chomp_config cfg,
 template <bool BAO>
 struct SigmaTabIntegrand {
   const Epoch* e;
-  const double* node;      // this cosmology's table: k_j, then (k_j/H0)^(3+n) T^2 / k_j^6
+  UniformDoubles node;      // this cosmology's table: k_j ...
+  UniformDoubles node_g;    // ... then (k_j/H0)^(3+n) T^2 / k_j^6
   double scale, inv_amp;
   double nine_over_r6;     // 9 / R^6
   SigmaInterpIntegrand deep;   // (same normalisation: amp2 = 1)
   __device__ __forceinline__ void operator()(double ln_k, double (&out)[1], int lev,
                                              long j) const {
     if (lev <= kSigmaLevel) {
-      const int idx = node_index(lev, j);
+      // (& 0x3fff: no-op on a node index, < kSigmaCount; it shows the code generator that the
+      //  byte offset fits the 32-bit vector offset of a load with a scalar base)
+      const unsigned idx = (unsigned)node_index(lev, j) & 0x3fffu;
       const double kR = scale * node[idx];
-      double s, c;
-      fast_sincos(kR, &s, &c);
-      const double t = s - kR * c;
-      out[0] = node[kSigmaCount + idx] * nine_over_r6 * (t * t);
+      const double t = tophat_numer_pm(kR, deep.lead);
+      out[0] = node_g[idx] * nine_over_r6 * (t * t);
     } else if (BAO) {
       SigmaIntegrandT<BAO> f{e, scale};
       out[0] = f(ln_k) * inv_amp;
@@ -646,16 +658,17 @@ __device__ __forceinline__ double sigma2_block(const Epoch& E, const double* sno
                                                double* red, bool* converged = nullptr,
                                                const RombergLoose* loose = nullptr,
                                                int* level_out = nullptr) {
-  double lo, hi;
-  sigma_limits(E, R, &lo, &hi);
   const double need_min = 1.0 / R / 10.0, need_max = 1.0 / R * 14.0662;
   const double amp2 = E.amp * E.sigma_norm * E.sigma_norm;
   if (need_min > E.k_min && need_max < E.k_max) {          // fixed range: table path
+    // (sigma_limits leaves [k_min, k_max] as it is here: its logarithms are the record's)
+    const double lo = E.ln_k_min, hi = E.ln_k_max;
     const double r3 = R * R * R;
-    const double txlo = log(E.k_min / 100.0), tdx = (log(E.k_max * 100.0) - txlo) / (double)kGTabN;
-    SigmaTabIntegrand<BAO> f{&E, snode, R, 1.0 / amp2, 9.0 / (r3 * r3),
-                             SigmaInterpIntegrand{snode + kSigmaOffG, txlo, tdx, 1.0 / tdx, R,
-                                                  9.0 / (r3 * r3), 1.0, false}};
+    const double nine_r6 = 9.0 / (r3 * r3);
+    SigmaTabIntegrand<BAO> f{&E, uniform_ptr(snode), uniform_ptr(snode + kSigmaCount), R, 1.0 / amp2,
+                             nine_r6,
+                             SigmaInterpIntegrand{uniform_ptr(snode + kSigmaOffG), E.gtab_xlo, E.gtab_dx,
+                                                  E.gtab_inv_dx, R, nine_r6, 1.0, false}};
     RombergLoose ls{0.0, 0.0, 0.0, 0.0, 0.0};          // (the integral is sigma^2 / amp2 here)
     if (loose) ls = RombergLoose{loose->rtol, loose->lo1 / amp2, loose->hi1 / amp2,
                                  loose->lo2 / amp2, loose->hi2 / amp2};
@@ -678,12 +691,12 @@ __device__ __forceinline__ double sigma2_block(const Epoch& E, const double* sno
     if (level_out) *level_out = r.level[0];
     return amp2 * r.value[0];
   }
+  double lo, hi;
+  sigma_limits(E, R, &lo, &hi);
   if constexpr (!BAO) {
-    const double xlo = log(E.k_min / 100.0), xhi = log(E.k_max * 100.0);
-    const double dx = (xhi - xlo) / (double)kGTabN;
     const double r3 = R * R * R;
-    SigmaInterpIntegrand f{snode + kSigmaOffG, xlo, dx, 1.0 / dx, R, amp2 * 9.0 / (r3 * r3), amp2,
-                           100.0 * E.k_max * R < 1.0};
+    SigmaInterpIntegrand f{uniform_ptr(snode + kSigmaOffG), E.gtab_xlo, E.gtab_dx, E.gtab_inv_dx, R,
+                           amp2 * 9.0 / (r3 * r3), amp2, 100.0 * E.k_max * R < 1.0};
     Scalar1<SigmaInterpIntegrand> w{f};
     RombergOut<1> r;
     bool fused = false;

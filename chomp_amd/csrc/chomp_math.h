@@ -26,6 +26,23 @@ constexpr double kPi = 3.14159265358979323846;
 constexpr double kHalfPi = 1.57079632679489661923;
 constexpr double kE = 2.71828182845904523536;
 
+// a b + C for a compile-time constant C, the constant read from a scalar register pair.  The
+// compiler's own form of a Horner step is v_fmac_f64 with the constant as the (tied) destination:
+// gfx950's VOP3 takes no 64-bit literal, so that constant is first put into a VGPR pair by two
+// v_mov_b32 -- each a full-rate issue slot like the FMA itself, i.e. a polynomial step costs
+// three vector instructions, and 20 of the 75 of a sigma(R) table node were such moves.
+// v_fma_f64 with the addend in SGPRs is one; the two s_mov_b32 that fill them go to the scalar
+// unit, which issues beside the vector pipeline.  Same operation, same bits.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double fma_k(double a, double b, double c) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+  return d;
+}
+#else
+CHOMP_HD double fma_k(double a, double b, double c) { return fma(a, b, c); }
+#endif
+
 // ---------------------------------------------------------------------------
 // Special-function tables as one POD block: uploaded once per context, staged in
 // LDS by the kernels that need them.
@@ -36,7 +53,24 @@ constexpr double kE = 2.71828182845904523536;
 // library routine with its Payne-Hanek branch; the sigma(R) and NFW integrands spend
 // most of their time here.
 // ---------------------------------------------------------------------------
-CHOMP_HD void fast_sincos(double x, double* sp, double* cp) {
+// The leading coefficients of the two polynomials below, for a caller with a loop around its
+// sincos: a Horner chain's first step has two constants and only one of them can come from
+// scalar registers, the other costs two v_mov_b32 per evaluation -- unless it sits in vector
+// registers the compiler cannot re-materialise (the empty asm), from outside the loop.
+struct SinCosLead {
+  double s0, c0;
+};
+CHOMP_HD SinCosLead sincos_lead() {
+  SinCosLead L{1.58969099521155010221e-10, -1.13596475577881948265e-11};
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(L.s0), "+v"(L.c0));
+#endif
+  return L;
+}
+// (the reduced argument's sine and cosine and the quadrant)
+CHOMP_HD unsigned sincos_reduced(double x, double* sp, double* cp,
+                                 const SinCosLead lead = SinCosLead{1.58969099521155010221e-10,
+                                                                    -1.13596475577881948265e-11}) {
   const double n = rint(x * 6.36619772367581382433e-01);
   double r = fma(-n, 1.57079632679489655800e+00, x);
   r = fma(-n, 6.12323399573676603587e-17, r);
@@ -44,28 +78,51 @@ CHOMP_HD void fast_sincos(double x, double* sp, double* cp) {
   const double shifted = n + 6755399441055744.0;
   unsigned long long bits;
   __builtin_memcpy(&bits, &shifted, sizeof bits);
-  const unsigned q = (unsigned)bits;
   const double z = r * r;
-  double ps = 1.58969099521155010221e-10;
-  ps = fma(ps, z, -2.50507602534068634195e-08);
-  ps = fma(ps, z, 2.75573137070700676789e-06);
-  ps = fma(ps, z, -1.98412698298579493134e-04);
-  ps = fma(ps, z, 8.33333333332248946124e-03);
-  ps = fma(ps, z, -1.66666666666666324348e-01);
-  const double s = fma(r * z, ps, r);
-  double pc = -1.13596475577881948265e-11;
-  pc = fma(pc, z, 2.08757232129817482790e-09);
-  pc = fma(pc, z, -2.75573143513906633035e-07);
-  pc = fma(pc, z, 2.48015872894767294178e-05);
-  pc = fma(pc, z, -1.38888888888741095749e-03);
-  pc = fma(pc, z, 4.16666666666666019037e-02);
-  const double c = fma(z * z, pc, fma(-0.5, z, 1.0));
+  double ps = lead.s0;
+  ps = fma_k(ps, z, -2.50507602534068634195e-08);
+  ps = fma_k(ps, z, 2.75573137070700676789e-06);
+  ps = fma_k(ps, z, -1.98412698298579493134e-04);
+  ps = fma_k(ps, z, 8.33333333332248946124e-03);
+  ps = fma_k(ps, z, -1.66666666666666324348e-01);
+  *sp = fma(r * z, ps, r);
+  double pc = lead.c0;
+  pc = fma_k(pc, z, 2.08757232129817482790e-09);
+  pc = fma_k(pc, z, -2.75573143513906633035e-07);
+  pc = fma_k(pc, z, 2.48015872894767294178e-05);
+  pc = fma_k(pc, z, -1.38888888888741095749e-03);
+  pc = fma_k(pc, z, 4.16666666666666019037e-02);
+  *cp = fma(z * z, pc, fma(-0.5, z, 1.0));
+  return (unsigned)bits;
+}
+CHOMP_HD void fast_sincos(double x, double* sp, double* cp) {
+  double s, c;
+  const unsigned q = sincos_reduced(x, &s, &c);
   const bool swap = (q & 1u) != 0;
   double so = swap ? c : s, co = swap ? s : c;
   if (q & 2u) so = -so;
   if ((q + 1u) & 2u) co = -co;
   *sp = so;
   *cp = co;
+}
+// +-(sin x - x cos x), the numerator of the top-hat window, for callers that square it: the sign
+// (the quadrant's second bit) is not worked out -- in an odd quadrant (sin, cos) = +-(c, -s) of
+// the reduced argument, in an even one +-(s, c), and negating both inputs of the FMA negates its
+// result exactly.  Nine vector instructions fewer per node than through fast_sincos.
+CHOMP_HD double tophat_numer_pm(double x, const SinCosLead lead = SinCosLead{1.58969099521155010221e-10,
+                                                                           -1.13596475577881948265e-11}) {
+  double s, c;
+  const unsigned q = sincos_reduced(x, &s, &c, lead);
+  const double even = fma(-x, c, s), odd = fma(x, s, c);
+  return (q & 1u) ? odd : even;
+}
+// +-(sin x, cos x) with ONE unknown sign for both (as above, for even functions of the pair)
+CHOMP_HD void fast_sincos_pm(double x, double* sp, double* cp) {
+  double s, c;
+  const unsigned q = sincos_reduced(x, &s, &c);
+  const bool swap = (q & 1u) != 0;
+  *sp = swap ? c : s;
+  *cp = swap ? -s : c;
 }
 
 // ---------------------------------------------------------------------------
@@ -456,6 +513,10 @@ struct Epoch {
   // Delta^2(k) = amp * exp((3+n) (ln k - ln H0)) * T(k)^2
   double amp, ln_H0;
   double k_min, k_max;
+  // ln k_min, ln k_max (sigma_r's limits where the range is the table's) and the uniform ln k
+  // grid of the interpolated integrand, [ln(k_min / 100), ln(100 k_max)] in kGTabN steps: what
+  // every sigma(R) integral started with two logarithms and three divisions for
+  double ln_k_min, ln_k_max, gtab_xlo, gtab_dx, gtab_inv_dx, pad_k;
   int flat, open, closed, mf_kind;
   // mass function (mass_function.py)
   double stq, st_a, mf_delta_v;
@@ -501,6 +562,15 @@ CHOMP_HD double growth_approx(double om0, double ol0, double a) {
 }
 
 CHOMP_HD void bao_constants(Epoch& e);
+constexpr int kGTabIntervals = 8192;      // (= kGTabN of chomp_mass_kernels.h)
+CHOMP_HD void epoch_k_range(Epoch& e) {
+  e.ln_k_min = log(e.k_min);
+  e.ln_k_max = log(e.k_max);
+  e.gtab_xlo = log(e.k_min / 100.0);
+  e.gtab_dx = (log(e.k_max * 100.0) - e.gtab_xlo) / (double)kGTabIntervals;
+  e.gtab_inv_dx = 1.0 / e.gtab_dx;
+  e.pad_k = 0.0;
+}
 
 // SingleEpoch.__init__ minus the two integrals (chi, sigma_norm).
 CHOMP_HD void epoch_background(Epoch& e, double cosmo_precision, double k_min,
@@ -514,6 +584,7 @@ CHOMP_HD void epoch_background(Epoch& e, double cosmo_precision, double k_min,
   e.closed = (tot > 1.0 + cosmo_precision) ? 1 : 0;
   e.k_min = k_min;
   e.k_max = k_max;
+  epoch_k_range(e);
   e.delta_H = 1.94e-5 * pow(e.om0, -0.785 - 0.05 * log(e.om0)) *
               exp(-0.95 * (e.ns - 1.0) - 0.169 * (e.ns - 1.0) * (e.ns - 1.0));
   e.growth_norm = growth_approx(e.om0, e.ol0, 1.0);
@@ -561,6 +632,7 @@ CHOMP_HD void epoch_shape_only(Epoch& e, double k_min, double k_max, int with_ba
   e.ln_H0 = log(e.H0);
   e.k_min = k_min;
   e.k_max = k_max;
+  // (no epoch_k_range: nothing that integrates the bare shape goes through sigma2_block)
   const double Omh2 = e.om0 * e.h * e.h;
   const double ratio = e.ob0 / e.om0;
   e.eh_theta = e.tcmb / 2.7;
@@ -758,7 +830,7 @@ struct SigmaIntegrandT {
     const double k = exp(ln_k);
     const double kR = scale * k;
     double s, c;
-    fast_sincos(kR, &s, &c);
+    fast_sincos_pm(kR, &s, &c);                   // (W is squared)
     const double kR2 = kR * kR;
     const double W = 3.0 * (s / (kR2 * kR) - c / kR2);
     const double T = transfer_t<BAO>(*e, k);
@@ -787,8 +859,10 @@ struct EIntegrand {
   }
 };
 
+// (cbrt for the reference's x ** (1 / 3): the two differ by ~ln(x) 2e-17 relative, a third of
+//  the instructions)
 CHOMP_HD double scale_of_mass(const Epoch& e, double mass) {     // cosmology.py:671
-  return pow(3.0 * mass / (4.0 * kPi * e.rho_bar), 1.0 / 3.0);
+  return cbrt(3.0 * mass / (4.0 * kPi * e.rho_bar));
 }
 
 // ---------------------------------------------------------------------------

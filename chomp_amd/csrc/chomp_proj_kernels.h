@@ -773,7 +773,7 @@ __global__ __launch_bounds__(256) void k_wtheta_nodes(chomp_config cfg, TabLayou
       const unsigned m = (unsigned)(idx - 1);
       const int lev = 32 - __builtin_clz(m);
       const long j = (long)m - (1L << (lev - 1));
-      const double h = intrange / (double)(1L << (lev - 1));
+      const double h = ldexp(intrange, 1 - lev);
       x = (a + 0.5 * h) + h * (double)j;
     }
     const double k = exp(x);
@@ -1467,7 +1467,7 @@ __global__ __launch_bounds__(256) void k_cell_nodes(ProjLayout L, const ProjDev*
     const unsigned m = (unsigned)(idx - 1);
     const int lev = 32 - __builtin_clz(m);
     const long j = (long)m - (1L << (lev - 1));
-    const double h = intrange / (double)(1L << (lev - 1));
+    const double h = ldexp(intrange, 1 - lev);
     chi = (a + 0.5 * h) + h * (double)j;
   }
   const double D = G.me.growth_factor(G.me.redshift(chi));
@@ -1697,7 +1697,7 @@ __global__ __launch_bounds__(256, 3) void k_cell4(chomp_config cfg, TabLayout HL
     for (int i = top + 1; i <= split && !R.done; ++i) {
       const double c_il = CHOMP_ROMBERG_C[i][lane & 31];
       const long numtosum = 1L << (i - 1);
-      const double h = (b - a) / (double)numtosum;
+      const double h = ldexp(b - a, 1 - i);                    // ((b - a) / numtosum)
       const double lox = a + 0.5 * h;
       double part = 0.0;
       for (long j = threadIdx.x; j < numtosum; j += 256) {
@@ -1796,7 +1796,7 @@ __global__ __launch_bounds__(kCellDeepThreads) void k_cell_deep(
     for (int lv = split + 1; lv <= cfg.divmax && !R.done; ++lv) {
       const double c_il = CHOMP_ROMBERG_C[lv][threadIdx.x & 31];   // (in flight behind the nodes)
       const long numtosum = 1L << (lv - 1);
-      const double h = (b - a) / (double)numtosum, lox = a + 0.5 * h;
+      const double h = ldexp(b - a, 1 - lv), lox = a + 0.5 * h;   // ((b - a) / numtosum)
       double part = 0.0;
       long j = threadIdx.x;
       for (; j + (U - 1) * (long)NT < numtosum; j += U * (long)NT) {
@@ -1855,7 +1855,14 @@ struct CovProjIntegrand {
   double K, norm;
   __device__ __forceinline__ double operator()(double chi) const {
     const double D = G->me.growth_factor(G->me.redshift(chi));
-    return norm * P->template eval_t<BAO>(K / chi) * (G->wa(chi) * G->wb(chi) * D * D / (chi * chi));
+    // Where the lower limit is chi = K / k_max (the large-K knots), the end point's wavenumber
+    // K / (K / k_max) is k_max or the double above it, by the luck of two roundings -- and halo
+    // spectra are zero above k_max (halo.py:649-672): half an end-point value more or less in
+    // every trapezoid sum, four Romberg levels and 1e-6 of the knot.  The reference's own knots
+    // (G12) all sit on the k_max side; a wavenumber within 2^-50 above k_max is k_max here.
+    double k = K / chi;
+    if (k > P->k_max && k <= P->k_max * (1.0 + 8.9e-16)) k = P->k_max;
+    return norm * P->template eval_t<BAO>(k) * (G->wa(chi) * G->wb(chi) * D * D / (chi * chi));
   }
 };
 

@@ -52,6 +52,27 @@ __device__ __forceinline__ double wave_sum(double v) {
   return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
 }
 
+// The same sum where only lanes 0..31 (0..15) can hold anything but zero -- the Romberg rows: lane
+// m < 32 holds C[i][m] T_m -- without the rows of lanes that hold the zeros: the bits of wave_sum
+// of the same vector ((r0 + r16) + (0 + 0)), six (nine) vector instructions fewer per row.
+// What lanes 32..63 (16..63) hold does not matter.
+__device__ __forceinline__ double wave_sum32(double v) {
+  asm("" : "+v"(v));            // (the caller's product, rounded: not contracted into the first add)
+  v += dpp_move<0xB1>(v);
+  v += dpp_move<0x4E>(v);
+  v += dpp_move<0x124>(v);
+  v += dpp_move<0x128>(v);
+  return readlane_d(v, 0) + readlane_d(v, 16);
+}
+__device__ __forceinline__ double wave_sum16(double v) {
+  asm("" : "+v"(v));
+  v += dpp_move<0xB1>(v);
+  v += dpp_move<0x4E>(v);
+  v += dpp_move<0x124>(v);
+  v += dpp_move<0x128>(v);
+  return readlane_d(v, 0);
+}
+
 __device__ __forceinline__ double dpp_or_shfl_xor(double v, int offset) {
   return __shfl_xor(v, offset, 64);
 }
@@ -184,9 +205,9 @@ struct RombergResume {
     const int lane = threadIdx.x & 63;
     n *= 2.0;
     ordsum += S;
-    const double Ti = range * ordsum / n;
+    const double Ti = ldexp(range * ordsum, -i);          // (/ n, n = 2^i: the same bits, one instruction)
     if (lane == i) Tl = Ti;
-    const double cur = wave_sum(lane < 32 ? c_il * Tl : 0.0);
+    const double cur = wave_sum32(c_il * Tl);
     const double err = fabs(cur - prev);
     prev = cur;
     value = cur;
@@ -219,9 +240,9 @@ __device__ __forceinline__ RombergOut<NF> romberg_group(const F& f, double a, do
 
   auto advance = [&](int q, int i, double S, double n, double c_il) {
     ordsum[q] += S;
-    const double Ti = intrange * ordsum[q] / n;          // R[i][0]
+    const double Ti = ldexp(intrange * ordsum[q], -i);   // R[i][0] (/ n, n = 2^i: the same bits)
     if (lane == i) Tl[q] = Ti;
-    const double cur = wave_sum(lane < 32 ? c_il * Tl[q] : 0.0);
+    const double cur = wave_sum32(c_il * Tl[q]);
     const double err = fabs(cur - prev[q]);
     prev[q] = cur;
     out.value[q] = cur;
@@ -271,7 +292,7 @@ __device__ __forceinline__ RombergOut<NF> romberg_group(const F& f, double a, do
         const int tz = __builtin_ctz((unsigned)gt);
         lev = L0 - tz;
         j = (long)(((gt >> tz) - 1) >> 1);
-        const double h = intrange / (double)(1L << (lev - 1));
+        const double h = ldexp(intrange, 1 - lev);
         x = (a + 0.5 * h) + h * (double)j;
       }
       detail::call_f<F, NF>(f, x, v, lev, j, 0);
@@ -353,7 +374,7 @@ __device__ __forceinline__ RombergOut<NF> romberg_group(const F& f, double a, do
     const double c_il = CHOMP_ROMBERG_C[i][cl];          // latency hidden by the nodes
     n *= 2.0;
     const long numtosum = 1L << (i - 1);
-    const double h = intrange / (double)numtosum;
+    const double h = ldexp(intrange, 1 - i);              // (intrange / numtosum)
     const double lox = a + 0.5 * h;
     double part[NF];
 #pragma unroll
@@ -431,9 +452,9 @@ __device__ __forceinline__ RombergOut<NF> romberg_wave6(const F& f, double a, do
   bool all_done = false;
   auto advance = [&](int q, int i, double S, double n, double c_il) {
     ordsum[q] += S;
-    const double Ti = intrange * ordsum[q] / n;          // R[i][0]
+    const double Ti = ldexp(intrange * ordsum[q], -i);   // R[i][0] (/ n, n = 2^i: the same bits)
     if (lane == i) Tl[q] = Ti;
-    const double cur = wave_sum(lane < 32 ? c_il * Tl[q] : 0.0);
+    const double cur = wave_sum32(c_il * Tl[q]);
     const double err = fabs(cur - prev[q]);
     prev[q] = cur;
     out.value[q] = cur;
@@ -455,7 +476,7 @@ __device__ __forceinline__ RombergOut<NF> romberg_wave6(const F& f, double a, do
       const int tz = __builtin_ctz((unsigned)lane);
       lev = L0 - tz;
       j = (long)(((lane >> tz) - 1) >> 1);
-      const double h = intrange / (double)(1L << (lev - 1));
+      const double h = ldexp(intrange, 1 - lev);
       x = (a + 0.5 * h) + h * (double)j;
     }
     detail::call_f<F, NF>(f, x, v, lev, j, 0);
@@ -494,20 +515,19 @@ __device__ __forceinline__ RombergOut<NF> romberg_wave6(const F& f, double a, do
     // them in order.  Same operations on the same operands as the row-by-row replay.
     double nq = 1.0;
     {
-      double os = ordsum[q], mine = ordsum[q], pw = 1.0, mypw = 1.0;
+      double os = ordsum[q], mine = ordsum[q];
       double osum[L0max + 1];
       osum[0] = os;
 #pragma unroll
       for (int i = 1; i <= L0max; ++i) {
         os += Ls[i];
         osum[i] = os;
-        pw *= 2.0;
-        if (i <= lane) { mine = os; mypw = pw; }
+        if (i <= lane) mine = os;
       }
-      const double T = lane <= L0max ? intrange * mine / mypw : 0.0;
+      const double T = lane <= L0max ? ldexp(intrange * mine, -lane) : 0.0;   // (/ 2^lane)
       double cur[L0max + 1];
 #pragma unroll
-      for (int i = 1; i <= L0max; ++i) cur[i] = wave_sum(lane <= i ? crow[i] * T : 0.0);
+      for (int i = 1; i <= L0max; ++i) cur[i] = wave_sum16(lane <= i ? crow[i] * T : 0.0);
       int stop = 0;
 #pragma unroll
       for (int i = 1; i <= L0max; ++i) {
@@ -541,7 +561,7 @@ __device__ __forceinline__ RombergOut<NF> romberg_wave6(const F& f, double a, do
     const double c_il = CHOMP_ROMBERG_C[i][cl];
     n *= 2.0;
     const long numtosum = 1L << (i - 1);
-    const double h = intrange / (double)numtosum;
+    const double h = ldexp(intrange, 1 - i);              // (intrange / numtosum)
     const double lox = a + 0.5 * h;
     double part[NF];
 #pragma unroll

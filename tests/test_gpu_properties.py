@@ -227,6 +227,20 @@ def test_posted_status_is_the_status_and_warns_when_looked_at():
     hg.setup("power_mm")                     # clears the device's words ...
     assert list(hg.status()) == [0, 0]
     assert list(hg.ctx.status_wait(0, 2)) == list(now)     # ... not the posted copy
+    # the words of a post are the finalising blocks' own writes into one of two pinned regions:
+    # set-ups that come round to the posted region again collect it first, nothing is lost
+    hg.setup("power_gm")
+    hg.ctx.status_post()
+    for _ in range(3):
+        hg.setup("power_mm")
+    assert list(hg.ctx.status_wait(0, 2)) == list(now)
+    assert list(hg.ctx.status_wait(1, 1)) == [now[1]]
+    hg.ctx.status_post()                     # ... and the next post is the last set-up's
+    assert list(hg.ctx.status_wait(0, 2)) == [0, 0]
+    # a post behind a set-up that did not end in a halo set-up (mass function only) is a copy
+    hg.ctx.epochs_set(hg._c_cosmo, hg._z)
+    hg.ctx.status_post()
+    assert list(hg.ctx.status_wait(0, 2)) == list(hg.ctx.status(0, 2))
     d2r = numpy.pi / 180.0
     cm = cosmology.MultiEpoch(0.0, 5.0)
     wa = kernel.WindowFunctionGalaxy(kernel.dNdzMagLim(0.0, 2.0, 2.0, 0.3, 2.0), cm)
