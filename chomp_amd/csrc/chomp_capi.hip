@@ -21,6 +21,7 @@
 #include "../../include/chomp_mi355x.h"
 #include "chomp_power_kernels.h"
 #include "chomp_proj_kernels.h"
+#include "chomp_probe_kernel.h"
 
 using namespace chomp;
 
@@ -893,7 +894,19 @@ int chomp_epochs_set(chomp_ctx* ctx, size_t n_epoch, const chomp_cosmo* cosmo,
     if (ctx->with_bao) CHOMP_SIGMA_NODES(true, 1); else CHOMP_SIGMA_NODES(false, 1);
   }
 #undef CHOMP_SIGMA_NODES
-  // (k_epoch_probe lives in chomp_probe.hip: the one kernel that is faster WITH machine LICM)
+  // (k_epoch_probe lives in chomp_probe.hip: the one kernel that is faster WITH machine LICM --
+  //  but for the probing phase of a large batch, one wavefront per probe, compiled here)
+  if (n_epoch >= 128) {
+    const dim3 pgrid((unsigned)n_epoch, 2 * kProbes);
+    if (ctx->with_bao)
+      hipLaunchKernelGGL((k_epoch_probe<true, 1, 1>), pgrid, dim3(64), 0, ctx->stream, ctx->cfg,
+                         ctx->d_epochs, ctx->d_search, ctx->d_cand, ctx->d_snodes, ctx->d_probe,
+                         ctx->d_count, ctx->d_status);
+    else
+      hipLaunchKernelGGL((k_epoch_probe<false, 1, 1>), pgrid, dim3(64), 0, ctx->stream, ctx->cfg,
+                         ctx->d_epochs, ctx->d_search, ctx->d_cand, ctx->d_snodes, ctx->d_probe,
+                         ctx->d_count, ctx->d_status);
+  }
   chomp::launch_epoch_probe(ctx->with_bao != 0, (unsigned)n_epoch, ctx->stream, ctx->cfg,
                             ctx->d_epochs, ctx->d_search, ctx->d_cand, ctx->d_snodes,
                             ctx->d_probe, ctx->d_count, ctx->d_status);

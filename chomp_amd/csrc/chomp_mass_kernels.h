@@ -674,7 +674,7 @@ __device__ __forceinline__ double sigma2_block(const Epoch& E, const double* sno
                                  loose->lo2 / amp2, loose->hi2 / amp2};
     RombergOut<1> r;
     bool fused = false;
-    if constexpr (NW == 1) fused = loose == nullptr && cfg.divmax >= 6;
+    if constexpr (NW == 1) fused = cfg.divmax >= 6;
     if (fused) {
       // one wavefront: levels 0..6 in ONE pass (lane p on node p of the level-6 grid, the upper
       // end point by every lane) and their rows replayed -- walked one by one they are seven
@@ -682,7 +682,8 @@ __device__ __forceinline__ double sigma2_block(const Epoch& E, const double* sno
       // integral of the nu table
       double fb[1];
       f(hi, fb, 0, 1);
-      r = romberg_wave6<1>(f, lo, hi, fb, cfg.global_precision, rtol, cfg.divmax);
+      r = romberg_wave6<1>(f, lo, hi, fb, cfg.global_precision, rtol, cfg.divmax, nullptr,
+                           loose ? &ls : nullptr);
     } else {
       r = romberg_group<NW, 1, SigmaTabIntegrand<BAO>, UNROLL>(
           f, lo, hi, cfg.global_precision, rtol, cfg.divmax, red, nullptr, loose ? &ls : nullptr);
@@ -700,10 +701,10 @@ __device__ __forceinline__ double sigma2_block(const Epoch& E, const double* sno
     Scalar1<SigmaInterpIntegrand> w{f};
     RombergOut<1> r;
     bool fused = false;
-    if constexpr (NW == 1) fused = loose == nullptr && cfg.divmax >= 6;
+    if constexpr (NW == 1) fused = cfg.divmax >= 6;
     if (fused) {
       const double fb[1] = {f(hi)};
-      r = romberg_wave6<1>(w, lo, hi, fb, cfg.global_precision, rtol, cfg.divmax);
+      r = romberg_wave6<1>(w, lo, hi, fb, cfg.global_precision, rtol, cfg.divmax, nullptr, loose);
     } else {
       r = romberg_group<NW, 1>(w, lo, hi, cfg.global_precision, rtol, cfg.divmax, red, nullptr, loose);
     }
@@ -990,8 +991,8 @@ __device__ __forceinline__ SidePlan plan_side(const Epoch& E, const double* lns,
   __syncthreads();
   if (threadIdx.x == 0) *sh = kSearchJ;
   __syncthreads();
-  {
-    const int j = kStride * (1 + (int)threadIdx.x) - 1;        // 7, 15, ..., 2047
+  for (int t = (int)threadIdx.x; t < 256; t += (int)blockDim.x) {   // (one round for a block of 256)
+    const int j = kStride * (1 + t) - 1;                       // 7, 15, ..., 2047
     if (j < kSearchJ && passes(j)) atomicMin(sh, j);
   }
   __syncthreads();
@@ -1042,8 +1043,22 @@ __global__ __launch_bounds__(64 * NW) void k_nu_table(chomp_config cfg, TabLayou
                                                       int epochs_fastest) {
   __shared__ Epoch E;
   __shared__ double red[romberg_scratch<NW, 1>()];
-  const int e = epochs_fastest ? (int)blockIdx.x : (int)blockIdx.y;
+  int e = epochs_fastest ? (int)blockIdx.x : (int)blockIdx.y;
   int i = (int)blockIdx.x;
+  if (!epochs_fastest) {
+    // A cosmology per epoch: an epoch's NM integrals read the same 131 KB node table, and
+    // workgroups go to the eight XCDs -- eight L2s -- round-robin by linear index: (mass, epoch)
+    // order puts every table into all eight.  Linear block b runs on XCD b mod 8; within an XCD
+    // the blocks walk through (epoch, mass) with the epochs = that XCD mod 8 -- one L2 per table
+    // (1024 cosmologies: 1 GB of table fills per launch down to 134 MB).
+    const int NM = (int)gridDim.x, n = (int)gridDim.y;
+    const int b = (int)blockIdx.x + NM * (int)blockIdx.y;
+    if (b < 8 * NM * (n / 8)) {
+      const int slot = b >> 3;
+      e = (slot / NM) * 8 + (b & 7);
+      i = slot % NM;
+    }
+  }
   if (epochs_fastest) {
     // Largest mass first -- but the first two and the last two rows take four masses from the
     // MIDDLE of the table.  Blocks go to the SIMDs round-robin (1024 of them: a SIMD gets linear

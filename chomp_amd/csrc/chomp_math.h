@@ -43,6 +43,34 @@ __device__ __forceinline__ double fma_k(double a, double b, double c) {
 CHOMP_HD double fma_k(double a, double b, double c) { return fma(a, b, c); }
 #endif
 
+// exp for every unqualified call inside this namespace.  Device code: the ROCm device library's
+// algorithm and coefficients (n = rint(x log2 e), Cody-Waite reduction by ln 2 in two FMAs, the
+// degree-11 polynomial, ldexp), operation for operation -- the same bits -- with the polynomial's
+// addends read from scalar registers (fma_k): 9 of its 11 steps cost the library's inlined code
+// three vector instructions each.  The library's two range clamps are left out: v_ldexp_f64
+// overflows to inf and underflows to 0 by itself.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double exp(double x) {
+  const double n = rint(x * 1.4426950408889634);                       // 0x3ff71547652b82fe
+  double r = fma(-6.93147180559945286e-01, n, x);                      // ln 2: 0x3fe62e42fefa39ef
+  r = fma(-2.31904681384629956e-17, n, r);                             //       0x3c7abc9e3b39803f
+  double p = fma(r, __longlong_as_double(0x3e5ade156a5dcb37LL), __longlong_as_double(0x3e928af3fca7ab0cLL));
+  p = fma_k(r, p, __longlong_as_double(0x3ec71dee623fde64LL));
+  p = fma_k(r, p, __longlong_as_double(0x3efa01997c89e6b0LL));
+  p = fma_k(r, p, __longlong_as_double(0x3f2a01a014761f6eLL));
+  p = fma_k(r, p, __longlong_as_double(0x3f56c16c1852b7b0LL));
+  p = fma_k(r, p, __longlong_as_double(0x3f81111111122322LL));
+  p = fma_k(r, p, __longlong_as_double(0x3fa55555555502a1LL));
+  p = fma_k(r, p, __longlong_as_double(0x3fc5555555555511LL));
+  p = fma_k(r, p, __longlong_as_double(0x3fe000000000000bLL));
+  p = fma(r, p, 1.0);
+  p = fma(r, p, 1.0);
+  return ldexp(p, (int)n);
+}
+#else
+CHOMP_HD double exp(double x) { return ::exp(x); }
+#endif
+
 // ---------------------------------------------------------------------------
 // Special-function tables as one POD block: uploaded once per context, staged in
 // LDS by the kernels that need them.

@@ -1,5 +1,6 @@
 // chomp_probe_kernel.h -- k_epoch_probe, the certifying probes of the mass-limit search
-// (included by chomp_probe.hip only: see launch_epoch_probe in chomp_mass_kernels.h).
+// (chomp_probe.hip instantiates the four-wavefront phases, chomp_capi.hip the single-wavefront
+// probing phase of a large batch: see launch_epoch_probe in chomp_mass_kernels.h).
 #pragma once
 
 #include "chomp_mass_kernels.h"
@@ -20,13 +21,17 @@ namespace chomp {
 // batch is throughput-bound, and there the fence in front of every block's arrival count -- an
 // L2 write-back on this chip -- costs more than the probes: PHASE 1 (the same grid) only
 // probes, PHASE 2 (grid n_epoch) certifies behind the kernel boundary.  Same numbers.
-template <bool BAO, int PHASE>
-__global__ __launch_bounds__(64 * kInitNW) void k_epoch_probe(
+// NW: wavefronts per block.  kInitNW for a (k, z) grid (the launch lasts as long as one probe:
+// four wavefronts on each) and for the certifying phase; 1 for the probing phase of a large
+// batch -- its 8 n_epoch integrals fill the chip as single wavefronts, with no barrier or LDS
+// hand-over per Romberg level (1024 epochs: 241 -> us, the kernel was at 41 % of its VALU issue rate).
+template <bool BAO, int PHASE, int NW = kInitNW>
+__global__ __launch_bounds__(64 * NW, NW == 1 ? 4 : 1) void k_epoch_probe(
     chomp_config cfg, Epoch* __restrict__ epochs, double* __restrict__ search,
     const double* __restrict__ cand, const double* __restrict__ snodes,
     double* __restrict__ probe, int* __restrict__ count, unsigned* __restrict__ status) {
   __shared__ Epoch E;
-  __shared__ double red[romberg_scratch<kInitNW, 1>()];
+  __shared__ double red[romberg_scratch<NW, 1>()];
   __shared__ double lns[kSGrid];   // the cosmology's coarse ln S(R) table
   __shared__ int last, sh_j;
   __shared__ double seeds[2][6];   // per side: dir, jl, nu_l, jh, nu_h, n_eval (uncertified)
@@ -53,7 +58,7 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_probe(
   PSTAMP(1);
   if (chi_role) {                  // comoving distance, cosmology.py:106-110
     EIntegrand f{E.om0, E.ol0, E.or0, E.H0};
-    const double chi = romberg1<kInitNW>(f, 0.0, E.z, cfg.global_precision,
+    const double chi = romberg1<NW>(f, 0.0, E.z, cfg.global_precision,
                                          cfg.cosmo_precision, cfg.divmax, red);
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_probe(
       // (away from an edge candidate 0 fails by the margin of the estimate)
       if ((c > 0 || (c == 0 && plan.at_edge)) && c < kSearchJ) {
         const double* tab = plan.dir < 0 ? T.down : T.up;
-        nu_mine = nu_probe<kInitNW, BAO>(E, snode, tab[c], cfg, T.thr_lo, T.thr_hi, red);
+        nu_mine = nu_probe<NW, BAO>(E, snode, tab[c], cfg, T.thr_lo, T.thr_hi, red);
       }
     }
     if (threadIdx.x == 0) {
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_probe(
     }
   }
   PSTAMP(4);
-  if constexpr (PHASE == 1) return;
+  if constexpr (PHASE != 1) {
   if constexpr (PHASE == 0) {
     if (threadIdx.x == 0) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the record's stores (above) have landed
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_probe(
     if (!open_side[sd]) continue;                // block-uniform
     int n_eval = (int)seeds[sd][5];
     bool exhausted = false;
-    const double mass = search_side_exact<kInitNW, BAO>(
+    const double mass = search_side_exact<NW, BAO>(
         E, snode, sd, cfg, cand, red, &n_eval, &exhausted, (int)seeds[sd][0], (int)seeds[sd][1],
         seeds[sd][2], (int)seeds[sd][3], seeds[sd][4]);
     if (threadIdx.x == 0) {
@@ -232,6 +237,7 @@ __global__ __launch_bounds__(64 * kInitNW) void k_epoch_probe(
   copy_doubles(reinterpret_cast<double*>(&epochs[e]), reinterpret_cast<const double*>(&E),
                kEpochDoubles);
   PSTAMP(6);
+  }  // (PHASE != 1)
 }
 
 }  // namespace chomp

@@ -437,11 +437,13 @@ __device__ __forceinline__ RombergOut<NF> romberg_group(const F& f, double a, do
 // A knot that scipy stops at level 6 costs one evaluation per lane, at level 7 two.
 // Needs divmax >= 6.  dump (optional, kRombergDump * NF doubles, LDS or global): the state the
 // integral stopped in, as romberg_group leaves it, for whoever carries it on (RombergResume).
+// loose (optional): the probes' early stopping rule (RombergLoose), as in romberg_group.
 template <int NF, class F>
 __device__ __forceinline__ RombergOut<NF> romberg_wave6(const F& f, double a, double b,
                                                         const double (&fb)[NF], double tol,
                                                         double rtol, int divmax,
-                                                        double* dump = nullptr) {
+                                                        double* dump = nullptr,
+                                                        const RombergLoose* loose = nullptr) {
   constexpr int L0max = 6;
   const int lane = threadIdx.x & 63;
   const int cl = lane & 31;
@@ -460,6 +462,7 @@ __device__ __forceinline__ RombergOut<NF> romberg_wave6(const F& f, double a, do
     out.value[q] = cur;
     out.level[q] = i;
     if (err < tol || err < rtol * fabs(cur)) done[q] = true;
+    if (loose != nullptr && loose->decides(err, cur)) done[q] = true;
   };
   constexpr int L0 = L0max, N0 = 1 << L0max;             // (the caller guarantees divmax >= 6)
   double crow[L0max + 1];
@@ -539,6 +542,7 @@ __device__ __forceinline__ RombergOut<NF> romberg_wave6(const F& f, double a, do
           out.level[q] = i;
           stop = i;
           if (err < tol || err < rtol * fabs(cur[i])) done[q] = true;
+          if (loose != nullptr && loose->decides(err, cur[i])) done[q] = true;
         }
       }
       // (the state the row-by-row replay leaves: the sums and T_l up to the row reached)
