@@ -353,6 +353,8 @@ def batch_leg(D, n, distinct, steps, warmup, stream, which="power_mm", mf="st"):
         res["stage_k_tflops"] = rk["achieved"]
         res["flop_per_step"] = rk["flop_per_step"]
         res["flop_source"] = "SQ counters of this batch (%s)" % rk["note"].split("counters: ")[-1]
+        if "frac_at_round3_flop_count" in rk:
+            res["stage_k_frac_at_round3_flop_count"] = rk["frac_at_round3_flop_count"]
     else:
         # no counter pass of this size: FLOP per epoch of the measured 1024-epoch batch of the
         # same kind (the per-epoch work does not depend on the batch size; the cosmology-only
@@ -481,14 +483,26 @@ def stage_k_roofline(stage_k_seconds, workload):
     if cnt is None:
         return None
     flop = float(cnt["fp64_flop_per_step"])
-    return {"bound": "fp64_valu", "achieved": flop / stage_k_seconds / 1e12,
-            "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": flop / stage_k_seconds / 1e12 / FP64_VALU_PEAK_TFLOPS,
-            "flop_per_step": flop, "stage_k_ms": stage_k_seconds * 1e3,
-            "valu_insts_per_step": cnt.get("valu_insts_per_step"),
-            "kernels": cnt.get("kernels"),
-            "note": "chain of %d dependent launches; counters: profiles/%s"
-                    % (len(cnt.get("kernels", [])), counters_file)}
+    out = {"bound": "fp64_valu", "achieved": flop / stage_k_seconds / 1e12,
+           "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "frac": flop / stage_k_seconds / 1e12 / FP64_VALU_PEAK_TFLOPS,
+           "flop_per_step": flop, "stage_k_ms": stage_k_seconds * 1e3,
+           "valu_insts_per_step": cnt.get("valu_insts_per_step"),
+           "kernels": cnt.get("kernels"),
+           "note": "fp64 operations the kernels of THIS round execute for the step (SQ counters); "
+                   "chain of %d dependent launches; counters: profiles/%s"
+                   % (len(cnt.get("kernels", [])), counters_file)}
+    # The same work priced at what the previous round's kernels executed for it: a round that
+    # removes redundant fp64 operations (divisions by powers of two, per-wavefront copies of a
+    # prologue) lowers `flop_per_step` with the time, and `frac` alone then hides the speed-up.
+    try:
+        with open(os.path.join(ROOT, "profiles", "round3_stage_k_counters.json")) as fh:
+            f3 = float(json.load(fh)[workload]["fp64_flop_per_step"])
+        out["flop_per_step_round3_kernels"] = f3
+        out["frac_at_round3_flop_count"] = f3 / stage_k_seconds / 1e12 / FP64_VALU_PEAK_TFLOPS
+    except (OSError, ValueError, KeyError):
+        pass
+    return out
 
 
 def launch_ranks(n):

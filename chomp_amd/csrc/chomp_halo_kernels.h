@@ -358,6 +358,10 @@ __device__ __forceinline__ void halo_nodes_block(const chomp_config& cfg, const 
   if (threadIdx.x == 0 && chunk == 0) {
     node[kNodeFields * kNodeCount] = a;
     node[kNodeFields * kNodeCount + 1] = b;
+    // (the limits of the knots' ln k grid, halo.py:52-54, for k_halo_knots: two logarithms --
+    //  ~190 instructions -- at the head of every one of its single-wavefront blocks otherwise)
+    node[kNodeFields * kNodeCount + 2] = log(cfg.k_min);
+    node[kNodeFields * kNodeCount + 3] = log(cfg.k_max);
   }
   // (the knots' end points from the TOP of the block: with six or more chunks of a level-10
   //  table the node loop leaves the last wavefront idle, and its lanes do this beside it -- a
@@ -1222,7 +1226,7 @@ __global__ __launch_bounds__(KNW == 0 ? 64 : 256, KNW == 1 ? 3 : 1) void k_halo_
   const double* ep = endp + ((size_t)e * 3 + group) * 2 * NK + 2 * (have ? ik : 0);
   const double fb[2] = {ep[0], ep[1]};
   double* t = tab + (size_t)e * L.stride;
-  const double ln_k0 = log(cfg.k_min), ln_k1 = log(cfg.k_max);
+  const double ln_k0 = node[kNodeFields * kNodeCount + 2], ln_k1 = node[kNodeFields * kNodeCount + 3];
   const double ln_k = linspace_at(ln_k0, ln_k1, NK, have ? ik : 0);          // halo.py:52-54
   const bool exclusion = (mask & kMaskExclusion) != 0;
   NodeIntegrand f{&S, node, KnotK::uniform(ln_k), exclusion};

@@ -292,13 +292,19 @@ int chomp_get_scalars(chomp_ctx* ctx, size_t epoch, double* out);
 #define CHOMP_ST_HALO_DIVMAX_PP_GG 0x1000u
 #define CHOMP_ST_NONFINITE 0x10000u
 int chomp_get_status(chomp_ctx* ctx, size_t epoch0, size_t n, unsigned* out);
-/* The same words without draining the stream.  chomp_status_post enqueues a copy of every epoch's
- * word to pinned host memory, ordered after the work enqueued so far (call it right after a
- * set-up); chomp_status_wait blocks until THAT copy has landed -- not until the stream is idle --
- * and returns the words as they were then.  A caller that keeps its samples on the device posts
- * after each set-up and waits whenever it next has a reason to look (the reference printed its
- * AccuracyWarning at the time of the integral; here the time of looking is the caller's choice).
- * ERR_STATE: wait before any post; post while the stream is being captured. */
+/* The same words without draining the stream.  chomp_status_post makes every epoch's word, as
+ * it is behind the work enqueued so far (call it right after a set-up), available in pinned host
+ * memory; chomp_status_wait blocks until THOSE words have landed -- not until the stream is idle
+ * -- and returns them as they were then, whatever has been set up since.  Behind a halo set-up
+ * (chomp_stage_k, chomp_halo_setup) a post puts nothing on the stream: the set-up's finalising
+ * blocks have written the words, tagged with the set-up's sequence number, to the pinned words
+ * themselves, and the wait polls for that number (an event record alone costs a step ~10 us on
+ * this stack).  Behind any other set-up it is a copy and an event.  A caller that keeps its
+ * samples on the device posts after each set-up and waits whenever it next has a reason to look
+ * (the reference printed its AccuracyWarning at the time of the integral; here the time of
+ * looking is the caller's choice).
+ * ERR_STATE: wait before any post; wait while the stream is being captured; wait for a set-up
+ * that never finalised its epochs (it failed). */
 int chomp_status_post(chomp_ctx* ctx);
 int chomp_status_wait(chomp_ctx* ctx, size_t epoch0, size_t n, unsigned* out);
 
