@@ -864,17 +864,18 @@ def test_many_cosmologies_in_one_batch_equal_single_epochs():
 def test_large_batch_shapes_vs_oracle():
     """The launch shapes only a large batch takes -- from 16 distinct cosmologies on
     k_sigma_nodes<., 4> + k_sigma_lns (cosmology-only tables without arrival counts, sigma_8
-    and the aiming table behind the kernel boundary), from 128 epochs on k_epoch_probe<., 1>
-    + <., 2> (probes, then their certification as a launch of its own), single-wavefront knot
-    blocks -- pinned DIRECTLY to the oracle, not to the device's own single-epoch answer:
-    eight epochs of a 144-epoch design (the consumer: simulation_design.py:116-155) against
+    and the aiming table behind the kernel boundary; k_nu_table's XCD-aware block order, whose
+    last 147 mod 8 epochs take the plain one), from 128 epochs on k_epoch_probe<., 1, 1>
+    + <., 2> (single-wavefront probes, then their certification as a launch of its own),
+    single-wavefront knot blocks -- pinned DIRECTLY to the oracle, not to the device's own
+    single-epoch answer: nine epochs of a 147-epoch design (the consumer: simulation_design.py:116-155) against
     oracle.chomp_oracle -- the ln M limits of the mass function bit for bit wherever the
     status word does not flag a saturated search, sigma_norm, the nu table and P_mm(k) to 1e-7."""
     from chomp_amd import grid, _lib
     from oracle import chomp_oracle as o
     rng = numpy.random.default_rng(404)
     base = dict(o.default_cosmo_dict)
-    n, n_cosmo = 144, 24
+    n, n_cosmo = 147, 24
     pool = []
     for _ in range(n_cosmo):
         om = rng.uniform(0.25, 0.33)
@@ -888,7 +889,7 @@ def test_large_batch_shapes_vs_oracle():
     p_big = big.power("power_mm", k)
     status = big.status()
     n_exact = 0
-    for i in (0, 5, 23, 24, 71, 100, 127, 143):
+    for i in (0, 5, 23, 24, 71, 100, 127, 143, 146):
         e = o.epoch(cds[i], zs[i])
         lo, hi, _ = o.mass_limits(e)
         sc = big.ctx.scalars(i)
@@ -906,6 +907,34 @@ def test_large_batch_shapes_vs_oracle():
             assert numpy.max(numpy.abs(p_big[i][ok] / ref[ok] - 1)) < 1e-7, (i, zs[i])
             assert numpy.array_equal(p_big[i][~ok], ref[~ok])
     assert n_exact >= 6
+
+
+def test_probe_shortcut_does_not_decide_on_coarse_rows():
+    """A case the randomised soak found (tools/soak.py 12 160, case 96): sigma^2(R) of the
+    candidate one 5 % step above the reference's mass_min has Romberg rows 3 and 4 -- 9 and 17
+    nodes -- that agree to 3.9e-7 and are both 0.9 % off, on the passing side of the band edge.
+    The probes' loose stopping rule (a device-only shortcut: 1e-6, clear of the edges) took
+    that for a converged integral and the search stopped a step early, unflagged, P_mm 6.6e-4
+    off.  The shortcut now decides nothing below Romberg level 8: the limits are the
+    reference's walk's, bit for bit, alone and as epoch 96 of 160 (single-wavefront probes)."""
+    from chomp_amd import grid
+    from oracle import chomp_oracle as o
+    cd = dict(o.default_cosmo_dict, omega_m0=0.282801919784524, omega_b0=0.04606049457071416,
+              omega_l0=0.717113386337925, h=0.615423691856908, sigma_8=0.7320155736315984,
+              n_scalar=0.9301320614204301)
+    z = 0.9637352201784997
+    e = o.epoch(cd, z)
+    lo, hi, _ = o.mass_limits(e)
+    ref = o.halo_power(o.halo_table(e, o.mass_table(e), families=("mm",)), "mm", numpy.logspace(-3, 2, 24))
+    for n, idx in ((1, 0), (160, 96)):
+        zs = numpy.linspace(0.0, 1.2, n)
+        zs[idx] = z
+        hg = grid.HaloGrid(zs, cosmo_dict=[cd] * n)
+        p = hg.power("power_mm", numpy.logspace(-3, 2, 24))
+        sc = hg.ctx.scalars(idx)
+        assert hg.status()[idx] == 0
+        assert sc["ln_mass_min"] == lo and sc["ln_mass_max"] == hi, (n, sc["ln_mass_min"] - lo)
+        assert numpy.max(numpy.abs(p[idx] / ref - 1)) < 1e-7
 
 
 def test_soak_seed_flag_iff_mismatch():
