@@ -345,6 +345,41 @@ def test_raw_kernel():
         kern.kernel_weighted_mean(lambda z: z)
 
 
+def test_bao_batch_of_many_epochs_equals_the_small_batch():
+    """The wiggle transfer function through the launch shapes of a large batch (the C ABI takes
+    with_bao for any number of epochs; the drop-in classes only ever ask for one): 130 epochs --
+    single-wavefront probes of the mass-limit search (k_epoch_probe<true, 1, 1>), their
+    certification behind the kernel boundary, single-wavefront nu-table and knot blocks --
+    against the same epochs in batches of four (four wavefronts per integral: other orders of
+    summation): the mass limits bit for bit, the nu table and P_mm to 1e-11."""
+    import numpy as np
+    from chomp_amd import grid, _lib
+    z = np.linspace(0.0, 1.3, 130)
+    k = np.logspace(-3, 2, 32)
+
+    class BaoGrid(grid.HaloGrid):
+        def setup(self, which="power_mm"):
+            _, need = grid._WHICH[which]
+            self.ctx.epochs_set(self._c_cosmo, self._z, with_bao=True)
+            self.ctx.stage_k(self._c_halo, self.kind, self._c_halo, self._c_hod, need)
+            self._tables = need
+
+    big = BaoGrid(z)
+    p_big = big.power("power_mm", k)
+    assert not big.status().any()
+    for i0 in (0, 64, 126):
+        small = BaoGrid(z[i0:i0 + 4])
+        p = small.power("power_mm", k)
+        for j in range(4):
+            a, b = big.ctx.scalars(i0 + j), small.ctx.scalars(j)
+            assert a["ln_mass_min"] == b["ln_mass_min"] and a["ln_mass_max"] == b["ln_mass_max"]
+            assert np.max(np.abs(big.ctx.table("nu", i0 + j) / small.ctx.table("nu", j) - 1)) < 1e-11
+        assert np.max(np.abs(p_big[i0:i0 + 4] / p - 1)) < 1e-11
+    # ... and the wiggles are there: not the no-wiggle spectrum
+    plain = grid.HaloGrid(z[:4]).power("power_mm", k)
+    assert np.max(np.abs(p_big[:4] / plain - 1)) > 1e-3
+
+
 def test_gaussian_covariance():
     """SURVEY 8(f) rank 4, Gaussian part: Covariance(corr, corr, nongaussian_cov=False)
     against the reference (G12): the projected-spectrum table over ln K, covariance_G of
