@@ -736,17 +736,6 @@ CHOMP_HD double eh_bao_transfer(const Epoch& e, double k) {
   return e.bao_ObO * (sinc * (Tb1 + Tb2)) + e.bao_OcO * Tc;
 }
 
-// cosmology.py:449-472
-CHOMP_HD double eh_transfer(const Epoch& e, double k) {
-  const double t = 1.0 + 0.43 * k * e.eh_s;
-  const double t2 = t * t;
-  const double Gamma_eff = e.eh_omh * (e.eh_alpha + (1.0 - e.eh_alpha) / (t2 * t2));
-  const double q = k * e.eh_theta / Gamma_eff;
-  const double L0 = log(2.0 * kE + 1.8 * q);
-  const double C0 = 14.2 + 731.0 / (1.0 + 62.5 * q);
-  return L0 / (L0 + C0 * q * q);
-}
-
 // ln x for a normal positive x to about 1 ulp (|error| < 3e-16 |ln x| + 2e-16) in ~35
 // instructions: x = 2^e m, m in [sqrt(1/2), sqrt(2)), ln m = 2 atanh((m-1)/(m+1)).
 // The library logarithm costs ~100; Stage E takes four logarithms per pair of k.
@@ -757,16 +746,16 @@ CHOMP_HD double fast_log(double x) {
   const double s = (m - 1.0) / (m + 1.0);                // |s| <= 0.1716
   const double z = s * s;
   double p = 1.0 / 23.0;
-  p = fma(p, z, 1.0 / 21.0);
-  p = fma(p, z, 1.0 / 19.0);
-  p = fma(p, z, 1.0 / 17.0);
-  p = fma(p, z, 1.0 / 15.0);
-  p = fma(p, z, 1.0 / 13.0);
-  p = fma(p, z, 1.0 / 11.0);
-  p = fma(p, z, 1.0 / 9.0);
-  p = fma(p, z, 1.0 / 7.0);
-  p = fma(p, z, 1.0 / 5.0);
-  p = fma(p, z, 1.0 / 3.0);
+  p = fma_k(p, z, 1.0 / 21.0);
+  p = fma_k(p, z, 1.0 / 19.0);
+  p = fma_k(p, z, 1.0 / 17.0);
+  p = fma_k(p, z, 1.0 / 15.0);
+  p = fma_k(p, z, 1.0 / 13.0);
+  p = fma_k(p, z, 1.0 / 11.0);
+  p = fma_k(p, z, 1.0 / 9.0);
+  p = fma_k(p, z, 1.0 / 7.0);
+  p = fma_k(p, z, 1.0 / 5.0);
+  p = fma_k(p, z, 1.0 / 3.0);
   const double s2 = s + s;
   const double lm = fma(s2 * z, p, s2);
   const double de = (double)e;
@@ -774,15 +763,11 @@ CHOMP_HD double fast_log(double x) {
   return fma(de, 6.93147180369123816490e-01, fma(de, 1.90821492927058770002e-10, lm));
 }
 
-// Stage E: 2 pi^2 (k/H0)^(3+n) T(k)^2 / k^3 -- linear_power(k) without its amplitude
-// (cosmology.py:449-472, 574-600) -- arranged with two divisions: q as one quotient, the
-// transfer function as L0 D / (L0 D + N q^2) with D = 1 + 62.5 q, N = 14.2 D + 731.
-template <bool BAO>
-CHOMP_HD double power_shape_t(const Epoch& e, double ln_k, double k) {
-  if (BAO) {
-    const double Tb = eh_bao_transfer(e, k);
-    return 2.0 * kPi * kPi * exp(fma(e.ns, ln_k, -(3.0 + e.ns) * e.ln_H0)) * Tb * Tb;
-  }
+// cosmology.py:449-472, arranged with two divisions instead of four and the ~35-instruction
+// logarithm above (the library's is ~95): q as one quotient, T = L0 D / (L0 D + N q^2) with
+// D = 1 + 62.5 q, N = 14.2 D + 731 -- the reference's L0 / (L0 + C0 q^2), C0 = 14.2 + 731 / D, to
+// ~3e-16.  One form for the sigma(R) node tables, linear_power and the streaming Stage E.
+CHOMP_HD double eh_transfer(const Epoch& e, double k) {
   const double t = 1.0 + 0.43 * k * e.eh_s;
   const double t2 = t * t, t4 = t2 * t2;
   const double q = k * e.eh_theta * t4 / (e.eh_omh * fma(e.eh_alpha, t4, 1.0 - e.eh_alpha));
@@ -790,7 +775,18 @@ CHOMP_HD double power_shape_t(const Epoch& e, double ln_k, double k) {
   const double D = fma(62.5, q, 1.0);
   const double N = fma(14.2, D, 731.0);
   const double LD = L0 * D;
-  const double T = LD / fma(N, q * q, LD);
+  return LD / fma(N, q * q, LD);
+}
+
+// Stage E: 2 pi^2 (k/H0)^(3+n) T(k)^2 / k^3 -- linear_power(k) without its amplitude
+// (cosmology.py:449-472, 574-600), the transfer function as eh_transfer arranges it.
+template <bool BAO>
+CHOMP_HD double power_shape_t(const Epoch& e, double ln_k, double k) {
+  if (BAO) {
+    const double Tb = eh_bao_transfer(e, k);
+    return 2.0 * kPi * kPi * exp(fma(e.ns, ln_k, -(3.0 + e.ns) * e.ln_H0)) * Tb * Tb;
+  }
+  const double T = eh_transfer(e, k);
   return 2.0 * kPi * kPi * exp(fma(e.ns, ln_k, -(3.0 + e.ns) * e.ln_H0)) * T * T;
 }
 // (transfer function chosen at run time: callers off the streaming path)

@@ -1,6 +1,6 @@
 """Randomised parity soak: device P_mm / P_gm against the oracle for random cosmologies,
 HODs and redshifts (not part of the test suite: the oracle takes seconds per case).
-    python tools/soak.py [seed] [n]
+    python tools/soak.py [seed] [n] [n_gm]      (n_gm: how many of the cases also compare P_gm, default 6)
 Exit code 1 if any epoch that the status word does not flag differs by more than 1e-4."""
 import os, sys, time, numpy
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
@@ -28,7 +28,7 @@ g = grid.HaloGrid(numpy.array(zs), cosmo_dict=cos, hod_dict=hods)
 pm = g.power("power_mm", k)
 from chomp_amd import _lib
 status = g.status()
-n_gm = min(n, 6)
+n_gm = min(n, int(sys.argv[3]) if len(sys.argv) > 3 else 6)
 pg = g.power("power_gm", k)
 worst, n_flag, n_unflagged_bad = 0.0, 0, 0
 for i in range(n):
