@@ -190,8 +190,14 @@ class Halo(object):
 
     def _power(self, which, need, k):
         ka = numpy.asarray(k, dtype=numpy.float64)
-        ctx = self._sync(need)
-        return ctx.power(self._power_code(which), ka, 0, 1).reshape(ka.shape)
+        # the evaluation is queued behind the set-up BEFORE the host looks at the set-up's status
+        # words: a host array comes back through a synchronising copy anyway, after which the
+        # words are there (no wait of their own, and the evaluation's launch does not wait for
+        # the host to wake up in between)
+        ctx = self._sync(need, defer_status=True)
+        out = ctx.power(self._power_code(which), ka, 0, 1).reshape(ka.shape)
+        self._resolve_status(stacklevel=5)
+        return out
 
     # -- reference surface -----------------------------------------------------
     def get_extrapolation(self):
