@@ -15,8 +15,9 @@ void launch_epoch_probe(bool bao, unsigned n_epoch, hipStream_t stream, const ch
   hipLaunchKernelGGL((k_epoch_probe<BAO, PHASE>), GRID, block, 0, stream, cfg, epochs, search, \
                      cand, snodes, probe, count, status)
   if (n_epoch >= 128) {            // a large batch: probed by the caller (k_epoch_probe<., 1, 1>,
-                                   // instantiated in chomp_capi.hip -- without machine LICM: 94 against
-                                   // 152 registers), certified here, behind the kernel boundary
+                                   // instantiated in chomp_capi.hip, the unit without machine LICM,
+                                   // capped at 128 registers: 120), certified here, behind the
+                                   // kernel boundary
     if (bao) CHOMP_PROBE(true, 2, dim3(n_epoch)); else CHOMP_PROBE(false, 2, dim3(n_epoch));
   } else {
     if (bao) CHOMP_PROBE(true, 0, grid); else CHOMP_PROBE(false, 0, grid);

@@ -24,7 +24,8 @@ namespace chomp {
 // NW: wavefronts per block.  kInitNW for a (k, z) grid (the launch lasts as long as one probe:
 // four wavefronts on each) and for the certifying phase; 1 for the probing phase of a large
 // batch -- its 8 n_epoch integrals fill the chip as single wavefronts, with no barrier or LDS
-// hand-over per Romberg level (1024 epochs: 241 -> us, the kernel was at 41 % of its VALU issue rate).
+// hand-over per Romberg level (1024 epochs: 241 -> 72 us; the four-wavefront kernel ran at 41 % of
+// its VALU issue rate).
 template <bool BAO, int PHASE, int NW = kInitNW>
 __global__ __launch_bounds__(64 * NW, NW == 1 ? 4 : 1) void k_epoch_probe(
     chomp_config cfg, Epoch* __restrict__ epochs, double* __restrict__ search,
