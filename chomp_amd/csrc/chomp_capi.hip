@@ -682,10 +682,27 @@ int chomp_get_status(chomp_ctx* ctx, size_t epoch0, size_t n, unsigned* out) {
 // the finalising blocks of the halo set-ups write (sequence number << 32 | word) into in turn
 // (known to the kernels through ctx->L), and h_status, where a post without a mirror is copied.
 // Not under stream capture (an allocation): returns OK with the words as they are.
+static int mirror_collect(chomp_ctx* ctx, int half, unsigned seq, size_t epoch0, size_t n,
+                          unsigned* out);
 static int ensure_hstatus(chomp_ctx* ctx) {
   if (ctx->n_epoch <= ctx->cap_hstatus && ctx->h_status && ctx->h_mirror) return CHOMP_OK;
   if (capturing(ctx)) return CHOMP_OK;
   HIPCHK(hipStreamSynchronize(ctx->stream));       // (a copy or a kernel's mirror may be in flight)
+  // (a post nobody has waited for yet survives the reallocation: its words are there now)
+  if (ctx->posted_kind == 1 || ctx->posted_kind == 2) {
+    const size_t np = ctx->n_hstatus;
+    std::vector<unsigned> keep(np);
+    if (ctx->posted_kind == 1) {
+      const int rcc = mirror_collect(ctx, ctx->posted_half, ctx->posted_seq, 0, np, keep.data());
+      if (rcc) return rcc;
+    } else {
+      std::memcpy(keep.data(), ctx->h_status, np * sizeof(unsigned));
+    }
+    ctx->posted_saved.swap(keep);
+    ctx->posted_kind = 3;
+  }
+  const int kept_kind = ctx->posted_kind;
+  const size_t kept_n = ctx->n_hstatus;
   if (ctx->graph_seen) {
     if (ctx->h_status) ctx->host_graveyard.push_back(ctx->h_status);
     if (ctx->h_mirror) ctx->host_graveyard.push_back(ctx->h_mirror);
@@ -697,8 +714,8 @@ static int ensure_hstatus(chomp_ctx* ctx) {
   ctx->h_mirror = nullptr;
   ctx->L.h_status = nullptr;
   ctx->cap_hstatus = 0;
-  ctx->posted_kind = 0;
-  ctx->n_hstatus = 0;
+  ctx->posted_kind = kept_kind == 3 ? 3 : 0;
+  ctx->n_hstatus = kept_kind == 3 ? kept_n : 0;
   HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_status), ctx->n_epoch * sizeof(unsigned),
                        hipHostMallocDefault));
   HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_mirror),

@@ -237,6 +237,13 @@ def test_posted_status_is_the_status_and_warns_when_looked_at():
     assert list(hg.ctx.status_wait(1, 1)) == [now[1]]
     hg.ctx.status_post()                     # ... and the next post is the last set-up's
     assert list(hg.ctx.status_wait(0, 2)) == [0, 0]
+    # ... nor when the batch grows and the pinned words are reallocated under an unread post
+    hg.setup("power_gm")
+    hg.ctx.status_post()
+    wide = grid.HaloGrid(numpy.linspace(0.0, 1.0, 9))
+    hg.ctx.epochs_set(wide._c_cosmo, wide._z)
+    assert list(hg.ctx.status_wait(0, 2)) == list(now)
+    hg.ctx.epochs_set(hg._c_cosmo, hg._z)
     # a post behind a set-up that did not end in a halo set-up (mass function only) is a copy
     hg.ctx.epochs_set(hg._c_cosmo, hg._z)
     hg.ctx.status_post()
