@@ -1,6 +1,7 @@
 """Randomised parity soak: device P_mm / P_gm against the oracle for random cosmologies,
 HODs and redshifts (not part of the test suite: the oracle takes seconds per case).
-    python tools/soak.py [seed] [n] [n_gm]      (n_gm: how many of the cases also compare P_gm, default 6)
+    python tools/soak.py [seed] [n] [n_gm] [st|tinker]   (n_gm: how many of the cases also compare P_gm and P_gg,
+                                                          default 6; the mass function, default st)
 Exit code 1 if any epoch that the status word does not flag differs by more than 1e-4."""
 import os, sys, time, numpy
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
@@ -24,23 +25,26 @@ for i in range(n):
     h["sigma"] = rng.uniform(0.1, 0.4); h["log_M_1p"] = h["log_M_min"] + rng.uniform(1.0, 1.5)
     hods.append(h)
 t = time.time()
-g = grid.HaloGrid(numpy.array(zs), cosmo_dict=cos, hod_dict=hods)
+kind = sys.argv[4] if len(sys.argv) > 4 else "st"
+g = grid.HaloGrid(numpy.array(zs), cosmo_dict=cos, hod_dict=hods, mass_function=kind)
 pm = g.power("power_mm", k)
 from chomp_amd import _lib
 status = g.status()
 n_gm = min(n, int(sys.argv[3]) if len(sys.argv) > 3 else 6)
 pg = g.power("power_gm", k)
+pgg = g.power("power_gg", k)
 worst, n_flag, n_unflagged_bad = 0.0, 0, 0
 for i in range(n):
     e = o.epoch(cos[i], float(zs[i]))
-    fam = ("mm", "gm") if i < n_gm else ("mm",)
-    tb = o.halo_table(e, o.mass_table(e), o.zheng(hods[i]), families=fam)
+    fam = ("mm", "gm", "gg") if i < n_gm else ("mm",)
+    tb = o.halo_table(e, o.mass_table(e, kind=kind), o.zheng(hods[i]), families=fam)
     err = numpy.max(numpy.abs(pm[i] / o.halo_power(tb, "mm", k) - 1))
     msg = "case %2d z=%.3f  mm %.2e" % (i, zs[i], err)
     if i < n_gm:
         eg = numpy.max(numpy.abs(pg[i] / o.halo_power(tb, "gm", k) - 1))
-        msg += "  gm %.2e" % eg
-        err = max(err, eg)
+        egg = numpy.max(numpy.abs(pgg[i] / o.halo_power(tb, "gg", k) - 1))
+        msg += "  gm %.2e  gg %.2e" % (eg, egg)
+        err = max(err, eg, egg)
     flagged = bool(status[i] & (_lib.ST_SATURATED | _lib.ST_MASS_SEARCH_EXHAUSTED))
     if flagged:
         msg += "  FLAGGED (status 0x%x: saturated mass-limit search)" % int(status[i])
