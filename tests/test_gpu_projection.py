@@ -379,8 +379,8 @@ def test_projection_step_replays_from_a_hip_graph(mods, ggl):
 def test_projection_soak_seed():
     """One seed of tools/soak_proj.py as a test: w(theta) and C_l of the drop-in classes for
     random cosmologies, magnitude-limited surveys and Zheng HODs -- two clustering set-ups with
-    P_gg, two lensing set-ups with P_gm, none of them the fixtures' -- against the oracle at three
-    theta and three l each (84 cases over three seeds: 4e-10)."""
+    P_gg, two lensing set-ups with P_gm (one of them through HaloFit), none of them the fixtures'
+    -- against the oracle at three theta and three l each (108 cases over four seeds: 4e-10)."""
     import os, sys
     from conftest import ROOT
     sys.path.insert(0, os.path.join(ROOT, "tools"))

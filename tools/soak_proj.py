@@ -47,7 +47,11 @@ def _case(rng, case, d2r, verbose):
         else:
             wb = kernel.WindowFunctionGalaxy(kernel.dNdzMagLim(0.0, 2.0, 2.0, z0, b), cm)
             kern = kernel.Kernel(1e-6 * d2r, 100.0 * d2r, wa, wb, cm)
-        h = halo.Halo(0.0, input_hod=hod.HODZheng(hd), cosmo_single_epoch=cosmology.SingleEpoch(0.0, c))
+        hf = case % 4 == 3          # HaloFit spectra (configs[4]'s kind), coefficients from z = 0 as there
+        hcls = halo.HaloFit if hf else halo.Halo
+        h = hcls(0.0, input_hod=hod.HODZheng(hd), cosmo_single_epoch=cosmology.SingleEpoch(0.0, c))
+        if hf:
+            h.power_mm(numpy.array([0.1]))      # (halo.py:1337-1338: the sigma spline is built at the first call)
         corr = correlation.Correlation(0.001, 1.0, kern, input_halo=h, power_spec=ps)
         cf = correlation.CorrelationFourier(10.0, 10000.0, kern, input_halo=h, powSpec=ps)
         w_dev = corr.correlation(theta)
@@ -63,13 +67,18 @@ def _case(rng, case, d2r, verbose):
         t = o.halo_table(e, o.mass_table(e), o.zheng(hd), families=(fam,))
         D_z = float(o.me_growth(me, kt.z_bar))
         power = lambda k: o.halo_power(t, fam, k)
+        if hf:
+            e0 = o.epoch(c, 0.0)
+            t0 = o.halo_table(e0, o.mass_table(e0), o.zheng(hd), families=("mm",))
+            t.hf = o.halofit_table(t0)
+            power = lambda k: o.halofit_power(t, fam, k)
         w_ref = o.wtheta(kt, power, theta, t.k_min, t.k_max, D_z)
         c_ref = o.cell(kt, power, ell, D_z)
         ew = float(numpy.max(numpy.abs(w_dev / w_ref - 1)))
         ec = float(numpy.max(numpy.abs(c_dev / c_ref - 1)))
         if verbose:
-            print("case %d %s z0=%.3f b=%.1f z_bar %.4f (dev %.4f)  w %.2e  C_l %.2e  status 0x%x" % (
-                case, ps, z0, b, kt.z_bar, kern.z_bar, ew, ec, h.status), flush=True)
+            print("case %d %s%s z0=%.3f b=%.1f z_bar %.4f (dev %.4f)  w %.2e  C_l %.2e  status 0x%x" % (
+                case, ps, " HaloFit" if hf else "", z0, b, kt.z_bar, kern.z_bar, ew, ec, h.status), flush=True)
         return max(ew, ec)
 
 
