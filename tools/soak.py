@@ -1,7 +1,8 @@
 """Randomised parity soak: device P_mm / P_gm against the oracle for random cosmologies,
 HODs and redshifts (not part of the test suite: the oracle takes seconds per case).
-    python tools/soak.py [seed] [n] [n_gm] [st|tinker]   (n_gm: how many of the cases also compare P_gm and P_gg,
-                                                          default 6; the mass function, default st)
+    python tools/soak.py [seed] [n] [n_gm] [st|tinker] [alpha]   (n_gm: how many of the cases also compare P_gm and P_gg,
+                                                          default 6; the mass function, default st;
+                                                          "alpha": the satellites' power-law index drawn from [0.8, 1.3] too)
 Exit code 1 if any epoch that the status word does not flag differs by more than 1e-4."""
 import os, sys, time, numpy
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
@@ -24,6 +25,10 @@ for i in range(n):
     h["log_M_min"] = rng.uniform(11.8, 12.6); h["log_M_0"] = h["log_M_min"]
     h["sigma"] = rng.uniform(0.1, 0.4); h["log_M_1p"] = h["log_M_min"] + rng.uniform(1.0, 1.5)
     hods.append(h)
+if len(sys.argv) > 5 and sys.argv[5] == "alpha":
+    rng_a = numpy.random.default_rng(1000 + (int(sys.argv[1]) if len(sys.argv) > 1 else 7))
+    for h in hods:
+        h["alpha"] = float(rng_a.uniform(0.8, 1.3))
 t = time.time()
 kind = sys.argv[4] if len(sys.argv) > 4 else "st"
 g = grid.HaloGrid(numpy.array(zs), cosmo_dict=cos, hod_dict=hods, mass_function=kind)
