@@ -33,6 +33,10 @@ constexpr double kE = 2.71828182845904523536;
 // three vector instructions, and 20 of the 75 of a sigma(R) table node were such moves.
 // v_fma_f64 with the addend in SGPRs is one; the two s_mov_b32 that fill them go to the scalar
 // unit, which issues beside the vector pipeline.  Same operation, same bits.
+// (The hazard recogniser does not look inside an asm statement: a and b must not be the direct
+//  result of a transcendental instruction -- v_rcp / v_sqrt / v_rsq_f64 need a wait state before a
+//  non-transcendental reader on gfx940+ -- and d must not be read by a DPP instruction right
+//  behind it.  Every use here takes products and polynomial partial sums.)
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ double fma_k(double a, double b, double c) {
   double d;
