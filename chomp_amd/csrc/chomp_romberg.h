@@ -35,8 +35,8 @@ namespace chomp {
 // per 32-bit half, ~10x the latency).
 template <int CTRL>
 __device__ __forceinline__ double dpp_move(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double readlane_d(double v, int lane) {
